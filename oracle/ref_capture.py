@@ -1,0 +1,341 @@
+"""Golden-vector capture from the UNMODIFIED reference (build container only).
+
+Runs ``/root/reference``'s ``pikazoo_v0`` in-process, with
+
+* in-memory stand-ins for the three third-party imports that are not installed here
+  (``gymnasium``, ``pettingzoo``, ``pygame`` -- none of them is on the step path), and
+* the env RNG injected through the stubbed ``gymnasium.utils.seeding.np_random``: a
+  duck-typed object exposing ``integers(lo, hi)`` that yields the build's Philox stream
+  (draw index = number of ``integers`` calls so far, i.e. the reference's own call order),
+
+and writes small ``.npz`` fixtures under ``tests/golden/``.  Nothing of the reference is
+copied: the fixtures hold inputs (actions, seeds, kwargs) and outputs (state words read
+from the reference's attributes, observations, rewards, terminations) only.
+
+Usage (here, not on the GPU box -- /root/reference does not exist there):
+    python oracle/ref_capture.py            # regenerate every fixture
+TEST INFRASTRUCTURE: not imported by the product.
+"""
+from __future__ import annotations
+
+import json
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+
+sys.dont_write_bytecode = True  # the reference mount is read-only
+_HERE = Path(__file__).resolve().parent
+_REPO = _HERE.parent
+if str(_REPO) not in sys.path:
+    sys.path.insert(0, str(_REPO))
+
+from oracle import pz_oracle as po  # noqa: E402
+
+REFERENCE_ROOT = Path("/root/reference")
+GOLDEN = _REPO / "tests" / "golden"
+
+
+# --------------------------------------------------------------------------------------
+# RNG shim + third-party stand-ins
+# --------------------------------------------------------------------------------------
+class PhiloxShim:
+    """Duck-typed stand-in for ``numpy.random.Generator``: only ``integers`` is ever called
+    by the reference (physics.py:218,613,728,729,795; pikazoo_env.py:246)."""
+
+    def __init__(self, seed: int, env_id: int):
+        self.seed = seed
+        self.env_id = env_id
+        self.counter = 0
+
+    def integers(self, low, high=None):
+        if high is None:
+            low, high = 0, low
+        assert low == 0
+        v = po.env_draw(self.seed, self.env_id, self.counter, int(high))
+        self.counter += 1
+        return np.int64(v)  # numpy returns np.int64 for scalar draws
+
+
+_NEXT_SHIM: list = []
+
+
+def _np_random_stub(seed=None):
+    shim = _NEXT_SHIM.pop() if _NEXT_SHIM else PhiloxShim(0, 0)
+    return shim, seed
+
+
+def install_stubs():
+    if "gymnasium" in sys.modules and getattr(sys.modules["gymnasium"], "_pz_stub", False):
+        return
+    gym = types.ModuleType("gymnasium")
+    gym._pz_stub = True
+    spaces = types.ModuleType("gymnasium.spaces")
+
+    class Space:
+        pass
+
+    class Discrete(Space):
+        def __init__(self, n):
+            self.n = n
+
+    class Box(Space):
+        def __init__(self, low, high, shape=None, dtype=None):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+    spaces.Space, spaces.Discrete, spaces.Box = Space, Discrete, Box
+    utils = types.ModuleType("gymnasium.utils")
+    seeding = types.ModuleType("gymnasium.utils.seeding")
+    seeding.np_random = _np_random_stub
+    utils.seeding = seeding
+    logger = types.ModuleType("gymnasium.logger")
+    logger.warn = lambda *a, **k: None
+    gym.spaces, gym.utils, gym.logger = spaces, utils, logger
+
+    pz = types.ModuleType("pettingzoo")
+
+    class ParallelEnv:
+        pass
+
+    pz.ParallelEnv = ParallelEnv
+    pz_utils = types.ModuleType("pettingzoo.utils")
+    pz_utils_env = types.ModuleType("pettingzoo.utils.env")
+    pz_utils_env.ParallelEnv = ParallelEnv
+
+    class BaseParallelWrapper(ParallelEnv):
+        """Behavioural stand-in: stores env, forwards reset/step and attribute access."""
+
+        def __init__(self, env):
+            self.env = env
+
+        def __getattr__(self, name):
+            if name == "env":
+                raise AttributeError(name)
+            return getattr(self.env, name)
+
+        def reset(self, seed=None, options=None):
+            return self.env.reset(seed=seed, options=options)
+
+        def step(self, actions):
+            return self.env.step(actions)
+
+        def observation_space(self, agent):
+            return self.env.observation_space(agent)
+
+        def action_space(self, agent):
+            return self.env.action_space(agent)
+
+    pz_utils.BaseParallelWrapper = BaseParallelWrapper
+    pz_utils.env = pz_utils_env
+    pz.utils = pz_utils
+
+    pygame = types.ModuleType("pygame")
+
+    sys.modules.update({
+        "gymnasium": gym, "gymnasium.spaces": spaces, "gymnasium.utils": utils,
+        "gymnasium.utils.seeding": seeding, "gymnasium.logger": logger,
+        "pettingzoo": pz, "pettingzoo.utils": pz_utils, "pettingzoo.utils.env": pz_utils_env,
+        "pygame": pygame,
+    })
+    if str(REFERENCE_ROOT) not in sys.path:
+        sys.path.insert(0, str(REFERENCE_ROOT))
+
+
+def reference_available() -> bool:
+    return (REFERENCE_ROOT / "pikazoo" / "env" / "physics.py").exists()
+
+
+def make_reference_env(seed: int, env_id: int, wrappers: dict | None = None, **kwargs):
+    """Construct the unmodified reference env with the Philox stream injected.
+
+    Draw indices 0,1 are consumed by the constructor (physics.py:120-121 -> :218)."""
+    install_stubs()
+    from pikazoo import pikazoo_v0  # the reference package
+
+    shim = PhiloxShim(seed, env_id)
+    _NEXT_SHIM.append(shim)
+    raw = pikazoo_v0.env(**kwargs)
+    assert raw.np_random is shim and raw.physics.np_random is shim
+    assert raw.physics.player1.np_random is shim and raw.physics.player2.np_random is shim
+    env = raw
+    wrappers = wrappers or {}
+    if wrappers.get("simplify_action"):
+        from pikazoo.wrappers import SimplifyAction
+        env = SimplifyAction(env)
+    if wrappers.get("additional_reward") is not None:
+        from pikazoo.wrappers import RewardByBallPosition
+        env = RewardByBallPosition(env, tuple(wrappers["additional_reward"]),
+                                   wrappers.get("x_line", 216), wrappers.get("y_line", 176))
+    return env, raw, shim
+
+
+def extract_state(raw, shim) -> np.ndarray:
+    """Read the W=44 persistent words from the reference objects' attributes."""
+    s = np.zeros(po.W, np.int64)
+    for base, pl, kb in ((0, raw.physics.player1, raw.keyboard_array[0]),
+                         (po.P_WORDS, raw.physics.player2, raw.keyboard_array[1])):
+        s[base + po.P_X] = pl.x
+        s[base + po.P_Y] = pl.y
+        s[base + po.P_YVEL] = pl.y_velocity
+        s[base + po.P_STATE] = pl.state
+        s[base + po.P_FRAME] = pl.frame_number
+        s[base + po.P_ARM_SWING] = pl.normal_status_arm_swing_direction
+        s[base + po.P_DELAY] = pl.delay_before_next_frame
+        s[base + po.P_DIVING_DIR] = pl.diving_direction
+        s[base + po.P_LYING_DOWN] = pl.lying_down_duration_left
+        s[base + po.P_COLLISION] = int(pl.is_collision_with_ball_happened)
+        s[base + po.P_BOLDNESS] = pl.computer_boldness
+        s[base + po.P_STAND_BY] = pl.computer_where_to_stand_by
+        s[base + po.P_HIT_KEY_PREV] = int(kb.power_hit_key_is_down_previous)
+    b = raw.physics.ball
+    s[po.B_X], s[po.B_Y], s[po.B_XVEL], s[po.B_YVEL] = b.x, b.y, b.x_velocity, b.y_velocity
+    s[po.B_POWER_HIT] = int(b.is_power_hit)
+    s[po.B_PREV_X], s[po.B_PREV_Y] = b.previous_x, b.previous_y
+    s[po.B_PPREV_X], s[po.B_PPREV_Y] = b.previous_previous_x, b.previous_previous_y
+    s[po.B_FINE_ROT] = b.fine_rotation
+    s[po.B_EXPECTED_X] = b.expected_landing_point_x
+    s[po.B_PUNCH_X] = b.punch_effect_x
+    s[po.E_SCORE1], s[po.E_SCORE2] = raw.scores
+    s[po.E_P2_SERVE] = int(raw.is_player2_serve)
+    s[po.E_ROUND_ENDED] = int(raw.round_ended)
+    s[po.E_GAME_ENDED] = int(raw.game_ended)
+    s[po.E_RNG_COUNTER] = shim.counter
+    return s
+
+
+# --------------------------------------------------------------------------------------
+# capture
+# --------------------------------------------------------------------------------------
+def capture(name: str, lanes: int, steps: int, seed: int, action_seed: int, env_id_base: int,
+            env_kwargs: dict, wrappers: dict | None = None, full: bool = True,
+            digest_every: int = 0) -> dict:
+    """Run `lanes` reference envs for `steps` steps under the random policy.
+
+    full=True stores every state/obs/reward; digest_every>0 stores one 64-bit digest of the
+    [W, lanes] state matrix every that many steps instead (long runs for rare branches)."""
+    wrappers = wrappers or {}
+    n_actions = 13 if wrappers.get("simplify_action") else 18
+    fused_reward = wrappers.get("additional_reward") is not None
+    envs = [make_reference_env(seed, env_id_base + i, wrappers, **env_kwargs) for i in range(lanes)]
+    state_ctor = np.stack([extract_state(raw, shim) for _, raw, shim in envs], axis=1)
+    obs_reset = np.zeros((lanes, 2, po.OBS), np.int64)
+    for i, (env, raw, shim) in enumerate(envs):
+        obs, infos = env.reset(seed=1234 + i)  # the reference ignores seed (pikazoo_env.py:149)
+        obs_reset[i, 0], obs_reset[i, 1] = obs["player_1"], obs["player_2"]
+        assert set(infos) == {"player_1", "player_2"}
+    state0 = np.stack([extract_state(raw, shim) for _, raw, shim in envs], axis=1)
+
+    out = dict(state_ctor=state_ctor.astype(np.int32), state0=state0.astype(np.int32),
+               obs_reset=obs_reset.astype(np.int32))
+    if full:
+        actions = np.zeros((steps, 2, lanes), np.int32)
+        states = np.zeros((steps, po.W, lanes), np.int32)
+        obs_all = np.zeros((steps, 2, lanes, po.OBS), np.int32)
+        rew = np.zeros((steps, 2, lanes), np.float64)
+        term = np.zeros((steps, lanes), np.uint8)
+    digests = []
+    cur = np.zeros((po.W, lanes), np.int32)
+    episodes = 0
+    for t in range(steps):
+        a1, a2 = po.random_actions(lanes, env_id_base, action_seed, t, n_actions)
+        for i, (env, raw, shim) in enumerate(envs):
+            if not raw.agents:  # harness auto-reset: reset() right before the next step
+                env.reset()
+            obs, rews, terms, truncs, infos = env.step({"player_1": int(a1[i]), "player_2": int(a2[i])})
+            assert not any(truncs.values())
+            assert terms["player_1"] == terms["player_2"]
+            cur[:, i] = extract_state(raw, shim)
+            episodes += int(terms["player_1"])
+            if full:
+                obs_all[t, 0, i], obs_all[t, 1, i] = obs["player_1"], obs["player_2"]
+                rew[t, 0, i], rew[t, 1, i] = rews["player_1"], rews["player_2"]
+                term[t, i] = int(terms["player_1"])
+                if not fused_reward:
+                    assert isinstance(rews["player_1"], int)
+        if full:
+            actions[t, 0], actions[t, 1] = a1, a2
+            states[t] = cur
+        if digest_every and (t + 1) % digest_every == 0:
+            digests.append(po.digest(cur))
+    meta = dict(name=name, lanes=lanes, steps=steps, seed=seed, action_seed=action_seed,
+                env_id_base=env_id_base, env_kwargs=env_kwargs, wrappers=wrappers,
+                n_actions=n_actions, episodes=episodes, digest_every=digest_every,
+                fields=po.FIELD_NAMES)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    if full:
+        out.update(actions=actions.astype(np.uint8), states=states.astype(np.int16),
+                   rng_counter=states[:, po.E_RNG_COUNTER, :].astype(np.int32),
+                   obs=obs_all.astype(np.int16), term=term,
+                   rew=(rew if fused_reward else rew.astype(np.int8)))
+        assert np.array_equal(out["states"].astype(np.int32)[:, :po.E_RNG_COUNTER],
+                              states[:, :po.E_RNG_COUNTER])  # int16 is lossless here
+    if digest_every:
+        out["digests"] = np.array(digests, dtype=np.uint64)
+        out["final_state"] = cur.copy()
+    return out
+
+
+TEST_TABLE = (0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01)
+INT_TABLE = (1, -2, 3, -4, 5, -6, 7, -8)
+
+FIXTURES = [
+    # name, lanes, steps, env_kwargs, wrappers
+    ("cfg2_human_human", 6, 3000, dict(winning_score=15, serve="winner"), None),
+    ("cfg3_p2_computer", 6, 3000, dict(winning_score=15, serve="winner", is_player2_computer=True), None),
+    ("p1_computer", 4, 2000, dict(winning_score=15, serve="winner", is_player1_computer=True), None),
+    ("both_computer", 4, 3000, dict(winning_score=15, is_player1_computer=True, is_player2_computer=True), None),
+    ("serve_alternate", 4, 2000, dict(winning_score=15, serve="alternate"), None),
+    ("serve_random", 4, 2000, dict(winning_score=15, serve="random", is_player2_computer=True), None),
+    ("winning_score_1", 4, 1000, dict(winning_score=1, serve="winner"), None),
+    ("winning_score_3", 4, 1500, dict(winning_score=3, serve="alternate", is_player2_computer=True), None),
+    ("cfg5_wrappers_float", 6, 3000, dict(winning_score=15, serve="winner"),
+     dict(simplify_action=True, additional_reward=TEST_TABLE, x_line=216, y_line=176)),
+    ("wrappers_int_table", 4, 1500, dict(winning_score=5, serve="winner", is_player2_computer=True),
+     dict(simplify_action=True, additional_reward=INT_TABLE, x_line=200, y_line=150)),
+    ("simplify_only", 4, 1500, dict(winning_score=15, serve="winner"), dict(simplify_action=True)),
+]
+
+DIGEST_RUNS = [
+    ("digest_human_human", 48, 20000, dict(winning_score=15, serve="winner"), None),
+    ("digest_p2_computer", 48, 20000, dict(winning_score=15, serve="winner", is_player2_computer=True), None),
+    ("digest_both_computer_random_serve", 32, 20000,
+     dict(winning_score=5, serve="random", is_player1_computer=True, is_player2_computer=True), None),
+]
+
+
+def main(argv=None):
+    import argparse
+    import time
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--skip-digests", action="store_true")
+    args = ap.parse_args(argv)
+    assert reference_available(), "the reference is only mounted in the build container"
+    GOLDEN.mkdir(parents=True, exist_ok=True)
+    for k, (name, lanes, steps, kw, wr) in enumerate(FIXTURES):
+        if args.only and args.only != name:
+            continue
+        t0 = time.time()
+        data = capture(name, lanes, steps, seed=20241008 + k, action_seed=77 + k,
+                       env_id_base=1000 * k, env_kwargs=kw, wrappers=wr, full=True)
+        np.savez_compressed(GOLDEN / f"{name}.npz", **data)
+        meta = json.loads(bytes(data["meta"]).decode())
+        print(f"{name}: {lanes}x{steps} episodes={meta['episodes']} "
+              f"{(GOLDEN / (name + '.npz')).stat().st_size / 1e3:.0f} kB {time.time() - t0:.1f}s")
+    if not args.skip_digests:
+        for k, (name, lanes, steps, kw, wr) in enumerate(DIGEST_RUNS):
+            if args.only and args.only != name:
+                continue
+            t0 = time.time()
+            data = capture(name, lanes, steps, seed=555 + k, action_seed=999 + k,
+                           env_id_base=(1 << 33) + 64 * k if k == 2 else 50000 * (k + 1),
+                           env_kwargs=kw, wrappers=wr, full=False, digest_every=500)
+            np.savez_compressed(GOLDEN / f"{name}.npz", **data)
+            meta = json.loads(bytes(data["meta"]).decode())
+            print(f"{name}: {lanes}x{steps} episodes={meta['episodes']} {time.time() - t0:.1f}s")
+
+
+if __name__ == "__main__":
+    main()
