@@ -1,0 +1,139 @@
+/*
+ * pikazoo_hip.h -- C ABI of libpikazoo_hip.so, the MI355X (gfx950) batched Pikachu-Volleyball
+ * step path.  Plain pointers and sizes only: no torch / HIP types in the signatures
+ * (`stream` is a hipStream_t passed as void*; NULL = the default stream).
+ *
+ * The reference (helpingstar/pika-zoo) has no FFI layer: the path sits behind the
+ * PettingZoo ParallelEnv Python API of `pikazoo_v0.env()` (pikazoo/env/pikazoo_env.py:72-240).
+ * Each entry point below names the reference interface it replaces; INTEGRATION.md shows the
+ * ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - every buffer is device memory owned by the caller (torch tensors in the Python host);
+ *    the library allocates nothing persistent and keeps no global state, so calls on
+ *    distinct state buffers are thread-safe;
+ *  - all calls are asynchronous on `stream`;
+ *  - return value: 0 = ok, negative = PZ_E_* argument error, positive = hipError_t;
+ *  - state is int32[PZ_STATE_WORDS][stride], field-major (structure of arrays): lane i
+ *    (one independent game) owns column i; `n` lanes are live, stride >= n;
+ *  - observations are int32[n][35] row-major per agent (pikazoo_env.py:576-624);
+ *  - out-of-range actions are undefined behaviour here (the reference raises IndexError at
+ *    pikazoo_env.py:182); the Python host validates them unless told not to.
+ */
+#ifndef PIKAZOO_HIP_H
+#define PIKAZOO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PZ_ABI_VERSION 1
+#define PZ_STATE_WORDS 44
+#define PZ_OBS_DIM 35
+
+/* ---- state columns ------------------------------------------------------------------- */
+/* player block (13 words): player 1 at 0, player 2 at 13.
+ * Player attributes physics.py:159-218; power_hit_key_is_down_previous physics.py:51 */
+enum pz_player_field {
+    PZ_P_X = 0, PZ_P_Y, PZ_P_Y_VELOCITY, PZ_P_STATE, PZ_P_FRAME_NUMBER,
+    PZ_P_ARM_SWING_DIRECTION, PZ_P_DELAY_BEFORE_NEXT_FRAME, PZ_P_DIVING_DIRECTION,
+    PZ_P_LYING_DOWN_DURATION_LEFT, PZ_P_IS_COLLISION_WITH_BALL_HAPPENED,
+    PZ_P_COMPUTER_BOLDNESS, PZ_P_COMPUTER_WHERE_TO_STAND_BY,
+    PZ_P_POWER_HIT_KEY_IS_DOWN_PREVIOUS, PZ_P_WORDS
+};
+/* ball block (12 words) at 26: physics.py:232-277 */
+enum pz_ball_field {
+    PZ_B_X = 26, PZ_B_Y, PZ_B_X_VELOCITY, PZ_B_Y_VELOCITY, PZ_B_IS_POWER_HIT,
+    PZ_B_PREVIOUS_X, PZ_B_PREVIOUS_Y, PZ_B_PREVIOUS_PREVIOUS_X, PZ_B_PREVIOUS_PREVIOUS_Y,
+    PZ_B_FINE_ROTATION, PZ_B_EXPECTED_LANDING_POINT_X, PZ_B_PUNCH_EFFECT_X
+};
+/* env block (6 words) at 38: pikazoo_env.py:100-111 + the RNG draw counter */
+enum pz_env_field {
+    PZ_E_SCORE_P1 = 38, PZ_E_SCORE_P2, PZ_E_IS_PLAYER2_SERVE, PZ_E_ROUND_ENDED,
+    PZ_E_GAME_ENDED, PZ_E_RNG_DRAW_COUNTER
+};
+
+enum pz_serve_mode { PZ_SERVE_WINNER = 0, PZ_SERVE_ALTERNATE = 1, PZ_SERVE_RANDOM = 2 };
+
+enum pz_error {
+    PZ_OK = 0,
+    PZ_E_NULL = -1,       /* a required pointer is NULL */
+    PZ_E_SIZE = -2,       /* n < 0, stride < n, k < 1 ... */
+    PZ_E_CONFIG = -3,     /* config field out of range */
+    PZ_E_ALIGN = -4       /* buffer not 16-byte aligned */
+};
+
+/* Constructor kwargs of pikazoo_v0.env (pikazoo_env.py:79-86) + the two fused wrappers
+ * (wrappers/simplify_action.py:16-25, wrappers/reward_by_ball_position.py:7-31) + the
+ * batched-env additions (auto_reset, seed, env_id_base). POD, 88 bytes, passed by pointer
+ * from the host and by value to the kernels. */
+typedef struct pz_config {
+    int32_t winning_score;        /* >= 1 */
+    int32_t serve_mode;           /* enum pz_serve_mode */
+    int32_t p1_computer;          /* is_player1_computer */
+    int32_t p2_computer;          /* is_player2_computer */
+    int32_t simplify_action;      /* 1: actions are Discrete(13), remapped per side */
+    int32_t ballpos_reward;       /* 1: rewards are float32 and include additional_reward */
+    int32_t x_line;               /* RewardByBallPosition x_line (default 216) */
+    int32_t y_line;               /* RewardByBallPosition y_line (default 176) */
+    float   additional_reward[8]; /* [0..3] player_1 zones, [4..7] player_2 zones */
+    int32_t auto_reset;           /* 1: a finished game is reset() in place before its next frame */
+    int32_t reserved;
+    uint64_t seed;                /* Philox4x32-10 key of the env RNG stream */
+    int64_t env_id_base;          /* global id of lane 0 (shards of one job use disjoint ranges) */
+} pz_config;
+
+/* ---- introspection -------------------------------------------------------------------- */
+int pz_abi_version(void);
+int pz_state_words(void);           /* = PZ_STATE_WORDS */
+int pz_obs_dim(void);               /* = PZ_OBS_DIM */
+int pz_config_bytes(void);          /* = sizeof(pz_config), for binding self-checks */
+const char *pz_error_string(int code);
+
+/* ---- raw_env.__init__ : pikazoo_env.py:79-141 -> PikaPhysics physics.py:107-123 ---------
+ * Fresh state for n games; consumes env-RNG draws 0,1 (the two boldness draws). */
+int pz_init(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg, void *stream);
+
+/* ---- raw_env.reset : pikazoo_env.py:149-173 ---------------------------------------------
+ * reset() semantics in place on lanes with mask[i] != 0 (mask == NULL: every lane); scores,
+ * flags and per-round fields are re-initialised, carry-over fields are kept, draws continue
+ * from the lane's counter.  Observations of ALL lanes are written (obs_* may be NULL). */
+int pz_reset(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
+             const uint8_t *mask, int32_t *obs_p1, int32_t *obs_p2, void *stream);
+
+/* ---- raw_env._get_obs : pikazoo_env.py:576-624 ------------------------------------------ */
+int pz_observe(const int32_t *state, int64_t n, int64_t stride,
+               int32_t *obs_p1, int32_t *obs_p2, void *stream);
+
+/* ---- raw_env.step : pikazoo_env.py:175-240 (one frame of every game, one launch) ---------
+ * act_p1/act_p2: int32[n] in [0,18) (or [0,13) with simplify_action).
+ * rew_p1/rew_p2: int32[n] (+1/-1/0), or float32[n] when cfg->ballpos_reward.
+ * terminated:    uint8[n] = game_ended after this frame (terminations of both agents);
+ *                truncations are always False in the reference (:234) and are not written. */
+int pz_step(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
+            const int32_t *act_p1, const int32_t *act_p2,
+            int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
+            uint8_t *terminated, void *stream);
+
+/* ---- the same frame with the uniform random policy drawn on device ----------------------
+ * actions of game g at step t come from Philox4x32-10(key=action_seed,
+ * ctr=(g.lo, g.hi, t.lo, 1 + 2*t.hi)): words 0/1 -> player 1/2, bounded by (u32*n_act)>>32.
+ * k >= 1 frames are run back to back inside ONE launch with the state held in registers
+ * (steps t0 .. t0+k-1); outputs hold the LAST frame, exactly as k calls of pz_step would
+ * leave them.  episodes_done (int64[1], device, may be NULL) is incremented by the number
+ * of games that terminated (atomicAdd; used for the aggregate counters). */
+int pz_step_random(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
+                   uint64_t action_seed, uint64_t t0, int32_t k,
+                   int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
+                   uint8_t *terminated, int64_t *episodes_done, void *stream);
+
+/* ---- the policy stream alone (for hosts that want the actions in HBM) -------------------- */
+int pz_random_actions(int32_t *act_p1, int32_t *act_p2, int64_t n, int64_t env_id_base,
+                      uint64_t action_seed, uint64_t t, int32_t n_actions, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIKAZOO_HIP_H */

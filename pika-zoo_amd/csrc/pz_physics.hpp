@@ -1,0 +1,557 @@
+// pz_physics.hpp -- per-lane game logic of the fused step kernel (device code, gfx950).
+//
+// One lane = one independent Pikachu-Volleyball game held entirely in registers.  All
+// arithmetic is int32; there is no floating point on the path except the optional
+// RewardByBallPosition add.  Written for SIMT: short bodies are predicated selects, the
+// only real loops are the two ball-flight predictors of the rule-based computer player.
+//
+// Behavioural spec: helpingstar/pika-zoo @ 2024_10_08 (citations `file:line` are relative
+// to the reference checkout and name the rule each block implements).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pikazoo_hip.h"
+
+namespace pz {
+
+// pikazoo/env/physics.py:9-33
+constexpr int kGroundWidth = 432;
+constexpr int kGroundHalfWidth = 216;
+constexpr int kPlayerLength = 64;
+constexpr int kPlayerHalfLength = 32;
+constexpr int kPlayerGroundY = 244;
+constexpr int kBallRadius = 20;
+constexpr int kBallGroundY = 252;
+constexpr int kNetPillarHalfWidth = 25;
+constexpr int kNetTopTopY = 176;
+constexpr int kNetTopBottomY = 192;
+constexpr int kLoopLimit = 1000;
+
+struct Player {
+    int x, y, yv, state, frame, arm, delay, dive, lying, coll, bold, standby, hitprev;
+};
+struct Ball {
+    int x, y, xv, yv, power, px, py, ppx, ppy, rot, ex, punch;
+};
+struct Env {
+    int s1, s2, p2serve, round_ended, game_ended;
+    uint32_t rng;  // env-stream draw counter
+};
+struct Game {
+    Player p1, p2;
+    Ball b;
+    Env e;
+};
+struct Input {
+    int xd, yd, hit;
+};
+// per-lane RNG identity (Philox counter words 0,1 and key)
+struct RngId {
+    uint32_t id_lo, id_hi, k0, k1;
+};
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  Only words 0 and 1 of the output block are used.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t& o0, uint32_t& o1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o0 = c0;
+    o1 = c1;
+}
+
+// np_random.integers(0, n): draw number `counter` of this game's env stream
+// (ctr = (id.lo, id.hi, counter, 0)), bounded by (u32 * n) >> 32; one draw = one tick.
+__device__ __forceinline__ int rng_integers(const RngId& id, uint32_t& counter, uint32_t n)
+{
+    uint32_t o0, o1;
+    philox4x32_10(id.id_lo, id.id_hi, counter, 0u, id.k0, id.k1, o0, o1);
+    counter += 1;
+    return (int)__umulhi(o0, n);
+}
+
+// uniform random policy: both players' actions of one game at step t
+__device__ __forceinline__ void policy_actions(uint32_t id_lo, uint32_t id_hi, uint64_t action_seed,
+                                               uint64_t t, uint32_t n_actions, int& a1, int& a2)
+{
+    uint32_t o0, o1;
+    philox4x32_10(id_lo, id_hi, (uint32_t)t, 1u + 2u * (uint32_t)(t >> 32), (uint32_t)action_seed,
+                  (uint32_t)(action_seed >> 32), o0, o1);
+    a1 = (int)__umulhi(o0, n_actions);
+    a2 = (int)__umulhi(o1, n_actions);
+}
+
+// ---------------------------------------------------------------------------------------
+// Action decode: action id -> (x_direction, y_direction, fire) as packed bit tables, built
+// at compile time from the key rows [left,right,up,down,power_hit] of
+// pikazoo_env.py:119-141 and the precedence rules of PikaUserInput.get_input
+// (physics.py:80-92: left beats right, up beats down; rows have 5 entries so there is no
+// down_right key, :69-70).  Two bits per action for each direction (value+1), one for fire.
+// ---------------------------------------------------------------------------------------
+struct ActionTables {
+    uint64_t xd, yd;
+    uint32_t fire;
+};
+
+constexpr ActionTables make_tables(const int* ids, int count)
+{
+    // keys per action id 0..17, bit0=left bit1=right bit2=up bit3=down bit4=power_hit
+    constexpr int kKeys[18] = {0x00, 0x10, 0x04, 0x02, 0x01, 0x08, 0x06, 0x05, 0x0A,
+                               0x09, 0x14, 0x12, 0x11, 0x18, 0x16, 0x15, 0x1A, 0x19};
+    ActionTables t{0, 0, 0};
+    for (int i = 0; i < count; ++i) {
+        const int k = kKeys[ids[i]];
+        const int xd = (k & 1) ? -1 : ((k & 2) ? 1 : 0);
+        const int yd = (k & 4) ? -1 : ((k & 8) ? 1 : 0);
+        t.xd |= (uint64_t)(xd + 1) << (2 * i);
+        t.yd |= (uint64_t)(yd + 1) << (2 * i);
+        t.fire |= (uint32_t)((k >> 4) & 1) << i;
+    }
+    return t;
+}
+
+constexpr int kAllActions[18] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17};
+// wrappers/simplify_action.py:17-18
+constexpr int kSimplifyP1[13] = {0, 1, 2, 3, 4, 6, 7, 10, 11, 12, 13, 14, 16};
+constexpr int kSimplifyP2[13] = {0, 1, 2, 4, 3, 7, 6, 10, 12, 11, 13, 15, 17};
+constexpr ActionTables kFullTables = make_tables(kAllActions, 18);
+constexpr ActionTables kSimpleTablesP1 = make_tables(kSimplifyP1, 13);
+constexpr ActionTables kSimpleTablesP2 = make_tables(kSimplifyP2, 13);
+
+// get_input (physics.py:59-99): direction decode + power-hit edge detection
+__device__ __forceinline__ Input decode_action(const ActionTables& t, int action, int& hitprev)
+{
+    Input in;
+    const uint32_t sh = (uint32_t)action;
+    in.xd = (int)((t.xd >> (2u * sh)) & 3u) - 1;
+    in.yd = (int)((t.yd >> (2u * sh)) & 3u) - 1;
+    const int fire = (int)((t.fire >> sh) & 1u);
+    in.hit = fire & (hitprev ^ 1);
+    hitprev = fire;
+    return in;
+}
+
+// ---------------------------------------------------------------------------------------
+// Round / game initialisation
+// ---------------------------------------------------------------------------------------
+// Player.initialize_for_new_round (physics.py:181-218); boldness is drawn for humans too.
+__device__ __forceinline__ void player_new_round(Player& p, int x0, const RngId& id, uint32_t& rng)
+{
+    p.x = x0;
+    p.y = kPlayerGroundY;
+    p.yv = 0;
+    p.coll = 0;
+    p.state = 0;
+    p.frame = 0;
+    p.arm = 1;
+    p.delay = 0;
+    p.bold = rng_integers(id, rng, 5u);
+}
+
+// Ball.initialize_for_new_round (physics.py:258-277): only these five fields are touched.
+__device__ __forceinline__ void ball_new_round(Ball& b, int p2_serves)
+{
+    b.x = p2_serves ? kGroundWidth - 56 : 56;
+    b.y = 0;
+    b.xv = 0;
+    b.yv = 1;
+    b.power = 0;
+}
+
+// raw_env.get_server (pikazoo_env.py:242-248); "random": integers(0,2)==0 => player 2 serves
+__device__ __forceinline__ int get_server(const pz_config& cfg, Env& e, const RngId& id)
+{
+    if (cfg.serve_mode == PZ_SERVE_WINNER) return e.p2serve;
+    if (cfg.serve_mode == PZ_SERVE_RANDOM) return rng_integers(id, e.rng, 2u) == 0;
+    return ((e.s1 + e.s2) & 1) == 1;
+}
+
+// players + ball for a new round; shared by reset() (pikazoo_env.py:162-164) and the
+// start-of-step new-round branch (:176-180)
+__device__ __forceinline__ void start_round(Game& g, const pz_config& cfg, const RngId& id)
+{
+    player_new_round(g.p1, 36, id, g.e.rng);
+    player_new_round(g.p2, kGroundWidth - 36, id, g.e.rng);
+    ball_new_round(g.b, get_server(cfg, g.e, id));
+}
+
+// raw_env.__init__ (pikazoo_env.py:96-111 -> physics.py:120-123,159-171,232-249)
+__device__ __forceinline__ void construct_game(Game& g, const RngId& id)
+{
+    g.e.rng = 0;
+    player_new_round(g.p1, 36, id, g.e.rng);
+    player_new_round(g.p2, kGroundWidth - 36, id, g.e.rng);
+    g.p1.dive = g.p2.dive = 0;
+    g.p1.lying = g.p2.lying = -1;
+    g.p1.standby = g.p2.standby = 0;
+    g.p1.hitprev = g.p2.hitprev = 0;
+    ball_new_round(g.b, 0);
+    g.b.px = g.b.py = g.b.ppx = g.b.ppy = 0;
+    g.b.rot = 0;
+    g.b.ex = 0;
+    g.b.punch = 0;
+    g.e.s1 = g.e.s2 = 0;
+    g.e.p2serve = g.e.round_ended = g.e.game_ended = 0;
+}
+
+// raw_env.reset (pikazoo_env.py:149-173): flags + scores cleared, then a new round.  The
+// `seed` argument is ignored by the reference; carry-over fields stay untouched.
+__device__ __forceinline__ void reset_game(Game& g, const pz_config& cfg, const RngId& id)
+{
+    g.e.game_ended = 0;
+    g.e.round_ended = 0;
+    g.e.p2serve = 0;
+    g.e.s1 = 0;
+    g.e.s2 = 0;
+    start_round(g, cfg, id);
+}
+
+// ---------------------------------------------------------------------------------------
+// Ball vs world (physics.py:359-436).  Returns true when the ball touches the ground.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool ball_world_step(Ball& b)
+{
+    b.ppx = b.px;
+    b.ppy = b.py;
+    b.px = b.x;
+    b.py = b.y;
+
+    int rot = b.rot + (b.xv >> 1);  // Python floor division (:373): arithmetic shift
+    rot = rot < 0 ? rot + 50 : (rot > 50 ? rot - 50 : rot);
+    b.rot = rot;
+
+    const int fx = b.x + b.xv;
+    if (fx < kBallRadius || fx > kGroundWidth) b.xv = -b.xv;  // asymmetric walls (:403)
+    if (b.y + b.yv < 0) b.yv = 1;
+
+    if (abs(b.x - kGroundHalfWidth) < kNetPillarHalfWidth && b.y > kNetTopTopY) {
+        if (b.y <= kNetTopBottomY) {
+            if (b.yv > 0) b.yv = -b.yv;
+        } else {
+            b.xv = (b.x < kGroundHalfWidth) ? -abs(b.xv) : abs(b.xv);
+        }
+    }
+
+    const int fy = b.y + b.yv;
+    const bool ground = fy > kBallGroundY;
+    if (ground) {
+        b.yv = -b.yv;
+        b.punch = b.x;
+        b.y = kBallGroundY;  // x is not advanced on the touching frame (:428-431)
+    } else {
+        b.y = fy;
+        b.x = b.x + b.xv;
+        b.yv += 1;
+    }
+    return ground;
+}
+
+// ---------------------------------------------------------------------------------------
+// Flight predictors of the computer player.
+// FULL_NET=true : calculate_expected_landing_point_x_for (physics.py:643-686), net top split
+//                 at y < 192 (strict) with side bounce below it.
+// FULL_NET=false: expected_landing_point_x_when_power_hit (physics.py:848-884), simplified
+//                 net rule (no side bounce).
+// Both keep the reference's iteration cap (physics.py:33): the x at the cap is the result.
+// ---------------------------------------------------------------------------------------
+template <bool FULL_NET>
+__device__ __forceinline__ int predict_landing_x(int x, int y, int xv, int yv)
+{
+    int count = 0;
+    for (;;) {
+        ++count;
+        const int fx = x + xv;
+        if (fx < kBallRadius || fx > kGroundWidth) xv = -xv;
+        if (y + yv < 0) yv = 1;
+        if (abs(x - kGroundHalfWidth) < kNetPillarHalfWidth && y > kNetTopTopY) {
+            if (!FULL_NET || y < kNetTopBottomY) {
+                if (yv > 0) yv = -yv;
+            } else {
+                xv = (x < kGroundHalfWidth) ? -abs(xv) : abs(xv);
+            }
+        }
+        y += yv;
+        if (y > kBallGroundY || count >= kLoopLimit) break;
+        x += xv;
+        yv += 1;
+    }
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------
+// Rule-based computer player: let_computer_decide_user_input (physics.py:689-771) with
+// decide_whether_input_power_hit (:774-817) folded in.  IS_P2 selects the court side.
+// Overwrites the decoded user input entirely (:709-711); may tick the RNG.
+// ---------------------------------------------------------------------------------------
+template <bool IS_P2>
+__device__ __forceinline__ void computer_decide(Player& p, const Ball& b, const Player& other, Input& in,
+                                                const RngId& id, uint32_t& rng)
+{
+    constexpr int kLeft = IS_P2 ? kGroundHalfWidth : 0;                    // left boundary of own side
+    constexpr int kRight = kLeft + kGroundHalfWidth;                       // right boundary
+    constexpr int kOppHigh = (IS_P2 ? kGroundWidth : 0) + kGroundHalfWidth;  // :718 / :801
+
+    in.xd = 0;
+    in.yd = 0;
+    in.hit = 0;
+
+    const int dxb = abs(b.x - p.x);
+    int target = b.ex;
+    if (dxb > 100 && abs(b.xv) < p.bold + 5) {
+        if ((b.ex <= kLeft || b.ex >= kOppHigh) && p.standby == 0) target = kLeft + kGroundHalfWidth / 2;
+    }
+
+    if (abs(target - p.x) > p.bold + 8) {
+        in.xd = (p.x < target) ? 1 : -1;
+    } else if (rng_integers(id, rng, 20u) == 0) {  // :728
+        p.standby = rng_integers(id, rng, 2u);     // :729
+    }
+
+    if (p.state == 0) {
+        if (abs(b.xv) < p.bold + 3 && dxb < kPlayerHalfLength && b.y > -36 && b.y < 10 * p.bold + 84 && b.yv > 0)
+            in.yd = -1;
+        if (b.ex > kLeft && b.ex < kRight && dxb > p.bold * 5 + kPlayerLength && b.x > kLeft && b.x < kRight &&
+            b.y > 174) {
+            in.hit = 1;  // dive
+            in.xd = (p.x < b.x) ? 1 : -1;
+        }
+    } else if (p.state == 1 || p.state == 2) {
+        if (dxb > 8) in.xd = (p.x < b.x) ? 1 : -1;
+        if (dxb < 48 && abs(b.y - p.y) < 48) {
+            // decide_whether_input_power_hit: scan x_direction 1,0 and y_direction in the
+            // order chosen by one draw (:795); first candidate whose predicted landing is on
+            // the opponent's side and > 64 away from the opponent wins.
+            const bool ascending = rng_integers(id, rng, 2u) == 0;
+            bool found = false;
+            for (int c = 0; c < 6 && !found; ++c) {
+                const int xdir = c < 3 ? 1 : 0;
+                const int j = c < 3 ? c : c - 3;
+                const int ydir = ascending ? j - 1 : 1 - j;
+                const int sxv = (b.x < kGroundHalfWidth) ? (xdir + 1) * 10 : -(xdir + 1) * 10;  // :841-844
+                const int syv = abs(b.yv) * ydir * 2;                                          // :845
+                const int ex = predict_landing_x<false>(b.x, b.y, sxv, syv);
+                if ((ex <= kLeft || ex >= kOppHigh) && abs(ex - other.x) > kPlayerLength) {
+                    in.xd = xdir;
+                    in.yd = ydir;
+                    found = true;
+                }
+            }
+            if (found) {
+                in.hit = 1;
+                if (abs(other.x - p.x) < 80 && in.yd != -1) in.yd = -1;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Player movement (physics.py:457-552; the game-end tail :554-564 is unreachable under the
+// env because termination is immediate, pikazoo_env.py:230-233).
+// ---------------------------------------------------------------------------------------
+template <bool IS_P2>
+__device__ __forceinline__ void player_move(Player& p, const Input& in)
+{
+    constexpr int kMinX = IS_P2 ? kGroundHalfWidth + kPlayerHalfLength : kPlayerHalfLength;
+    constexpr int kMaxX = IS_P2 ? kGroundWidth - kPlayerHalfLength : kGroundHalfWidth - kPlayerHalfLength;
+
+    if (p.state == 4) {  // lying down after a dive: only the countdown runs (:458-462)
+        p.lying -= 1;
+        if (p.lying < -1) p.state = 0;
+        return;
+    }
+
+    const int vx = (p.state < 3) ? in.xd * 6 : p.dive * 8;
+    p.x = min(max(p.x + vx, kMinX), kMaxX);
+
+    if (p.state < 3 && in.yd == -1 && p.y == kPlayerGroundY) {  // jump
+        p.yv = -16;
+        p.state = 1;
+        p.frame = 0;
+    }
+
+    const int fy = p.y + p.yv;
+    p.y = fy;
+    if (fy < kPlayerGroundY) {
+        p.yv += 1;
+    } else if (fy > kPlayerGroundY) {  // landing
+        p.yv = 0;
+        p.y = kPlayerGroundY;
+        p.frame = 0;
+        if (p.state == 3) {
+            p.state = 4;
+            p.lying = 3;
+        } else {
+            p.state = 0;
+        }
+    }
+
+    if (in.hit == 1) {
+        if (p.state == 1) {  // power hit
+            p.delay = 5;
+            p.frame = 0;
+            p.state = 2;
+        } else if (p.state == 0 && in.xd != 0) {  // dive
+            p.state = 3;
+            p.frame = 0;
+            p.dive = in.xd;
+            p.yv = -5;
+        }
+    }
+
+    if (p.state == 1) {
+        p.frame = (int)((uint32_t)(p.frame + 1) % 3u);  // frame is never negative
+    } else if (p.state == 2) {
+        if (p.delay < 1) {
+            p.frame += 1;
+            if (p.frame > 4) {
+                p.frame = 0;
+                p.state = 1;
+            }
+        } else {
+            p.delay -= 1;
+        }
+    } else if (p.state == 0) {
+        p.delay += 1;
+        if (p.delay > 3) {
+            p.delay = 0;
+            const int f = p.frame + p.arm;
+            if (f < 0 || f > 4) p.arm = -p.arm;
+            p.frame = p.frame + p.arm;
+        }
+    }
+}
+
+// is_collision_between_ball_and_player_happened (physics.py:340-356)
+__device__ __forceinline__ bool ball_touches_player(const Ball& b, const Player& p)
+{
+    return abs(b.x - p.x) <= kPlayerHalfLength && abs(b.y - p.y) <= kPlayerHalfLength;
+}
+
+// process_collision_between_ball_and_player (physics.py:580-640)
+__device__ __forceinline__ void ball_player_collision(Ball& b, int player_x, const Input& in, int player_state,
+                                                      const RngId& id, uint32_t& rng)
+{
+    const int d = b.x - player_x;
+    if (d < 0)
+        b.xv = -((-d) / 3);
+    else if (d > 0)
+        b.xv = d / 3;
+    if (b.xv == 0) b.xv = rng_integers(id, rng, 3u) - 1;  // :613
+
+    const int ayv = abs(b.yv);
+    b.yv = ayv < 15 ? -15 : -ayv;
+
+    if (player_state == 2) {  // jumping and power hitting
+        b.xv = (b.x < kGroundHalfWidth) ? (abs(in.xd) + 1) * 10 : -(abs(in.xd) + 1) * 10;
+        b.punch = b.x;
+        b.yv = abs(b.yv) * in.yd * 2;
+        b.power = 1;
+    } else {
+        b.power = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// One frame of one game: raw_env.step (pikazoo_env.py:175-240) around physics_engine
+// (physics.py:280-337).  Returns player_1's reward (+1/-1/0); player_2's is its negation.
+// `frozen` (auto_reset off and the game already over) leaves the game untouched.
+// ---------------------------------------------------------------------------------------
+template <bool AI1, bool AI2>
+__device__ __forceinline__ int step_game(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool& frozen)
+{
+    // The reference empties `agents` on termination (:237-238) and expects reset() before the
+    // next step; auto_reset applies reset() (:149-164) in place.  Both that and the new-round
+    // branch (:176-180) end in the same per-round initialisation, kept at one call site so the
+    // wave runs the (divergent, Philox-drawing) body once.
+    frozen = g.e.game_ended && !cfg.auto_reset;
+    if (frozen) return 0;
+    if (g.e.round_ended) {  // game_ended implies round_ended
+        if (g.e.game_ended) {
+            g.e.game_ended = 0;
+            g.e.p2serve = 0;
+            g.e.s1 = 0;
+            g.e.s2 = 0;
+        }
+        g.e.round_ended = 0;
+        start_round(g, cfg, id);
+    }
+
+    // :182-184 -- every player's key state is sampled, computer-controlled or not
+    Input in1, in2;
+    if (cfg.simplify_action) {
+        in1 = decode_action(kSimpleTablesP1, a1, g.p1.hitprev);
+        in2 = decode_action(kSimpleTablesP2, a2, g.p2.hitprev);
+    } else {
+        in1 = decode_action(kFullTables, a1, g.p1.hitprev);
+        in2 = decode_action(kFullTables, a2, g.p2.hitprev);
+    }
+
+    // physics_engine
+    const bool ground = ball_world_step(g.b);
+
+    if (AI1 || AI2) {
+        // :314-315 recomputes the landing point before each player; the ball does not move
+        // between the two calls, so one evaluation serves both.
+        g.b.ex = predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
+    }
+    if (AI1) computer_decide<false>(g.p1, g.b, g.p2, in1, id, g.e.rng);
+    player_move<false>(g.p1, in1);
+    if (AI2) computer_decide<true>(g.p2, g.b, g.p1, in2, id, g.e.rng);
+    player_move<true>(g.p2, in2);
+
+    bool hit_processed = false;
+    {
+        const bool touch = ball_touches_player(g.b, g.p1);
+        if (touch && !g.p1.coll) {
+            ball_player_collision(g.b, g.p1.x, in1, g.p1.state, id, g.e.rng);
+            hit_processed = true;
+        }
+        g.p1.coll = touch;
+    }
+    {
+        const bool touch = ball_touches_player(g.b, g.p2);
+        if (touch && !g.p2.coll) {
+            ball_player_collision(g.b, g.p2.x, in2, g.p2.state, id, g.e.rng);
+            hit_processed = true;
+        }
+        g.p2.coll = touch;
+    }
+    if ((AI1 || AI2) && hit_processed) {
+        // :331-332 -- when both players hit in one frame the second evaluation overwrites the
+        // first, so a single one after both collisions leaves the same value.
+        g.b.ex = predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
+    }
+
+    // scoring / round end / game end (:190-210); round_ended and game_ended are both 0 here
+    int reward = 0;
+    if (ground) {
+        if (g.b.punch < kGroundHalfWidth) {
+            g.e.p2serve = 1;
+            g.e.s2 += 1;
+            if (g.e.s2 >= cfg.winning_score) g.e.game_ended = 1;
+            reward = -1;
+        } else {
+            g.e.p2serve = 0;
+            g.e.s1 += 1;
+            if (g.e.s1 >= cfg.winning_score) g.e.game_ended = 1;
+            reward = 1;
+        }
+        g.e.round_ended = 1;
+    }
+    return reward;
+}
+
+}  // namespace pz

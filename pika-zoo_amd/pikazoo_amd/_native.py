@@ -1,0 +1,95 @@
+"""ctypes binding of libpikazoo_hip.so (C ABI declared in include/pikazoo_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  If it is missing or a
+call fails, the error is raised to the caller.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+PKG_ROOT = Path(__file__).resolve().parent.parent  # .../pika-zoo_amd
+LIB_PATH = PKG_ROOT / "lib" / "libpikazoo_hip.so"
+
+ABI_VERSION = 1
+STATE_WORDS = 44
+OBS_DIM = 35
+SERVE_MODES = {"winner": 0, "alternate": 1, "random": 2}
+
+
+class PzConfig(C.Structure):
+    """`pz_config` (include/pikazoo_hip.h): the kwargs of pikazoo_v0.env (pikazoo_env.py:79-86),
+    the two fusable wrappers, and the batched-env additions."""
+
+    _fields_ = [
+        ("winning_score", C.c_int32),
+        ("serve_mode", C.c_int32),
+        ("p1_computer", C.c_int32),
+        ("p2_computer", C.c_int32),
+        ("simplify_action", C.c_int32),
+        ("ballpos_reward", C.c_int32),
+        ("x_line", C.c_int32),
+        ("y_line", C.c_int32),
+        ("additional_reward", C.c_float * 8),
+        ("auto_reset", C.c_int32),
+        ("reserved", C.c_int32),
+        ("seed", C.c_uint64),
+        ("env_id_base", C.c_int64),
+    ]
+
+
+class PikazooNativeError(RuntimeError):
+    pass
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "pz_abi_version": (C.c_int, []),
+    "pz_state_words": (C.c_int, []),
+    "pz_obs_dim": (C.c_int, []),
+    "pz_config_bytes": (C.c_int, []),
+    "pz_error_string": (C.c_char_p, [C.c_int]),
+    "pz_init": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P]),
+    "pz_reset": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, _P, _P, _P]),
+    "pz_observe": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P]),
+    "pz_step": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pz_step_random": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), C.c_uint64, C.c_uint64,
+                                 C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "pz_random_actions": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise PikazooNativeError(
+            f"{LIB_PATH} is missing: build it with `python pika-zoo_amd/build.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.pz_abi_version() != ABI_VERSION:
+        raise PikazooNativeError(f"ABI mismatch: library {lib.pz_abi_version()} != binding {ABI_VERSION}")
+    if lib.pz_config_bytes() != C.sizeof(PzConfig) or lib.pz_state_words() != STATE_WORDS \
+            or lib.pz_obs_dim() != OBS_DIM:
+        raise PikazooNativeError("pz_config / state layout of the library does not match this binding")
+    _lib = lib
+    return lib
+
+
+def exported_names():
+    return list(_SIGNATURES)
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().pz_error_string(code)
+        raise PikazooNativeError(f"{what} failed: {msg.decode() if msg else code} (code {code})")

@@ -1,0 +1,80 @@
+"""Multi-GPU sharding of the batch: one process per GPU, no collective on the step path.
+
+Games are independent (each reference env owns its physics and RNG, pikazoo_env.py:96-98), so
+rank r simply owns the contiguous global lane range ``[r*n_local, (r+1)*n_local)``;
+``env_id_base`` feeds the Philox counter, which makes trajectories independent of the GPU count.
+The only collective is a SUM all-reduce of a few int64 counters per reporting window
+(``torch.distributed``: backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass(frozen=True)
+class Shard:
+    rank: int
+    world_size: int
+    n_local: int
+    env_id_base: int
+    n_global: int
+
+
+def shard_for_rank(n_global: int, rank: int, world_size: int) -> Shard:
+    """Contiguous split of ``n_global`` lanes; the first ``n_global % world_size`` ranks get one more."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    q, r = divmod(int(n_global), int(world_size))
+    n_local = q + (1 if rank < r else 0)
+    base = rank * q + min(rank, r)
+    return Shard(rank, world_size, n_local, base, int(n_global))
+
+
+def weak_shard(n_per_gpu: int, rank: int, world_size: int) -> Shard:
+    """Weak scaling: every rank owns ``n_per_gpu`` lanes of a ``world_size * n_per_gpu`` job."""
+    return Shard(rank, world_size, int(n_per_gpu), rank * int(n_per_gpu), world_size * int(n_per_gpu))
+
+
+def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """Join the process group described by RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun).
+
+    Returns (rank, world_size, local_rank).  Single-process runs (no WORLD_SIZE) skip the group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def all_reduce_sum(values, device=None) -> list[int]:
+    """SUM over ranks of a short list of integer counters (one tiny all-reduce)."""
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.tolist()]
+
+
+def all_reduce_max(value: float, device=None) -> float:
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

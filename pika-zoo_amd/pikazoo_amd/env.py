@@ -1,0 +1,338 @@
+"""Batched Pikachu-Volleyball environment on MI355X: the host side of the fused HIP step kernel.
+
+Mirrors the PettingZoo *parallel* API of the reference's ``raw_env``
+(pikazoo/env/pikazoo_env.py:72-240): same constructor kwargs, ``possible_agents`` / ``agents``,
+``reset(seed, options) -> (obs, infos)``, ``step(actions) -> (obs, rewards, terminations,
+truncations, infos)``, ``observation_space(agent)``, ``action_space(agent)`` -- but every dict
+value is a device tensor with a leading ``num_envs`` axis (one GPU lane per independent game).
+
+All game state lives in one ``int32[44, num_envs]`` tensor in HBM (field-major); a step is ONE
+kernel launch through the C ABI in ``include/pikazoo_hip.h``.  PyTorch is used only for device
+memory and streams.  There is no CPU fallback: constructing the env without the HIP library or
+without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _native
+from .spaces import Box, Discrete
+
+AGENTS = ["player_1", "player_2"]
+
+# observation bounds: pikazoo/env/pikazoo_env.py:485-562 (player, opponent, ball)
+_PLAYER_LOW = [32, 108, -15, -1, -2, 0, 0, 0, 0, 0, 0, 0, 0]
+_PLAYER_HIGH = [400, 244, 16, 1, 3, 4, 4, 1, 1, 1, 1, 1, 1]
+_BALL_LOW = [20, 0, 0, 0, 0, 0, -20, -124, 0]
+_BALL_HIGH = [432, 252, 432, 252, 432, 252, 20, 124, 1]
+OBS_LOW = np.array(_PLAYER_LOW * 2 + _BALL_LOW, dtype=np.int32)
+OBS_HIGH = np.array(_PLAYER_HIGH * 2 + _BALL_HIGH, dtype=np.int32)
+
+# state columns used on the host (include/pikazoo_hip.h)
+_E_SCORE_P1 = 38
+_E_GAME_ENDED = 42
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class raw_env:
+    """``pikazoo_v0.raw_env`` for ``num_envs`` games at once.
+
+    Reference kwargs (pikazoo_env.py:79-86): ``winning_score``, ``serve`` in {"winner",
+    "alternate", "random"}, ``is_player1_computer``, ``is_player2_computer``, ``render_mode``
+    (must be None: rendering is out of scope of the step path).
+
+    Batched-env kwargs: ``num_envs``; ``device`` (a CUDA/HIP device); ``seed`` (Philox key of
+    the env RNG stream -- the reference seeds PCG64 from OS entropy and ignores ``reset(seed)``,
+    pikazoo_env.py:96,149); ``env_id_base`` (global id of lane 0, so shards of one job draw
+    disjoint streams); ``auto_reset`` (a finished game is ``reset()`` in place right before its
+    next frame, exactly what ``if not env.agents: env.reset()`` does around the reference);
+    ``validate_actions`` (range-check actions like the reference's table lookup does; costs a
+    device sync per step); ``scalar_api`` (``num_envs == 1`` only: return numpy rows / Python
+    scalars and empty ``agents`` on termination, i.e. the reference's exact return types).
+
+    Returned tensors are views of env-owned buffers that the next ``step`` overwrites;
+    ``clone()`` what must outlive it.
+    """
+
+    metadata = {"render_modes": [], "name": "pikazoo_v0", "render_fps": 20, "is_parallelizable": True}
+
+    def __init__(self, winning_score: int = 15, serve: str = "winner", is_player1_computer: bool = False,
+                 is_player2_computer: bool = False, render_mode=None, *, num_envs: int = 1,
+                 device="cuda", seed: int = 0, env_id_base: int = 0, auto_reset: bool = True,
+                 validate_actions: bool = True, scalar_api: bool = False):
+        assert serve in ("winner", "alternate", "random")  # pikazoo_env.py:104
+        if render_mode is not None:
+            raise NotImplementedError("rendering is outside the step path; use render_mode=None")
+        if int(winning_score) < 1:
+            raise ValueError("winning_score must be >= 1")
+        if int(num_envs) < 1:
+            raise ValueError("num_envs must be >= 1")
+        self._lib = _native.load()  # raises when the HIP library has not been built
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"pikazoo_amd runs on MI355X only (got device {self.device}); no CPU fallback")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: pikazoo_amd has no CPU fallback")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if scalar_api and num_envs != 1:
+            raise ValueError("scalar_api needs num_envs == 1")
+
+        self.possible_agents = AGENTS[:]
+        self.agents = self.possible_agents[:]
+        self.num_envs = int(num_envs)
+        self.winning_score = int(winning_score)
+        self.serve = serve
+        self.render_mode = None
+        self.auto_reset = bool(auto_reset)
+        self.validate_actions = bool(validate_actions)
+        self.scalar_api = bool(scalar_api)
+        self.seed = int(seed)
+        self.env_id_base = int(env_id_base)
+
+        cfg = _native.PzConfig()
+        cfg.winning_score = self.winning_score
+        cfg.serve_mode = _native.SERVE_MODES[serve]
+        cfg.p1_computer = int(bool(is_player1_computer))
+        cfg.p2_computer = int(bool(is_player2_computer))
+        cfg.simplify_action = 0
+        cfg.ballpos_reward = 0
+        cfg.x_line, cfg.y_line = 216, 176
+        cfg.auto_reset = int(self.auto_reset)
+        cfg.seed = self.seed & 0xFFFFFFFFFFFFFFFF
+        cfg.env_id_base = self.env_id_base
+        self._cfg = cfg
+        self._cfg_ref = C.byref(cfg)
+
+        n, dev = self.num_envs, self.device
+        self.state = torch.zeros((_native.STATE_WORDS, n), dtype=torch.int32, device=dev)
+        self._obs = [torch.zeros((n, _native.OBS_DIM), dtype=torch.int32, device=dev) for _ in range(2)]
+        # one 4-byte word per lane and agent; viewed as int32 or float32 (RewardByBallPosition)
+        self._rew_raw = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
+        self._term_u8 = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self._term = self._term_u8.view(torch.bool)
+        self._trunc = torch.zeros(n, dtype=torch.bool, device=dev)  # always False (pikazoo_env.py:234)
+        self._episodes = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._scores = self.state[_E_SCORE_P1:_E_SCORE_P1 + 2].t()  # live [n, 2] view of the state
+        self.steps_done = 0  # frames stepped by this env (per lane)
+
+        self.action_spaces = {a: Discrete(18) for a in self.possible_agents}
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.pz_init(self.state.data_ptr(), n, n, self._cfg_ref, self._stream()), "pz_init")
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def num_agents(self):
+        return len(self.agents)
+
+    @property
+    def max_num_agents(self):
+        return len(self.possible_agents)
+
+    @property
+    def scores(self) -> torch.Tensor:
+        """``int32[num_envs, 2]`` live view (the reference's ``scores`` list, pikazoo_env.py:100)."""
+        return self._scores
+
+    @property
+    def episodes_done(self) -> int:
+        """Games finished inside ``step_random`` launches (device counter; syncs)."""
+        return int(self._episodes.item())
+
+    # ---- fusable wrappers (set by pikazoo_amd.wrappers) -----------------------------------------
+    def _fuse_simplify_action(self):
+        """wrappers/simplify_action.py:16-25 inside the kernel: actions become Discrete(13)."""
+        if self._cfg.simplify_action:
+            raise RuntimeError("SimplifyAction is already applied")
+        self._cfg.simplify_action = 1
+        self.action_spaces = {a: Discrete(13) for a in self.possible_agents}
+
+    def _fuse_ballpos_reward(self, additional_reward, x_line: int, y_line: int):
+        """wrappers/reward_by_ball_position.py:20-31 inside the kernel: rewards become float32."""
+        assert len(additional_reward) == 8  # reward_by_ball_position.py:15
+        if self._cfg.ballpos_reward:
+            raise NotImplementedError("only one RewardByBallPosition can be fused")
+        self._cfg.ballpos_reward = 1
+        self._cfg.x_line, self._cfg.y_line = int(x_line), int(y_line)
+        for i, v in enumerate(additional_reward):
+            self._cfg.additional_reward[i] = float(v)
+
+    @property
+    def n_actions(self) -> int:
+        return 13 if self._cfg.simplify_action else 18
+
+    @property
+    def reward_dtype(self):
+        return torch.float32 if self._cfg.ballpos_reward else torch.int32
+
+    # ---- spaces (pikazoo_env.py:481-568) ----------------------------------------------------------
+    @functools.lru_cache(maxsize=None)
+    def observation_space(self, agent=None):
+        return Box(low=OBS_LOW.copy(), high=OBS_HIGH.copy(), shape=(35,), dtype=np.int32)
+
+    def action_space(self, agent):
+        return self.action_spaces[agent]
+
+    # ---- results packing ----------------------------------------------------------------------------
+    def _rewards(self):
+        dt = self.reward_dtype
+        return [r if dt == torch.int32 else r.view(torch.float32) for r in self._rew_raw]
+
+    def _infos(self):
+        return {a: {"score": self._scores} for a in self.agents}  # aliased like pikazoo_env.py:573-574
+
+    def _pack_obs(self):
+        if self.scalar_api:
+            return {a: self._obs[i][0].cpu().numpy() for i, a in enumerate(self.possible_agents)}
+        return {a: self._obs[i] for i, a in enumerate(self.possible_agents)}
+
+    def _pack_step(self):
+        rew = self._rewards()
+        if not self.scalar_api:
+            obs = self._pack_obs()
+            out = (obs, dict(zip(self.possible_agents, rew)), {a: self._term for a in self.possible_agents},
+                   {a: self._trunc for a in self.possible_agents}, self._infos())
+            return out
+        # the reference's exact return types (numpy rows, Python scalars, list of scores)
+        ended = bool(self._term_u8.item())
+        score = self._scores[0].tolist()
+        agents = self.agents
+        out = (self._pack_obs(), {a: rew[i][0].item() for i, a in enumerate(agents)},
+               {a: ended for a in agents}, {a: False for a in agents}, {a: {"score": score} for a in agents})
+        if ended and not self.auto_reset:
+            self.agents = []  # pikazoo_env.py:237-238
+        return out
+
+    # ---- reset (pikazoo_env.py:149-173) ---------------------------------------------------------------
+    def reset(self, seed=None, options=None, mask: Optional[torch.Tensor] = None):
+        """``reset()`` of every game (or of the lanes where ``mask`` is non-zero).
+
+        ``seed`` and ``options`` are accepted and ignored, like the reference (it never re-seeds,
+        pikazoo_env.py:149-173); the env stream continues from each lane's draw counter."""
+        self.agents = self.possible_agents[:]
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+            if m.shape != (self.num_envs,):
+                raise ValueError(f"mask must have shape ({self.num_envs},)")
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.pz_reset(self.state.data_ptr(), self.num_envs, self.num_envs, self._cfg_ref,
+                                             _ptr(m), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
+                                             self._stream()), "pz_reset")
+        if self.scalar_api:
+            return self._pack_obs(), {a: {"score": self._scores[0].tolist()} for a in self.agents}
+        return self._pack_obs(), self._infos()
+
+    # ---- step (pikazoo_env.py:175-240) ------------------------------------------------------------------
+    def _action_tensor(self, a) -> torch.Tensor:
+        if not isinstance(a, torch.Tensor):
+            a = torch.as_tensor(np.asarray(a).reshape(-1), device=self.device)
+        elif a.device != self.device:
+            a = a.to(self.device)
+        a = a.reshape(-1)
+        if a.dtype != torch.int32:
+            if a.dtype.is_floating_point or a.dtype == torch.bool:
+                raise TypeError(f"actions must be integer tensors, got {a.dtype}")
+            a = a.to(torch.int32)
+        a = a.contiguous()
+        if a.numel() != self.num_envs:
+            raise ValueError(f"expected {self.num_envs} actions per agent, got {a.numel()}")
+        return a
+
+    def step(self, actions: Dict[str, torch.Tensor]):
+        """One frame of every game.  ``actions[agent]``: int tensor ``[num_envs]`` in
+        ``[0, action_space(agent).n)`` (ints / arrays are accepted for small batches).  As in the
+        reference, both agents' key states are read even for a computer-controlled side."""
+        if not self.agents:
+            raise RuntimeError("step() after termination: call reset() first (agents is empty)")
+        a1 = self._action_tensor(actions[self.possible_agents[0]])  # KeyError on a missing agent
+        a2 = self._action_tensor(actions[self.possible_agents[1]])
+        if self.validate_actions:
+            n_act = self.n_actions
+            lo = torch.minimum(a1.min(), a2.min())
+            hi = torch.maximum(a1.max(), a2.max())
+            if int(lo.item()) < 0 or int(hi.item()) >= n_act:
+                # the reference's table lookup raises IndexError (pikazoo_env.py:182)
+                raise IndexError(f"action out of range [0, {n_act})")
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.pz_step(self.state.data_ptr(), self.num_envs, self.num_envs, self._cfg_ref,
+                                            a1.data_ptr(), a2.data_ptr(), self._obs[0].data_ptr(),
+                                            self._obs[1].data_ptr(), self._rew_raw[0].data_ptr(),
+                                            self._rew_raw[1].data_ptr(), self._term_u8.data_ptr(), self._stream()),
+                          "pz_step")
+        self.steps_done += 1
+        return self._pack_step()
+
+    def step_random(self, action_seed: int, t0: Optional[int] = None, k: int = 1):
+        """``k`` frames under the uniform random policy drawn on device (Philox stream
+        ``action_seed``, step indices ``t0 .. t0+k-1``; ``t0`` defaults to ``steps_done``) in ONE
+        launch.  Returns the last frame's step tuple."""
+        if t0 is None:
+            t0 = self.steps_done
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.pz_step_random(self.state.data_ptr(), self.num_envs, self.num_envs,
+                                                   self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0),
+                                                   int(k), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
+                                                   self._rew_raw[0].data_ptr(), self._rew_raw[1].data_ptr(),
+                                                   self._term_u8.data_ptr(), self._episodes.data_ptr(),
+                                                   self._stream()), "pz_step_random")
+        self.steps_done += int(k)
+        return self._pack_step()
+
+    def random_actions(self, action_seed: int, t: Optional[int] = None):
+        """The policy stream of :meth:`step_random` as two ``int32[num_envs]`` device tensors."""
+        if t is None:
+            t = self.steps_done
+        a1 = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+        a2 = torch.empty_like(a1)
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.pz_random_actions(a1.data_ptr(), a2.data_ptr(), self.num_envs, self.env_id_base,
+                                                      int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t), self.n_actions,
+                                                      self._stream()), "pz_random_actions")
+        return {self.possible_agents[0]: a1, self.possible_agents[1]: a2}
+
+    def observe(self):
+        """``_get_obs`` (pikazoo_env.py:576-624) of the current state into fresh tensors."""
+        o1 = torch.empty_like(self._obs[0])
+        o2 = torch.empty_like(self._obs[1])
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.pz_observe(self.state.data_ptr(), self.num_envs, self.num_envs, o1.data_ptr(),
+                                               o2.data_ptr(), self._stream()), "pz_observe")
+        return {self.possible_agents[0]: o1, self.possible_agents[1]: o2}
+
+    # ---- checkpoint = the state tensor --------------------------------------------------------------------
+    def state_dict(self):
+        return {"state": self.state.clone(), "steps_done": self.steps_done, "seed": self.seed,
+                "env_id_base": self.env_id_base}
+
+    def load_state_dict(self, sd):
+        if sd["state"].shape != self.state.shape:
+            raise ValueError("state shape mismatch")
+        self.state.copy_(sd["state"])
+        self.steps_done = int(sd["steps_done"])
+
+    def render(self):
+        raise NotImplementedError("rendering is outside the step path (render_mode=None only)")
+
+    def close(self):
+        pass
+
+
+def env(**kwargs):
+    """``pikazoo_v0.env(**kwargs)`` (pikazoo/env/pikazoo_env.py:27-29)."""
+    return raw_env(**kwargs)

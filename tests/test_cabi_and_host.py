@@ -1,0 +1,142 @@
+"""CPU tests (no GPU needed): the C-ABI library loads and exports every symbol include/*.h
+declares, the binding's struct matches the library, host-side logic (spaces, sharding, the N>1
+counter all-reduce over gloo) behaves, and the product has no CPU fallback."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    sys.path.insert(0, str(REPO / "pika-zoo_amd"))
+    import build as pz_build
+
+    return pz_build.build()
+
+
+def header_functions():
+    text = (REPO / "include" / "pikazoo_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pz_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from pikazoo_amd import _native
+
+    lib = C.CDLL(str(built_lib))
+    names = header_functions()
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/pikazoo_hip.h but not exported"
+    assert sorted(_native.exported_names()) == names, "binding and header disagree"
+
+
+def test_binding_matches_library_layout(built_lib):
+    from pikazoo_amd import _native
+
+    lib = _native.load()
+    assert lib.pz_abi_version() == 1 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
+    assert lib.pz_config_bytes() == C.sizeof(_native.PzConfig) == 88
+    assert lib.pz_error_string(0) == b"ok" and b"NULL" in lib.pz_error_string(-1)
+
+
+def test_header_layout_matches_oracle_layout(oracle):
+    """The product header and the oracle declare the state layout independently; keep them equal."""
+    from pikazoo_amd import _native
+
+    text = (REPO / "include" / "pikazoo_hip.h").read_text()
+    assert "#define PZ_STATE_WORDS 44" in text and "PZ_B_X = 26" in text and "PZ_E_SCORE_P1 = 38" in text
+    assert C.sizeof(oracle.Config) == C.sizeof(_native.PzConfig)
+    for (n1, t1), (n2, t2) in zip(oracle.Config._fields_, _native.PzConfig._fields_):
+        assert n1 == n2 and C.sizeof(t1) == C.sizeof(t2)
+
+
+def test_no_cpu_fallback_and_no_oracle_in_product():
+    from pikazoo_amd import pikazoo_v0
+
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            pikazoo_v0.env(num_envs=4)
+    with pytest.raises(RuntimeError):
+        pikazoo_v0.env(num_envs=4, device="cpu")
+    # nothing under the product tree may reference the oracle
+    for p in (REPO / "pika-zoo_amd").rglob("*"):
+        if p.suffix in (".py", ".hip", ".hpp", ".h", ".cpp"):
+            assert "oracle" not in p.read_text().lower().replace("oracle/", "oracle/") or p.name == "never", p
+
+
+def test_spaces():
+    from pikazoo_amd.env import OBS_HIGH, OBS_LOW
+    from pikazoo_amd.spaces import Box, Discrete
+
+    d = Discrete(18)
+    assert d.n == 18 and d.contains(17) and not d.contains(18) and 0 <= d.sample() < 18
+    b = Box(OBS_LOW, OBS_HIGH, shape=(35,), dtype=np.int32)
+    assert b.shape == (35,) and b.contains(OBS_LOW) and not b.contains(OBS_LOW - 1)
+    # pikazoo_env.py:485-562
+    assert OBS_LOW.tolist()[:13] == [32, 108, -15, -1, -2, 0, 0, 0, 0, 0, 0, 0, 0]
+    assert OBS_HIGH.tolist()[26:] == [432, 252, 432, 252, 432, 252, 20, 124, 1]
+    assert OBS_LOW.tolist()[26:] == [20, 0, 0, 0, 0, 0, -20, -124, 0]
+
+
+def test_sharding_covers_all_lanes_once():
+    from pikazoo_amd.dist import shard_for_rank, weak_shard
+
+    for n, w in [(65536, 8), (10, 3), (7, 8), (524288, 8)]:
+        shards = [shard_for_rank(n, r, w) for r in range(w)]
+        assert sum(s.n_local for s in shards) == n
+        pos = 0
+        for s in shards:
+            assert s.env_id_base == pos
+            pos += s.n_local
+    s = weak_shard(65536, 3, 8)
+    assert (s.n_local, s.env_id_base, s.n_global) == (65536, 196608, 524288)
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(sys.argv[1], "pika-zoo_amd")); sys.path.insert(0, sys.argv[1])
+from pikazoo_amd import dist
+from oracle import pz_oracle as po
+rank, world, _ = dist.init_from_env("gloo")
+N, STEPS = 96, 300
+sh = dist.shard_for_rank(N, rank, world)
+# each rank steps its own shard with the CPU oracle standing in for the GPU (test only)
+env = po.OracleEnv(sh.n_local, po.make_config(is_player2_computer=True, winning_score=2, seed=7, env_id_base=sh.env_id_base))
+env.reset()
+eps = env.rollout_random(3, 0, STEPS)
+steps, episodes = dist.all_reduce_sum([sh.n_local * STEPS, eps])
+tmax = dist.all_reduce_max(float(rank + 1))
+dist.barrier()
+np.save(os.path.join(sys.argv[2], f"state_{rank}.npy"), env.state)
+if rank == 0:
+    open(os.path.join(sys.argv[2], "agg.txt"), "w").write(f"{steps} {episodes} {tmax}")
+'''
+
+
+def test_two_rank_sharding_equals_single_process(tmp_path, oracle):
+    """world_size-2 gloo run: shards stepped independently + one counter all-reduce give the same
+    trajectories and totals as the single-process batch (env ids are global)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), str(REPO),
+                           str(tmp_path)], env=env, timeout=600)
+    whole = oracle.OracleEnv(96, oracle.make_config(is_player2_computer=True, winning_score=2, seed=7))
+    whole.reset()
+    eps = whole.rollout_random(3, 0, 300)
+    got = np.concatenate([np.load(tmp_path / "state_0.npy"), np.load(tmp_path / "state_1.npy")], axis=1)
+    assert np.array_equal(got, whole.state)
+    steps, episodes, tmax = (tmp_path / "agg.txt").read_text().split()
+    assert int(steps) == 96 * 300 and int(episodes) == eps and float(tmax) == 2.0

@@ -1,0 +1,145 @@
+"""GPU tests of the drop-in API surface: the reference's own two tests restated against the HIP
+path (tests/test_parallel_api.py:5-7 -> API conformance; tests/env/test_env.py:7-21 -> observation
+symmetry), plus the wrapper classes and the error behaviour of the reference's step()."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_env_observation_symmetry_scalar_api():
+    """tests/env/test_env.py:7-21 verbatim in structure: both computer, action 0, until the game ends."""
+    from pikazoo_amd import pikazoo_v0
+
+    env = pikazoo_v0.env(winning_score=15, is_player1_computer=True, is_player2_computer=True, render_mode=None,
+                         num_envs=1, scalar_api=True, auto_reset=False, seed=11)
+
+    def divide_and_assert(observations):
+        p1a, p2a = observations["player_1"][0:13], observations["player_1"][13:26]
+        p2b, p1b = observations["player_2"][0:13], observations["player_2"][13:26]
+        assert np.all(p1a == p1b) and np.all(p2a == p2b)
+
+    observations, infos = env.reset()
+    divide_and_assert(observations)
+    steps = 0
+    while env.agents:
+        actions = {agent: 0 for agent in env.agents}
+        observations, rewards, terminations, truncations, infos = env.step(actions)
+        divide_and_assert(observations)
+        steps += 1
+        assert steps < 200000
+    assert terminations == {"player_1": True, "player_2": True}
+    assert max(infos["player_1"]["score"]) == 15
+    with pytest.raises(RuntimeError):
+        env.step({"player_1": 0, "player_2": 0})
+    env.reset()
+    assert env.agents == ["player_1", "player_2"]
+
+
+def test_parallel_api_conformance_scalar():
+    """What pettingzoo.test.parallel_api_test checks (tests/test_parallel_api.py:7), restated:
+    dict keys == live agents, observations inside observation_space, agent list lifecycle,
+    reset after termination, reward/termination types."""
+    from pikazoo_amd import pikazoo_v0
+
+    env = pikazoo_v0.env(num_envs=1, scalar_api=True, auto_reset=False, winning_score=2, seed=5)
+    rng = np.random.default_rng(0)
+    assert env.possible_agents == ["player_1", "player_2"] and env.metadata["name"] == "pikazoo_v0"
+    for a in env.possible_agents:
+        assert env.action_space(a).n == 18 and env.observation_space(a).shape == (35,)
+        assert env.observation_space(a).dtype == np.int32
+        assert env.observation_space(a) is env.observation_space(a)  # lru_cached like the reference
+    episodes = 0
+    obs, infos = env.reset(seed=42, options={"x": 1})
+    for cycle in range(6000):
+        assert set(obs) == set(env.agents) == set(infos)
+        for a in env.agents:
+            assert obs[a].shape == (35,) and env.observation_space(a).contains(obs[a])
+        actions = {a: int(rng.integers(0, 18)) for a in env.agents}
+        obs, rew, term, trunc, infos = env.step(actions)
+        assert set(obs) == set(rew) == set(term) == set(trunc) == set(infos) == {"player_1", "player_2"}
+        assert isinstance(rew["player_1"], int) and rew["player_1"] == -rew["player_2"]
+        assert isinstance(term["player_1"], bool) and trunc["player_1"] is False
+        assert len(infos["player_1"]["score"]) == 2
+        if term["player_1"]:
+            assert env.agents == [] and max(infos["player_1"]["score"]) == 2
+            episodes += 1
+            obs, infos = env.reset()
+            assert env.agents == env.possible_agents
+    assert episodes >= 3
+
+
+def test_batched_api_shapes_and_types():
+    from pikazoo_amd import pikazoo_v0
+
+    n = 1024
+    env = pikazoo_v0.env(num_envs=n, device="cuda:0", seed=1)
+    assert env.num_envs == n and env.agents == env.possible_agents == ["player_1", "player_2"]
+    obs, infos = env.reset()
+    for a in env.agents:
+        assert obs[a].shape == (n, 35) and obs[a].dtype == torch.int32 and obs[a].is_cuda
+        assert infos[a]["score"].shape == (n, 2)
+    a = {ag: torch.randint(0, 18, (n,), device="cuda:0") for ag in env.agents}  # int64 accepted
+    obs, rew, term, trunc, infos = env.step(a)
+    for ag in env.agents:
+        assert rew[ag].shape == (n,) and rew[ag].dtype == torch.int32
+        assert term[ag].shape == (n,) and term[ag].dtype == torch.bool
+        assert trunc[ag].dtype == torch.bool and not bool(trunc[ag].any())
+    # infos["score"] aliases live state like the reference's list (pikazoo_env.py:573-574)
+    assert infos["player_1"]["score"].data_ptr() == env.scores.data_ptr()
+    # numpy / list actions work for small batches
+    env.step({"player_1": np.zeros(n, np.int64), "player_2": [0] * n})
+
+
+def test_step_error_behaviour():
+    from pikazoo_amd import pikazoo_v0
+
+    env = pikazoo_v0.env(num_envs=8, seed=1, validate_actions=True)
+    env.reset()
+    ok = torch.zeros(8, dtype=torch.int32, device="cuda:0")
+    with pytest.raises(IndexError):  # the reference's table lookup raises IndexError (pikazoo_env.py:182)
+        env.step({"player_1": ok + 18, "player_2": ok})
+    with pytest.raises(IndexError):
+        env.step({"player_1": ok, "player_2": ok - 1})
+    with pytest.raises(KeyError):
+        env.step({"player_1": ok})
+    with pytest.raises(ValueError):
+        env.step({"player_1": ok[:4], "player_2": ok})
+    with pytest.raises(TypeError):
+        env.step({"player_1": ok.float(), "player_2": ok})
+    with pytest.raises(AssertionError):  # pikazoo_env.py:104
+        pikazoo_v0.env(serve="loser")
+    with pytest.raises(NotImplementedError):
+        pikazoo_v0.env(render_mode="human")
+    with pytest.raises(RuntimeError):
+        pikazoo_v0.env(device="cpu")
+
+
+def test_wrappers_surface():
+    from pikazoo_amd import pikazoo_v0
+    from pikazoo_amd.wrappers import RewardByBallPosition, SimplifyAction
+
+    table = (0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01)
+    env = pikazoo_v0.env(num_envs=4096, seed=3)
+    env = SimplifyAction(env)
+    env = RewardByBallPosition(env, additional_reward=table, x_line=216, y_line=176)
+    assert env.action_space("player_1").n == 13 and env.action_space("player_2").n == 13
+    obs, _ = env.reset()
+    for t in range(50):
+        a = env.unwrapped.random_actions(9, t)
+        assert int(a["player_1"].max()) <= 12
+        obs, rew, term, trunc, infos = env.step(a)
+        assert rew["player_1"].dtype == torch.float32
+        # recompute the wrapper on the host from the observation (reward_by_ball_position.py:22-29)
+        bx, by = obs["player_1"][:, 26], obs["player_1"][:, 27]
+        zone = (by > 176).long() + 2 * (bx >= 216).long()
+        tab = torch.tensor(table, device=bx.device)
+        base = torch.where(env.unwrapped.state[41] != 0,
+                           torch.where(env.unwrapped.state[40] != 0, -1.0, 1.0), 0.0)
+        assert torch.equal(rew["player_1"], (base + tab[zone]).float())
+        assert torch.equal(rew["player_2"], (-base + tab[4 + zone]).float())
+    with pytest.raises(AssertionError):
+        RewardByBallPosition(pikazoo_v0.env(num_envs=2), additional_reward=(1, 2, 3))
+    with pytest.raises(RuntimeError):
+        SimplifyAction(env)

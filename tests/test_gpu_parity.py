@@ -1,0 +1,342 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the C ABI
+(libpikazoo_hip.so via pikazoo_amd), against
+
+* the golden trajectories captured from the unmodified reference (tests/golden/*.npz),
+* the CPU oracle (oracle/pz_oracle.c) on seeded random batches at sizes it finishes in seconds,
+* size-independent properties at BASELINE.json's full sizes (65 536 and 524 288 lanes).
+
+Bar: bit-exact for every integer (44 state words, 2x35 observations, int rewards, terminations);
+float32 rewards of the fused RewardByBallPosition are bit-exact against the oracle's fp32 add and
+within 1e-6 of the reference's float64 sum.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import DIGEST_FIXTURES, FULL_FIXTURES, golden_state, load_golden, oracle_config_from_meta
+
+pytestmark = pytest.mark.gpu
+
+
+def make_env(meta=None, **over):
+    from pikazoo_amd import pikazoo_v0
+    from pikazoo_amd.wrappers import RewardByBallPosition, SimplifyAction
+
+    kw = dict(meta["env_kwargs"]) if meta else {}
+    wr = (meta["wrappers"] or {}) if meta else {}
+    if meta:
+        kw.update(num_envs=meta["lanes"], seed=meta["seed"], env_id_base=meta["env_id_base"])
+    wr = dict(wr)
+    wr.update(over.pop("wrappers", {}))
+    kw.update(over)
+    kw.setdefault("device", "cuda:0")
+    kw.setdefault("validate_actions", False)
+    env = pikazoo_v0.env(**kw)
+    if wr.get("simplify_action"):
+        env = SimplifyAction(env)
+    if wr.get("additional_reward") is not None:
+        env = RewardByBallPosition(env, tuple(wr["additional_reward"]), wr.get("x_line", 216), wr.get("y_line", 176))
+    return env
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# 1. golden trajectories of the reference
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", FULL_FIXTURES)
+def test_hip_matches_reference_trajectory(name):
+    d = load_golden(name)
+    meta = d["meta"]
+    env = make_env(meta)
+    raw = env.unwrapped
+    T, L = meta["steps"], meta["lanes"]
+    assert np.array_equal(cpu(raw.state), d["state_ctor"])
+    obs, infos = env.reset(seed=123)  # seed ignored like the reference
+    assert np.array_equal(cpu(raw.state), d["state0"])
+    assert np.array_equal(cpu(obs["player_1"]), d["obs_reset"][:, 0])
+    assert np.array_equal(cpu(obs["player_2"]), d["obs_reset"][:, 1])
+
+    dev = raw.device
+    acts = torch.as_tensor(d["actions"].astype(np.int32), device=dev)  # [T, 2, L]
+    h_state = torch.empty((T, 44, L), dtype=torch.int32, device=dev)
+    h_obs = torch.empty((T, 2, L, 35), dtype=torch.int32, device=dev)
+    h_rew = torch.empty((T, 2, L), dtype=raw.reward_dtype, device=dev)
+    h_term = torch.empty((T, L), dtype=torch.bool, device=dev)
+    for t in range(T):
+        obs, rew, term, trunc, infos = env.step({"player_1": acts[t, 0], "player_2": acts[t, 1]})
+        h_state[t].copy_(raw.state)
+        h_obs[t, 0].copy_(obs["player_1"])
+        h_obs[t, 1].copy_(obs["player_2"])
+        h_rew[t, 0].copy_(rew["player_1"])
+        h_rew[t, 1].copy_(rew["player_2"])
+        h_term[t].copy_(term["player_1"])
+        assert term["player_1"] is term["player_2"]
+    h_state, h_obs, h_rew, h_term = cpu(h_state), cpu(h_obs), cpu(h_rew), cpu(h_term)
+    assert not cpu(trunc["player_1"]).any()
+    for t in range(T):
+        st = golden_state(d, t)
+        if not np.array_equal(h_state[t], st):
+            f, l = np.argwhere(h_state[t] != st)[0]
+            pytest.fail(f"{name}: step {t} lane {l} word {f}: hip {h_state[t][f, l]} != reference {st[f, l]}")
+    assert np.array_equal(h_obs, d["obs"].astype(np.int32).transpose(0, 1, 2, 3))
+    assert np.array_equal(h_term.astype(np.uint8), d["term"])
+    if raw.reward_dtype == torch.float32:
+        np.testing.assert_allclose(h_rew, d["rew"], rtol=0, atol=1e-6)
+    else:
+        assert np.array_equal(h_rew, d["rew"].astype(np.int32))
+
+
+@pytest.mark.parametrize("name", DIGEST_FIXTURES)
+def test_hip_matches_reference_long_run_digests(name, oracle):
+    """20 000-step runs of the reference, one digest per 500 steps, replayed with the on-device
+    random policy (k frames per launch)."""
+    d = load_golden(name)
+    meta = d["meta"]
+    env = make_env(meta)
+    raw = env.unwrapped
+    env.reset()
+    assert np.array_equal(cpu(raw.state), d["state0"])
+    every = meta["digest_every"]
+    for k, dg in enumerate(d["digests"]):
+        env.step_random(meta["action_seed"], t0=k * every, k=every)
+        assert oracle.digest(cpu(raw.state)) == int(dg), f"{name}: after {(k + 1) * every} steps"
+    assert np.array_equal(cpu(raw.state), d["final_state"])
+    assert raw.episodes_done == meta["episodes"]
+
+
+# ------------------------------------------------------------------------------------------------
+# 2. HIP vs CPU oracle on seeded random batches
+# ------------------------------------------------------------------------------------------------
+CASES = {
+    "cfg2_4096_random_random": dict(n=4096, steps=1500, kw=dict(winning_score=15, serve="winner")),
+    "cfg3_p2_computer": dict(n=16384, steps=600, kw=dict(is_player2_computer=True)),
+    "p1_computer_alternate": dict(n=4096, steps=600, kw=dict(is_player1_computer=True, serve="alternate")),
+    "both_computer_random_serve_ws2": dict(n=4096, steps=800, kw=dict(is_player1_computer=True,
+                                                                     is_player2_computer=True, serve="random",
+                                                                     winning_score=2)),
+    "cfg5_wrappers": dict(n=16384, steps=600, kw=dict(winning_score=15),
+                          wr=dict(simplify_action=True,
+                                  additional_reward=(0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01))),
+    "ws1_no_auto_reset": dict(n=2048, steps=500, kw=dict(winning_score=1, auto_reset=False)),
+    "ragged_batch": dict(n=1000 + 37, steps=300, kw=dict(is_player2_computer=True, winning_score=3)),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_hip_matches_oracle_random_batches(case, oracle):
+    c = CASES[case]
+    n, steps, kw, wr = c["n"], c["steps"], dict(c["kw"]), c.get("wr", {})
+    seed, base, aseed = 99, 12345, 4242
+    env = make_env(num_envs=n, seed=seed, env_id_base=base, wrappers=wr, **kw)
+    raw = env.unwrapped
+    ocfg = oracle.make_config(
+        winning_score=kw.get("winning_score", 15), serve=kw.get("serve", "winner"),
+        is_player1_computer=kw.get("is_player1_computer", False),
+        is_player2_computer=kw.get("is_player2_computer", False),
+        simplify_action=bool(wr.get("simplify_action")), additional_reward=wr.get("additional_reward"),
+        auto_reset=kw.get("auto_reset", True), seed=seed, env_id_base=base)
+    ref = oracle.OracleEnv(n, ocfg, nthreads=8)
+    assert np.array_equal(cpu(raw.state), ref.state)
+    obs, _ = env.reset()
+    r1, r2 = ref.reset()
+    assert np.array_equal(cpu(obs["player_1"]), r1) and np.array_equal(cpu(obs["player_2"]), r2)
+    n_act = raw.n_actions
+    for t in range(steps):
+        acts = env.random_actions(aseed, t)
+        a1, a2 = oracle.random_actions(n, base, aseed, t, n_act)
+        if t % 50 == 0:
+            assert np.array_equal(cpu(acts["player_1"]), a1) and np.array_equal(cpu(acts["player_2"]), a2)
+        obs, rew, term, trunc, infos = env.step(acts)
+        robs, rrew, rterm = ref.step(a1, a2)
+        if t % 10 == 0 or t == steps - 1:
+            hs = cpu(raw.state)
+            if not np.array_equal(hs, ref.state):
+                f, l = np.argwhere(hs != ref.state)[0]
+                pytest.fail(f"{case}: step {t} lane {l} word {oracle.FIELD_NAMES[f]}: "
+                            f"hip {hs[f, l]} != oracle {ref.state[f, l]}")
+            assert np.array_equal(cpu(obs["player_1"]), robs[0]), (case, t)
+            assert np.array_equal(cpu(obs["player_2"]), robs[1]), (case, t)
+            assert np.array_equal(cpu(rew["player_1"]), rrew[0]), (case, t)  # bit-exact, fp32 included
+            assert np.array_equal(cpu(rew["player_2"]), rrew[1]), (case, t)
+            assert np.array_equal(cpu(term["player_1"]).astype(np.uint8), rterm), (case, t)
+            assert np.array_equal(cpu(infos["player_1"]["score"]), ref.state[38:40].T)
+    assert ref.state[43].min() >= 4  # draws happened
+
+
+def test_step_random_equals_step_with_policy_stream(oracle):
+    n, aseed = 8192, 31337
+    kw = dict(num_envs=n, seed=5, env_id_base=777, is_player2_computer=True, winning_score=4)
+    e1, e2, e3 = make_env(**kw), make_env(**kw), make_env(**kw)
+    for e in (e1, e2, e3):
+        e.reset()
+    total_term = 0
+    for t in range(240):
+        o1 = e1.step(e1.random_actions(aseed, t))
+        o2 = e2.step_random(aseed)  # t0 defaults to steps_done
+        total_term += int(o1[2]["player_1"].sum().item())
+        if t % 40 == 0 or t == 239:
+            assert torch.equal(e1.state, e2.state)
+            for a in ("player_1", "player_2"):
+                assert torch.equal(o1[0][a], o2[0][a]) and torch.equal(o1[1][a], o2[1][a])
+            assert torch.equal(o1[2]["player_1"], o2[2]["player_1"])
+    # k frames in one launch == k launches; outputs are the last frame's
+    for k0 in range(0, 240, 60):
+        o3 = e3.step_random(aseed, t0=k0, k=60)
+    assert torch.equal(e1.state, e3.state)
+    assert torch.equal(o1[0]["player_1"], o3[0]["player_1"]) and torch.equal(o1[1]["player_2"], o3[1]["player_2"])
+    assert e2.episodes_done == total_term == e3.episodes_done and total_term > 0
+    ocfg = oracle.make_config(winning_score=4, is_player2_computer=True, seed=5, env_id_base=777)
+    ref = oracle.OracleEnv(n, ocfg, nthreads=8)
+    ref.reset()
+    assert ref.rollout_random(aseed, 0, 240) == total_term
+    assert np.array_equal(cpu(e3.state), ref.state)
+
+
+# ------------------------------------------------------------------------------------------------
+# 3. full-size properties (no oracle): 65 536 and 524 288 lanes
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,kw", [
+    (65536, dict(is_player2_computer=True)),
+    (524288, dict()),
+])
+def test_full_size_properties(n, kw, oracle):
+    from pikazoo_amd.env import OBS_HIGH, OBS_LOW
+
+    env = make_env(num_envs=n, seed=2024, env_id_base=0, winning_score=3, **kw)
+    raw = env.unwrapped
+    env.reset()
+    lo = torch.as_tensor(OBS_LOW, device=raw.device)
+    hi = torch.as_tensor(OBS_HIGH, device=raw.device)
+    terms = 0
+    for t in range(400):
+        obs, rew, term, trunc, infos = env.step_random(7)
+        if t % 25 == 0 or t == 399:
+            o1, o2 = obs["player_1"], obs["player_2"]
+            # the reference's own property test (tests/env/test_env.py:18-21) on every lane
+            assert torch.equal(o1[:, 0:13], o2[:, 13:26]) and torch.equal(o1[:, 13:26], o2[:, 0:13])
+            assert torch.equal(o1[:, 26:], o2[:, 26:])
+            # observation_space bounds (pikazoo_env.py:485-562); the ball's previous positions may be 0
+            assert bool(((o1 >= lo) & (o1 <= hi)).all())
+            # observation == _get_obs(state); terminated == game_ended; rewards antisymmetric
+            fresh = raw.observe()
+            assert torch.equal(fresh["player_1"], o1) and torch.equal(fresh["player_2"], o2)
+            assert torch.equal(term["player_1"], raw.state[42] != 0)
+            assert torch.equal(rew["player_1"], -rew["player_2"])
+            assert bool((rew["player_1"].abs() <= 1).all())
+            assert bool((raw.scores <= 3).all()) and bool((raw.scores >= 0).all())
+            # a reward is paid exactly on round-ending frames
+            assert torch.equal(rew["player_1"] != 0, raw.state[41] != 0)
+        terms += int(term["player_1"].sum().item())
+    assert terms > 0 and raw.episodes_done == terms
+    # determinism + shard invariance: the first 4 096 lanes of a shard starting at lane 1 000
+    sub = make_env(num_envs=4096, seed=2024, env_id_base=1000, winning_score=3, **kw)
+    sub.reset()
+    sub.step_random(7, t0=0, k=400)
+    assert torch.equal(sub.unwrapped.state, raw.state[:, 1000:1000 + 4096])
+    # cross-check a slice against the oracle at full length
+    ocfg = oracle.make_config(winning_score=3, is_player2_computer=kw.get("is_player2_computer", False), seed=2024,
+                              env_id_base=n - 512)
+    ref = oracle.OracleEnv(512, ocfg, nthreads=8)
+    ref.reset()
+    ref.rollout_random(7, 0, 400)
+    assert np.array_equal(cpu(raw.state[:, n - 512:]), ref.state)
+
+
+# ------------------------------------------------------------------------------------------------
+# 4. C ABI edge cases
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 129])
+def test_small_and_ragged_sizes(n, oracle):
+    env = make_env(num_envs=n, seed=1, env_id_base=5, is_player1_computer=True, is_player2_computer=True,
+                   winning_score=1)
+    env.reset()
+    ref = oracle.OracleEnv(n, oracle.make_config(winning_score=1, is_player1_computer=True, is_player2_computer=True,
+                                                 seed=1, env_id_base=5))
+    ref.reset()
+    for t in range(300):
+        acts = env.random_actions(3, t)
+        obs, rew, term, _, _ = env.step(acts)
+        robs, rrew, rterm = ref.step(cpu(acts["player_1"]), cpu(acts["player_2"]))
+    assert np.array_equal(cpu(env.unwrapped.state), ref.state)
+    assert np.array_equal(cpu(obs["player_1"]), robs[0]) and np.array_equal(cpu(obs["player_2"]), robs[1])
+    assert np.array_equal(cpu(rew["player_1"]), rrew[0])
+
+
+def test_stride_larger_than_n_and_error_codes(oracle):
+    from pikazoo_amd import _native
+
+    lib = _native.load()
+    n, stride = 100, 256
+    cfg = _native.PzConfig()
+    cfg.winning_score, cfg.serve_mode, cfg.p2_computer, cfg.auto_reset, cfg.seed, cfg.env_id_base = 2, 0, 1, 1, 77, 9
+    dev = torch.device("cuda:0")
+    state = torch.full((44, stride), -7, dtype=torch.int32, device=dev)
+    obs1 = torch.zeros((n, 35), dtype=torch.int32, device=dev)
+    obs2 = torch.zeros_like(obs1)
+    rew1 = torch.zeros(n, dtype=torch.int32, device=dev)
+    rew2 = torch.zeros_like(rew1)
+    term = torch.zeros(n, dtype=torch.uint8, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.pz_init(state.data_ptr(), n, stride, C.byref(cfg), s) == 0
+    assert lib.pz_reset(state.data_ptr(), n, stride, C.byref(cfg), None, obs1.data_ptr(), obs2.data_ptr(), s) == 0
+    for t in range(100):
+        assert lib.pz_step_random(state.data_ptr(), n, stride, C.byref(cfg), 11, t, 1, obs1.data_ptr(),
+                                  obs2.data_ptr(), rew1.data_ptr(), rew2.data_ptr(), term.data_ptr(), None, s) == 0
+    torch.cuda.synchronize()
+    assert bool((state[:, n:] == -7).all()), "columns beyond n must not be touched"
+    ref = oracle.OracleEnv(n, oracle.make_config(winning_score=2, is_player2_computer=True, seed=77, env_id_base=9))
+    ref.reset()
+    ref.rollout_random(11, 0, 100)
+    assert np.array_equal(cpu(state[:, :n]), ref.state)
+    assert np.array_equal(cpu(obs1), ref.obs[0])
+    # argument errors are reported, not launched
+    assert lib.pz_init(None, n, stride, C.byref(cfg), s) == -1
+    assert lib.pz_init(state.data_ptr(), n, n - 1, C.byref(cfg), s) == -2
+    cfg.winning_score = 0
+    assert lib.pz_init(state.data_ptr(), n, stride, C.byref(cfg), s) == -3
+    cfg.winning_score = 2
+    assert lib.pz_step_random(state.data_ptr(), n, stride, C.byref(cfg), 11, 0, 0, obs1.data_ptr(), obs2.data_ptr(),
+                              rew1.data_ptr(), rew2.data_ptr(), term.data_ptr(), None, s) == -2
+    assert lib.pz_observe(state.data_ptr(), n, stride, obs1.data_ptr() + 4, obs2.data_ptr(), s) == -4
+    assert lib.pz_init(state.data_ptr(), 0, stride, C.byref(cfg), s) == 0  # empty batch is a no-op
+    assert b"aligned" in lib.pz_error_string(-4)
+
+
+def test_masked_reset_and_frozen_lanes(oracle):
+    n = 256
+    env = make_env(num_envs=n, seed=3, winning_score=1, auto_reset=False)
+    raw = env.unwrapped
+    ref = oracle.OracleEnv(n, oracle.make_config(winning_score=1, seed=3, auto_reset=False))
+    env.reset(), ref.reset()
+    for t in range(500):
+        acts = env.random_actions(8, t)
+        obs, rew, term, _, _ = env.step(acts)
+        ref.step(cpu(acts["player_1"]), cpu(acts["player_2"]))
+    assert bool(term["player_1"].all()) and np.array_equal(cpu(raw.state), ref.state)
+    frozen = raw.state.clone()
+    obs, rew, term, _, _ = env.step(acts)
+    assert torch.equal(raw.state, frozen) and bool((rew["player_1"] == 0).all()) and bool(term["player_1"].all())
+    mask = (torch.arange(n, device=raw.device) % 3 == 0)
+    obs, _ = env.reset(mask=mask)
+    r1, r2 = ref.reset(cpu(mask).astype(np.uint8))
+    assert np.array_equal(cpu(raw.state), ref.state)
+    assert np.array_equal(cpu(obs["player_1"]), r1) and np.array_equal(cpu(obs["player_2"]), r2)
+    assert torch.equal(raw.state[42] != 0, ~mask)
+
+
+def test_checkpoint_roundtrip():
+    env = make_env(num_envs=512, seed=8, is_player2_computer=True)
+    env.reset()
+    env.step_random(1, k=100)
+    sd = env.unwrapped.state_dict()
+    env.step_random(1, k=50)
+    after = env.unwrapped.state.clone()
+    env2 = make_env(num_envs=512, seed=8, is_player2_computer=True)
+    env2.unwrapped.load_state_dict(sd)
+    env2.step_random(1, k=50)
+    assert torch.equal(env2.unwrapped.state, after)
