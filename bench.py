@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--p2-computer", action="store_true", help="config 3: rule-based AI on player 2")
     ap.add_argument("--wrappers", action="store_true", help="config 5: fused SimplifyAction+RewardByBallPosition")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of the CPU baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on CPU baseline threads")
     ap.add_argument("--check-lanes", type=int, default=2048, help="lanes replayed on the CPU oracle for parity")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--extra", action="store_true", help="also time configs 3 and 5 and report them under 'extra'")
@@ -147,12 +148,25 @@ def run_gpu(args, env, acts, warmup, steps, launch):
     return wall, ev_ms
 
 
+def usable_cores(requested: int) -> int:
+    """Threads for the CPU baseline: the cores this process may actually run on (affinity mask and
+    cgroup CPU quota), capped at `requested` (the GPU box gives one GPU's job a 16-core share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, min(n, requested))
+
+
 def cpu_baseline(args, raw_gpu, p2_computer, wrappers, total_steps):
     """Oracle timed on the host cores (bounded sample) + bit-exact check of a GPU lane subset."""
     from oracle import pz_oracle as po
 
     po.build()
-    cores = os.cpu_count() or 1
+    cores = usable_cores(args.cpu_threads)
     table = (0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01) if wrappers else None
     n = raw_gpu.num_envs
 
@@ -160,11 +174,11 @@ def cpu_baseline(args, raw_gpu, p2_computer, wrappers, total_steps):
         return po.make_config(winning_score=15, serve="winner", is_player2_computer=p2_computer,
                               simplify_action=wrappers, additional_reward=table, seed=0, env_id_base=base)
 
-    # timing sample: the same 65 536-game batch, as many 50-step chunks as fit the budget
+    # timing sample: the same 65 536-game batch, as many 250-step chunks as fit the budget
     env = po.OracleEnv(n, cfg(raw_gpu.env_id_base), nthreads=cores)
     env.reset()
     env.rollout_random(ACTION_SEED, 0, 10)  # touch pages / spin up the thread pool
-    done, t_spent, chunk = 10, 0.0, 50
+    done, t_spent, chunk = 10, 0.0, 250
     while t_spent < args.cpu_seconds and done < 100000:
         t0 = time.perf_counter()
         env.rollout_random(ACTION_SEED, done, chunk)

@@ -220,8 +220,12 @@ def test_full_size_properties(n, kw, oracle):
             # the reference's own property test (tests/env/test_env.py:18-21) on every lane
             assert torch.equal(o1[:, 0:13], o2[:, 13:26]) and torch.equal(o1[:, 13:26], o2[:, 0:13])
             assert torch.equal(o1[:, 26:], o2[:, 26:])
-            # observation_space bounds (pikazoo_env.py:485-562); the ball's previous positions may be 0
-            assert bool(((o1 >= lo) & (o1 <= hi)).all())
+            # observation_space bounds (pikazoo_env.py:485-562).  Column 33 (ball y velocity) is exempt:
+            # the reference's +-124 is "the minimum and maximum values I observed" (README.md:88-89) and
+            # the reference itself exceeds it (+-145 seen in 2e8 oracle steps of this very run).
+            inb = (o1 >= lo) & (o1 <= hi)
+            inb[:, 33] = True
+            assert bool(inb.all())
             # observation == _get_obs(state); terminated == game_ended; rewards antisymmetric
             fresh = raw.observe()
             assert torch.equal(fresh["player_1"], o1) and torch.equal(fresh["player_2"], o2)
