@@ -195,26 +195,49 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
     const bool live = i < a.n;
     const int valid = (int)min((int64_t)kLanes, a.n - base);
 
-    Game g;
+    Game g{};
     RngId id = make_rng_id(a.cfg, live ? i : 0);
     int reward = 0;
     bool frozen = false;
     unsigned int finished = 0;
-    if (live) {
-        load_game(g, a.state + i, a.stride);
-        if (RANDOM) {
-            const uint32_t n_actions = a.cfg.simplify_action ? 13u : 18u;
-            for (int32_t s = 0; s < a.k; ++s) {
-                int a1, a2;
-                policy_actions(id.id_lo, id.id_hi, a.action_seed, a.t0 + (uint64_t)s, n_actions, a1, a2);
-                reward = step_game<AI1, AI2>(g, a.cfg, id, a1, a2, frozen);
-                finished += (unsigned int)(g.e.game_ended && !frozen);
-            }
-        } else {
-            reward = step_game<AI1, AI2>(g, a.cfg, id, a.act_p1[i], a.act_p2[i], frozen);
-            finished = (unsigned int)(g.e.game_ended && !frozen);
+#ifdef PZ_ABLATE
+    // timing-only build (tools/ablate.py): cfg.reserved bits redirect traffic to one workgroup's
+    // span (so it stays in cache) or skip the frame; results are wrong by construction.
+    const int ab = a.cfg.reserved;
+    const int64_t i_ld = (ab & 1) ? lane : i;          // bit0: state loads hit workgroup 0's columns
+    const int64_t i_st = (ab & 2) ? lane : i;          // bit1: state stores go to workgroup 0's columns
+    const int64_t obs_base = (ab & 4) ? 0 : base;      // bit2: observation rows go to workgroup 0's span
+#define PZ_LD_INDEX i_ld
+#define PZ_ST_INDEX i_st
+#define PZ_OBS_BASE obs_base
+#define PZ_SKIP_FRAME (ab & 8)                         // bit3: no game logic
+#define PZ_SKIP_OBS (ab & 16)                          // bit4: no observation staging / flush at all
+#else
+#define PZ_LD_INDEX i
+#define PZ_ST_INDEX i
+#define PZ_OBS_BASE base
+#define PZ_SKIP_FRAME 0
+#define PZ_SKIP_OBS 0
+#endif
+    if (live) load_game(g, a.state + PZ_LD_INDEX, a.stride);
+    // The frame runs in wave-uniform control flow (the computer player's power-hit candidates
+    // are evaluated cooperatively by the wave); lanes past the end of the batch idle inside.
+    // lds_obs[0] doubles as the cooperative scratch until the observations are staged.
+    if (RANDOM) {
+        const uint32_t n_actions = a.cfg.simplify_action ? 13u : 18u;
+        for (int32_t s = 0; s < a.k; ++s) {
+            int a1, a2;
+            policy_actions(id.id_lo, id.id_hi, a.action_seed, a.t0 + (uint64_t)s, n_actions, a1, a2);
+            reward = step_games<AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane);
+            finished += (unsigned int)(live && g.e.game_ended && !frozen);
         }
-        store_game(g, a.state + i, a.stride);
+    } else if (!PZ_SKIP_FRAME) {
+        const int a1 = live ? a.act_p1[i] : 0, a2 = live ? a.act_p2[i] : 0;
+        reward = step_games<AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane);
+        finished = (unsigned int)(live && g.e.game_ended && !frozen);
+    }
+    if (live) {
+        store_game(g, a.state + PZ_ST_INDEX, a.stride);
 
         // rewards (pikazoo_env.py:217-228), optionally with RewardByBallPosition fused
         // (reward_by_ball_position.py:22-29: zone from the post-step ball position)
@@ -232,11 +255,13 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
             static_cast<int32_t*>(a.rew_p2)[i] = -reward;
         }
         a.terminated[i] = (uint8_t)g.e.game_ended;  // :233
-        stage_obs(g, lds_obs[0], lds_obs[1], lane);
+        if (!PZ_SKIP_OBS) stage_obs(g, lds_obs[0], lds_obs[1], lane);
     }
     __syncthreads();
-    flush_rows(lds_obs[0], a.obs_p1 + base * PZ_OBS_DIM, valid * PZ_OBS_DIM, lane);
-    flush_rows(lds_obs[1], a.obs_p2 + base * PZ_OBS_DIM, valid * PZ_OBS_DIM, lane);
+    if (!PZ_SKIP_OBS) {
+        flush_rows(lds_obs[0], a.obs_p1 + PZ_OBS_BASE * PZ_OBS_DIM, valid * PZ_OBS_DIM, lane);
+        flush_rows(lds_obs[1], a.obs_p2 + PZ_OBS_BASE * PZ_OBS_DIM, valid * PZ_OBS_DIM, lane);
+    }
 
     if (a.episodes_done != nullptr) {
         // one atomic per wave: reduce the per-lane counts across the wavefront first

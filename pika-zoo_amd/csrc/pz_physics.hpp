@@ -293,17 +293,35 @@ __device__ __forceinline__ int predict_landing_x(int x, int y, int xv, int yv)
 
 // ---------------------------------------------------------------------------------------
 // Rule-based computer player: let_computer_decide_user_input (physics.py:689-771) with
-// decide_whether_input_power_hit (:774-817) folded in.  IS_P2 selects the court side.
-// Overwrites the decoded user input entirely (:709-711); may tick the RNG.
+// decide_whether_input_power_hit (:774-817).  IS_P2 selects the court side.
+//
+// The decision is split in three so that the expensive part -- up to six power-hit flight
+// predictions per deciding player -- is shared by the whole wavefront instead of being run
+// one after the other by the few lanes that need it:
+//   begin  (per lane)   everything up to the point where the six candidates are needed,
+//                       including the RNG draws in the reference's order (:728,:729,:795);
+//   candidates (wave)   every (deciding lane, candidate) pair becomes one work item; items are
+//                       dealt to the 64 lanes, so a wave's cost is the longest single flight,
+//                       not the sum of six;
+//   finish (per lane)   first candidate in the drawn scan order that lands on the opponent's
+//                       side and > 64 away from the opponent wins (:796-816), then :768-771.
+// The candidates are pure functions of the ball, so evaluating all six is result-identical
+// to the reference's early-exit scan.
 // ---------------------------------------------------------------------------------------
-template <bool IS_P2>
-__device__ __forceinline__ void computer_decide(Player& p, const Ball& b, const Player& other, Input& in,
-                                                const RngId& id, uint32_t& rng)
-{
-    constexpr int kLeft = IS_P2 ? kGroundHalfWidth : 0;                    // left boundary of own side
-    constexpr int kRight = kLeft + kGroundHalfWidth;                       // right boundary
-    constexpr int kOppHigh = (IS_P2 ? kGroundWidth : 0) + kGroundHalfWidth;  // :718 / :801
+struct HitScan {
+    bool need;       // this lane's computer player is choosing a power-hit direction
+    bool ascending;  // y_direction scanned -1,0,1 (draw == 0) or 1,0,-1
+};
 
+template <bool IS_P2>
+__device__ __forceinline__ HitScan computer_decide_begin(Player& p, const Ball& b, Input& in, const RngId& id,
+                                                         uint32_t& rng)
+{
+    constexpr int kLeft = IS_P2 ? kGroundHalfWidth : 0;                      // left boundary of own side
+    constexpr int kRight = kLeft + kGroundHalfWidth;                         // right boundary
+    constexpr int kOppHigh = (IS_P2 ? kGroundWidth : 0) + kGroundHalfWidth;  // :718
+
+    HitScan hs{false, false};
     in.xd = 0;
     in.yd = 0;
     in.hit = 0;
@@ -331,29 +349,75 @@ __device__ __forceinline__ void computer_decide(Player& p, const Ball& b, const 
     } else if (p.state == 1 || p.state == 2) {
         if (dxb > 8) in.xd = (p.x < b.x) ? 1 : -1;
         if (dxb < 48 && abs(b.y - p.y) < 48) {
-            // decide_whether_input_power_hit: scan x_direction 1,0 and y_direction in the
-            // order chosen by one draw (:795); first candidate whose predicted landing is on
-            // the opponent's side and > 64 away from the opponent wins.
-            const bool ascending = rng_integers(id, rng, 2u) == 0;
-            bool found = false;
-            for (int c = 0; c < 6 && !found; ++c) {
-                const int xdir = c < 3 ? 1 : 0;
-                const int j = c < 3 ? c : c - 3;
-                const int ydir = ascending ? j - 1 : 1 - j;
-                const int sxv = (b.x < kGroundHalfWidth) ? (xdir + 1) * 10 : -(xdir + 1) * 10;  // :841-844
-                const int syv = abs(b.yv) * ydir * 2;                                          // :845
-                const int ex = predict_landing_x<false>(b.x, b.y, sxv, syv);
-                if ((ex <= kLeft || ex >= kOppHigh) && abs(ex - other.x) > kPlayerLength) {
-                    in.xd = xdir;
-                    in.yd = ydir;
-                    found = true;
-                }
-            }
-            if (found) {
-                in.hit = 1;
-                if (abs(other.x - p.x) < 80 && in.yd != -1) in.yd = -1;
-            }
+            hs.need = true;
+            hs.ascending = rng_integers(id, rng, 2u) == 0;  // :795
         }
+    }
+    return hs;
+}
+
+// candidate c = 0..5 in canonical order: x_direction 1 for c<3 else 0; y_direction (c mod 3) - 1
+__device__ __forceinline__ int candidate_xdir(int c) { return c < 3 ? 1 : 0; }
+__device__ __forceinline__ int candidate_ydir(int c) { return (c < 3 ? c : c - 3) - 1; }
+
+// Wave-cooperative evaluation of expected_landing_point_x_when_power_hit (:820-884) for the six
+// candidates of every lane with `need`.  Must be called by all 64 lanes of the (single-wave)
+// workgroup in uniform control flow.  scratch: >= 576 words of LDS.
+__device__ __forceinline__ void wave_power_hit_candidates(bool need, const Ball& b, int (&ex)[6],
+                                                          int32_t* __restrict__ scratch, int lane)
+{
+    const unsigned long long mask = __ballot(need);
+    if (mask == 0ull) return;  // wave-uniform
+    const int deciders = __popcll(mask);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (need) {
+        scratch[rank] = b.x;
+        scratch[64 + rank] = b.y;
+        scratch[128 + rank] = abs(b.yv);
+    }
+    __syncthreads();
+    const int items = deciders * 6;
+    for (int first = 0; first < items; first += 64) {
+        const int item = first + lane;
+        if (item < items) {
+            const int r = item / 6, c = item - 6 * r;
+            const int sx = scratch[r], sy = scratch[64 + r], sayv = scratch[128 + r];
+            const int xdir = candidate_xdir(c), ydir = candidate_ydir(c);
+            const int sxv = (sx < kGroundHalfWidth) ? (xdir + 1) * 10 : -(xdir + 1) * 10;  // :841-844
+            const int syv = sayv * ydir * 2;                                              // :845
+            scratch[192 + item] = predict_landing_x<false>(sx, sy, sxv, syv);
+        }
+    }
+    __syncthreads();
+    if (need) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ex[c] = scratch[192 + rank * 6 + c];
+    }
+    __syncthreads();  // scratch is reused (observation staging)
+}
+
+template <bool IS_P2>
+__device__ __forceinline__ void computer_decide_finish(const HitScan& hs, const int (&ex)[6], const Player& p,
+                                                       const Player& other, Input& in)
+{
+    constexpr int kLeft = IS_P2 ? kGroundHalfWidth : 0;
+    constexpr int kOppHigh = (IS_P2 ? kGroundWidth : 0) + kGroundHalfWidth;  // :801
+    if (!hs.need) return;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        // scan order: x_direction 1 then 0; y_direction ascending (-1,0,1) or descending (1,0,-1)
+        const int c = hs.ascending ? k : (k < 3 ? 2 - k : 8 - k);
+        const int e = ex[c];
+        if (!found && (e <= kLeft || e >= kOppHigh) && abs(e - other.x) > kPlayerLength) {
+            in.xd = candidate_xdir(c);
+            in.yd = candidate_ydir(c);
+            found = true;
+        }
+    }
+    if (found) {
+        in.hit = 1;
+        if (abs(other.x - p.x) < 80 && in.yd != -1) in.yd = -1;
     }
 }
 
@@ -465,91 +529,113 @@ __device__ __forceinline__ void ball_player_collision(Ball& b, int player_x, con
 }
 
 // ---------------------------------------------------------------------------------------
-// One frame of one game: raw_env.step (pikazoo_env.py:175-240) around physics_engine
-// (physics.py:280-337).  Returns player_1's reward (+1/-1/0); player_2's is its negation.
+// One frame of the wave's 64 games: raw_env.step (pikazoo_env.py:175-240) around
+// physics_engine (physics.py:280-337).  Called by ALL lanes of the wave in uniform control
+// flow (the power-hit candidates are evaluated cooperatively); `live` is false for lanes past
+// the end of the batch.  Returns player_1's reward (+1/-1/0); player_2's is its negation.
 // `frozen` (auto_reset off and the game already over) leaves the game untouched.
 // ---------------------------------------------------------------------------------------
 template <bool AI1, bool AI2>
-__device__ __forceinline__ int step_game(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool& frozen)
+__device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
+                                          bool& frozen, int32_t* __restrict__ scratch, int lane)
 {
     // The reference empties `agents` on termination (:237-238) and expects reset() before the
     // next step; auto_reset applies reset() (:149-164) in place.  Both that and the new-round
     // branch (:176-180) end in the same per-round initialisation, kept at one call site so the
     // wave runs the (divergent, Philox-drawing) body once.
-    frozen = g.e.game_ended && !cfg.auto_reset;
-    if (frozen) return 0;
-    if (g.e.round_ended) {  // game_ended implies round_ended
-        if (g.e.game_ended) {
-            g.e.game_ended = 0;
-            g.e.p2serve = 0;
-            g.e.s1 = 0;
-            g.e.s2 = 0;
+    frozen = live && g.e.game_ended && !cfg.auto_reset;
+    const bool active = live && !frozen;
+    Input in1{0, 0, 0}, in2{0, 0, 0};
+    bool ground = false;
+    if (active) {
+        if (g.e.round_ended) {  // game_ended implies round_ended
+            if (g.e.game_ended) {
+                g.e.game_ended = 0;
+                g.e.p2serve = 0;
+                g.e.s1 = 0;
+                g.e.s2 = 0;
+            }
+            g.e.round_ended = 0;
+            start_round(g, cfg, id);
         }
-        g.e.round_ended = 0;
-        start_round(g, cfg, id);
-    }
 
-    // :182-184 -- every player's key state is sampled, computer-controlled or not
-    Input in1, in2;
-    if (cfg.simplify_action) {
-        in1 = decode_action(kSimpleTablesP1, a1, g.p1.hitprev);
-        in2 = decode_action(kSimpleTablesP2, a2, g.p2.hitprev);
-    } else {
-        in1 = decode_action(kFullTables, a1, g.p1.hitprev);
-        in2 = decode_action(kFullTables, a2, g.p2.hitprev);
-    }
-
-    // physics_engine
-    const bool ground = ball_world_step(g.b);
-
-    if (AI1 || AI2) {
-        // :314-315 recomputes the landing point before each player; the ball does not move
-        // between the two calls, so one evaluation serves both.
-        g.b.ex = predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
-    }
-    if (AI1) computer_decide<false>(g.p1, g.b, g.p2, in1, id, g.e.rng);
-    player_move<false>(g.p1, in1);
-    if (AI2) computer_decide<true>(g.p2, g.b, g.p1, in2, id, g.e.rng);
-    player_move<true>(g.p2, in2);
-
-    bool hit_processed = false;
-    {
-        const bool touch = ball_touches_player(g.b, g.p1);
-        if (touch && !g.p1.coll) {
-            ball_player_collision(g.b, g.p1.x, in1, g.p1.state, id, g.e.rng);
-            hit_processed = true;
-        }
-        g.p1.coll = touch;
-    }
-    {
-        const bool touch = ball_touches_player(g.b, g.p2);
-        if (touch && !g.p2.coll) {
-            ball_player_collision(g.b, g.p2.x, in2, g.p2.state, id, g.e.rng);
-            hit_processed = true;
-        }
-        g.p2.coll = touch;
-    }
-    if ((AI1 || AI2) && hit_processed) {
-        // :331-332 -- when both players hit in one frame the second evaluation overwrites the
-        // first, so a single one after both collisions leaves the same value.
-        g.b.ex = predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
-    }
-
-    // scoring / round end / game end (:190-210); round_ended and game_ended are both 0 here
-    int reward = 0;
-    if (ground) {
-        if (g.b.punch < kGroundHalfWidth) {
-            g.e.p2serve = 1;
-            g.e.s2 += 1;
-            if (g.e.s2 >= cfg.winning_score) g.e.game_ended = 1;
-            reward = -1;
+        // :182-184 -- every player's key state is sampled, computer-controlled or not
+        if (cfg.simplify_action) {
+            in1 = decode_action(kSimpleTablesP1, a1, g.p1.hitprev);
+            in2 = decode_action(kSimpleTablesP2, a2, g.p2.hitprev);
         } else {
-            g.e.p2serve = 0;
-            g.e.s1 += 1;
-            if (g.e.s1 >= cfg.winning_score) g.e.game_ended = 1;
-            reward = 1;
+            in1 = decode_action(kFullTables, a1, g.p1.hitprev);
+            in2 = decode_action(kFullTables, a2, g.p2.hitprev);
         }
-        g.e.round_ended = 1;
+
+        // physics_engine
+        ground = ball_world_step(g.b);
+
+        if (AI1 || AI2) {
+            // :314-315 recomputes the landing point before each player; the ball does not move
+            // between the two calls, so one evaluation serves both.
+            g.b.ex = predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
+        }
+    }
+
+    if (AI1) {
+        HitScan hs{false, false};
+        int ex[6] = {0, 0, 0, 0, 0, 0};
+        if (active) hs = computer_decide_begin<false>(g.p1, g.b, in1, id, g.e.rng);
+        wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
+        computer_decide_finish<false>(hs, ex, g.p1, g.p2, in1);
+    }
+    if (active) player_move<false>(g.p1, in1);
+    if (AI2) {
+        HitScan hs{false, false};
+        int ex[6] = {0, 0, 0, 0, 0, 0};
+        if (active) hs = computer_decide_begin<true>(g.p2, g.b, in2, id, g.e.rng);
+        wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
+        computer_decide_finish<true>(hs, ex, g.p2, g.p1, in2);
+    }
+
+    int reward = 0;
+    if (active) {
+        player_move<true>(g.p2, in2);
+
+        bool hit_processed = false;
+        {
+            const bool touch = ball_touches_player(g.b, g.p1);
+            if (touch && !g.p1.coll) {
+                ball_player_collision(g.b, g.p1.x, in1, g.p1.state, id, g.e.rng);
+                hit_processed = true;
+            }
+            g.p1.coll = touch;
+        }
+        {
+            const bool touch = ball_touches_player(g.b, g.p2);
+            if (touch && !g.p2.coll) {
+                ball_player_collision(g.b, g.p2.x, in2, g.p2.state, id, g.e.rng);
+                hit_processed = true;
+            }
+            g.p2.coll = touch;
+        }
+        if ((AI1 || AI2) && hit_processed) {
+            // :331-332 -- when both players hit in one frame the second evaluation overwrites the
+            // first, so a single one after both collisions leaves the same value.
+            g.b.ex = predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
+        }
+
+        // scoring / round end / game end (:190-210); round_ended and game_ended are both 0 here
+        if (ground) {
+            if (g.b.punch < kGroundHalfWidth) {
+                g.e.p2serve = 1;
+                g.e.s2 += 1;
+                if (g.e.s2 >= cfg.winning_score) g.e.game_ended = 1;
+                reward = -1;
+            } else {
+                g.e.p2serve = 0;
+                g.e.s1 += 1;
+                if (g.e.s1 >= cfg.winning_score) g.e.game_ended = 1;
+                reward = 1;
+            }
+            g.e.round_ended = 1;
+        }
     }
     return reward;
 }

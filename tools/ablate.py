@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Timing-only ablation of the step kernel (diagnostic, not product, not a test).
+
+Builds csrc with -DPZ_ABLATE into pika-zoo_amd/lib/libpikazoo_hip_ablate.so and times the
+human-vs-human step at 65 536 games with traffic classes redirected to one workgroup's span or the
+frame skipped (cfg.reserved bits, see pz_kernels.hip).  Interleaved rounds in one process
+(cdna_hip_programming.md rule 24); prints median / min microseconds per launch from HIP events.
+
+    python tools/ablate.py --build      # here (cross-compile)
+    python tools/ablate.py              # on the GPU box
+"""
+import ctypes as C
+import statistics
+import subprocess
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "pika-zoo_amd"))
+LIB = REPO / "pika-zoo_amd" / "lib" / "libpikazoo_hip_ablate.so"
+
+
+def build():
+    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-DPZ_ABLATE=1",
+           f"-I{REPO / 'include'}", f"-I{REPO / 'pika-zoo_amd' / 'csrc'}", "-o", str(LIB),
+           str(REPO / "pika-zoo_amd" / "csrc" / "pz_kernels.hip")]
+    subprocess.check_call(cmd)
+
+
+def main():
+    if "--build" in sys.argv:
+        build()
+        return
+    import torch
+    from pikazoo_amd import _native
+
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    p2ai = "--ai" in sys.argv
+    lib = C.CDLL(str(LIB))
+    dev = torch.device("cuda:0")
+    cfg = _native.PzConfig()
+    cfg.winning_score, cfg.auto_reset, cfg.seed, cfg.p2_computer = 15, 1, 0, int(p2ai)
+    state = torch.zeros((44, n), dtype=torch.int32, device=dev)
+    obs = [torch.zeros((n, 35), dtype=torch.int32, device=dev) for _ in range(2)]
+    rew = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
+    term = torch.zeros(n, dtype=torch.uint8, device=dev)
+    acts = torch.randint(0, 18, (64, 2, n), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    P = C.c_void_p
+    lib.pz_init.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P]
+    lib.pz_reset.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P]
+    lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P]
+    assert lib.pz_init(state.data_ptr(), n, n, C.byref(cfg), stream) == 0
+    assert lib.pz_reset(state.data_ptr(), n, n, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(), stream) == 0
+
+    def run(flags, steps):
+        cfg.reserved = flags
+        for t in range(steps):
+            a = acts[t % 64]
+            lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
+                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), stream)
+
+    run(0, 600)  # desynchronise the games so divergence is realistic
+    snapshot = state.clone()
+    variants = {
+        "baseline": 0, "loads_cached": 1, "state_stores_cached": 2, "obs_stores_cached": 4,
+        "all_stores_cached": 6, "all_traffic_cached": 7, "no_frame": 8, "no_obs": 16,
+        "no_frame_no_obs": 24, "no_frame_all_cached": 15, "nothing": 31,
+    }
+    times = {k: [] for k in variants}
+    K = 300
+    for rnd in range(7):
+        for name, flags in variants.items():
+            state.copy_(snapshot)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run(flags, K)
+            e1.record()
+            torch.cuda.synchronize()
+            times[name].append(e0.elapsed_time(e1) * 1e3 / K)
+    print(f"n={n} p2_computer={p2ai}: microseconds per launch (median / min over 7 interleaved rounds of {K})")
+    for name in variants:
+        print(f"  {name:24s} {statistics.median(times[name]):7.2f} {min(times[name]):7.2f}")
+
+
+if __name__ == "__main__":
+    main()
