@@ -133,6 +133,17 @@ int pz_step_random(int32_t *state, int64_t n, int64_t stride, const pz_config *c
 int pz_random_actions(int32_t *act_p1, int32_t *act_p2, int64_t n, int64_t env_id_base,
                       uint64_t action_seed, uint64_t t, int32_t n_actions, void *stream);
 
+/* ---- self-test hook ------------------------------------------------------------------------
+ * The computer player's flight predictors (calculate_expected_landing_point_x_for
+ * physics.py:643-686 when full_net != 0, expected_landing_point_x_when_power_hit
+ * physics.py:848-884 otherwise) evaluated two ways on n caller-supplied ball states
+ * (x, y, x_velocity, y_velocity; for the power-hit form the velocities are the already
+ * substituted ones): out_fast = the closed-form fast-forward the step kernel uses, out_iter =
+ * the frame-by-frame iteration of the reference.  They must be identical. */
+int pz_selftest_predictor(const int32_t *x, const int32_t *y, const int32_t *xv, const int32_t *yv,
+                          int64_t n, int32_t full_net, int32_t *out_fast, int32_t *out_iter,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -204,6 +204,7 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
     // timing-only build (tools/ablate.py): cfg.reserved bits redirect traffic to one workgroup's
     // span (so it stays in cache) or skip the frame; results are wrong by construction.
     const int ab = a.cfg.reserved;
+    g_pz_ablate_bits = ab;  // every lane stores the same value; read back by the predictor hooks
     const int64_t i_ld = (ab & 1) ? lane : i;          // bit0: state loads hit workgroup 0's columns
     const int64_t i_st = (ab & 2) ? lane : i;          // bit1: state stores go to workgroup 0's columns
     const int64_t obs_base = (ab & 4) ? 0 : base;      // bit2: observation rows go to workgroup 0's span
@@ -336,6 +337,22 @@ __global__ __launch_bounds__(256) void random_actions_kernel(int32_t* act_p1, in
     act_p2[i] = a2;
 }
 
+// Self-test hook: both forms of the flight predictor on caller-supplied ball states.
+__global__ __launch_bounds__(256) void predictor_selftest_kernel(const int32_t* x, const int32_t* y, const int32_t* xv,
+                                                                 const int32_t* yv, int64_t n, int full_net,
+                                                                 int32_t* out_fast, int32_t* out_iter)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (full_net) {
+        out_fast[i] = predict_landing_x<true>(x[i], y[i], xv[i], yv[i]);
+        out_iter[i] = predict_landing_x_iterative<true>(x[i], y[i], xv[i], yv[i]);
+    } else {
+        out_fast[i] = predict_landing_x<false>(x[i], y[i], xv[i], yv[i]);
+        out_iter[i] = predict_landing_x_iterative<false>(x[i], y[i], xv[i], yv[i]);
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 static int check_common(const void* state, int64_t n, int64_t stride, const pz_config* cfg)
 {
@@ -453,6 +470,17 @@ int pz_random_actions(int32_t* act_p1, int32_t* act_p2, int64_t n, int64_t env_i
     if (n == 0) return PZ_OK;
     hipLaunchKernelGGL(random_actions_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, act_p1,
                        act_p2, n, env_id_base, action_seed, t, (uint32_t)n_actions);
+    return (int)hipGetLastError();
+}
+
+int pz_selftest_predictor(const int32_t* x, const int32_t* y, const int32_t* xv, const int32_t* yv, int64_t n,
+                          int32_t full_net, int32_t* out_fast, int32_t* out_iter, void* stream)
+{
+    if (!x || !y || !xv || !yv || !out_fast || !out_iter) return PZ_E_NULL;
+    if (n < 0) return PZ_E_SIZE;
+    if (n == 0) return PZ_OK;
+    hipLaunchKernelGGL(predictor_selftest_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, xv,
+                       yv, n, (int)full_net, out_fast, out_iter);
     return (int)hipGetLastError();
 }
 

@@ -16,6 +16,14 @@
 
 namespace pz {
 
+// timing-only ablation hooks (tools/ablate.py builds with -DPZ_ABLATE; never defined in the product)
+#ifdef PZ_ABLATE
+__device__ int g_pz_ablate_bits;
+#define PZ_ABLATE_SKIP(bit) ((g_pz_ablate_bits & (bit)) != 0)
+#else
+#define PZ_ABLATE_SKIP(bit) false
+#endif
+
 // pikazoo/env/physics.py:9-33
 constexpr int kGroundWidth = 432;
 constexpr int kGroundHalfWidth = 216;
@@ -267,11 +275,111 @@ __device__ __forceinline__ bool ball_world_step(Ball& b)
 //                 net rule (no side bounce).
 // Both keep the reference's iteration cap (physics.py:33): the x at the cap is the result.
 // ---------------------------------------------------------------------------------------
+// The frame-by-frame form, exactly as the reference iterates it.  Kept as the in-library
+// cross-check of the fast-forward form below (pz_selftest_predictor).
 template <bool FULL_NET>
-__device__ __forceinline__ int predict_landing_x(int x, int y, int xv, int yv)
+__device__ __forceinline__ int predict_landing_x_iterative(int x, int y, int xv, int yv)
 {
     int count = 0;
     for (;;) {
+        ++count;
+        const int fx = x + xv;
+        if (fx < kBallRadius || fx > kGroundWidth) xv = -xv;
+        if (y + yv < 0) yv = 1;
+        if (abs(x - kGroundHalfWidth) < kNetPillarHalfWidth && y > kNetTopTopY) {
+            if (!FULL_NET || y < kNetTopBottomY) {
+                if (yv > 0) yv = -yv;
+            } else {
+                xv = (x < kGroundHalfWidth) ? -abs(xv) : abs(xv);
+            }
+        }
+        y += yv;
+        if (y > kBallGroundY || count >= kLoopLimit) break;
+        x += xv;
+        yv += 1;
+    }
+    return x;
+}
+
+// Fast-forward form.  On a GPU the predictor's cost is its longest lane (a wave -- and at one
+// wave per SIMD the whole launch -- waits for the slowest flight), so the free-flight stretches
+// are jumped in closed form instead of being iterated (mean 17 / max ~110 iterations become
+// mean 2.3 / max ~16 loop trips for the landing predictor, 29 / ~215 become 4.6 / ~35 for the
+// power-hit predictor on states sampled from play).
+//
+// With Y(m) = y + m*yv + m(m-1)/2 and X(m) = x + m*xv the state after m "plain" iterations
+// (no wall flip, no ceiling clamp, not in the net box, no landing, cap not reached), the next
+// K iterations are all plain exactly when
+//     20 <= X(m) <= 432   for m = 1..K    (linear: check m = K; X(0) is in range)
+//     0  <= Y(m)          for m = 1..K    (convex: check its lowest point m = clamp(-yv, 1, K);
+//                                           y itself can be negative -- the net-top bounce runs
+//                                           after the ceiling clamp and can throw a very fast
+//                                           ball above 0)
+//     Y(m) <= ymax        for m = 0..K    (convex: check both ends)
+//     count + K <= 998                    (the cap test of iterations 0..K-1 stays false)
+// where ymax = 252 (only landing ends the stretch) if the ball is outside the net box
+// (x <= 191 or x >= 241) and X(0..K-1) stay on that side of it, else ymax = 176 (above the
+// net top, where the box cannot apply).  Then x = X(K), y = Y(K), yv += K, count += K.
+// K is *proposed* in float (distance to the wall or the box edge times 1/|xv|; roots of
+// Y(K) = ymax and, for a ball whose apex would cross the ceiling, of Y(K) = 0) and *verified*
+// with the exact integer conditions above; a failed verification falls back to the single
+// iteration, so the result is identical to the iterative form by construction.
+// pz_selftest_predictor compares the two over the whole input domain on the GPU.
+__device__ __forceinline__ int flight_height(int y, int yv, int m)
+{
+    return y + __mul24(m, yv) + (__mul24(m, m - 1) >> 1);
+}
+
+template <bool FULL_NET>
+__device__ __forceinline__ int predict_landing_x(int x, int y, int xv, int yv)
+{
+    constexpr int kBoxLeft = kGroundHalfWidth - kNetPillarHalfWidth;   // 191: last x left of the box
+    constexpr int kBoxRight = kGroundHalfWidth + kNetPillarHalfWidth;  // 241: first x right of it
+    int count = 0;
+    for (;;) {
+        const bool left = x <= kBoxLeft, right = x >= kBoxRight;
+        const bool outside = left || right;
+        const int ymax = outside ? kBallGroundY : kNetTopTopY;
+        if ((unsigned)y <= (unsigned)ymax && abs(yv) < 4096) {
+            // plain moves available along x: up to the wall, or up to the edge of the net box
+            const int axv = abs(xv);
+            const bool toward_box = (xv > 0) ? left : right;  // only meaningful when outside
+            const int room = (xv > 0) ? ((left ? kBoxLeft : kGroundWidth) - x) : (x - (right ? kBoxRight : kBallRadius));
+            const int kx = axv ? (int)((float)room * __builtin_amdgcn_rcpf((float)axv)) + (int)(outside && toward_box)
+                               : kLoopLimit;
+            // plain moves available along y: far root of Y(K) = ymax ...
+            const float hb = (float)(2 * yv - 1);
+            const float hb2 = hb * hb;
+            int K = (int)((__builtin_amdgcn_sqrtf(hb2 + 8.0f * (float)(ymax - y)) - hb) * 0.5f);
+            // ... and, if the apex Y(-yv) would be above the ceiling, the near root of Y(K) = 0
+            if (yv < 0 && y - (__mul24(yv, yv - 1) >> 1) < 0) {
+                const float d2 = fmaxf(hb2 - 8.0f * (float)y, 0.0f);
+                K = min(K, (int)((-hb - __builtin_amdgcn_sqrtf(d2)) * 0.5f));
+            }
+            K = min(min(K, kx), kLoopLimit - 2 - count);
+            if (K >= 2) {
+                int ye = flight_height(y, yv, K);
+                if (ye > ymax) {  // the root was rounded up: one less is the exact bound
+                    K -= 1;
+                    ye = flight_height(y, yv, K);
+                }
+                const int xe = x + __mul24(K, xv);
+                const int lowest = flight_height(y, yv, min(max(-yv, 1), K));
+                bool ok = (unsigned)(xe - kBallRadius) <= (unsigned)(kGroundWidth - kBallRadius) &&
+                          (unsigned)ye <= (unsigned)ymax && lowest >= 0;
+                if (outside) {
+                    const int xl = xe - xv;  // X(K-1) must still be on the same side of the box
+                    ok = ok && (left ? xl <= kBoxLeft : xl >= kBoxRight);
+                }
+                if (ok) {
+                    x = xe;
+                    y = ye;
+                    yv += K;
+                    count += K;
+                }
+            }
+        }
+        // one iteration, exactly as the reference
         ++count;
         const int fx = x + xv;
         if (fx < kBallRadius || fx > kGroundWidth) xv = -xv;
@@ -385,7 +493,7 @@ __device__ __forceinline__ void wave_power_hit_candidates(bool need, const Ball&
             const int xdir = candidate_xdir(c), ydir = candidate_ydir(c);
             const int sxv = (sx < kGroundHalfWidth) ? (xdir + 1) * 10 : -(xdir + 1) * 10;  // :841-844
             const int syv = sayv * ydir * 2;                                              // :845
-            scratch[192 + item] = predict_landing_x<false>(sx, sy, sxv, syv);
+            scratch[192 + item] = PZ_ABLATE_SKIP(64) ? sx : predict_landing_x<false>(sx, sy, sxv, syv);
         }
     }
     __syncthreads();
@@ -574,7 +682,7 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
         if (AI1 || AI2) {
             // :314-315 recomputes the landing point before each player; the ball does not move
             // between the two calls, so one evaluation serves both.
-            g.b.ex = predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
+            g.b.ex = PZ_ABLATE_SKIP(32) ? g.b.x : predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
         }
     }
 
@@ -618,7 +726,7 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
         if ((AI1 || AI2) && hit_processed) {
             // :331-332 -- when both players hit in one frame the second evaluation overwrites the
             // first, so a single one after both collisions leaves the same value.
-            g.b.ex = predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
+            g.b.ex = PZ_ABLATE_SKIP(128) ? g.b.x : predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
         }
 
         // scoring / round end / game end (:190-210); round_ended and game_ended are both 0 here

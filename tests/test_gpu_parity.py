@@ -344,3 +344,70 @@ def test_checkpoint_roundtrip():
     env2.unwrapped.load_state_dict(sd)
     env2.step_random(1, k=50)
     assert torch.equal(env2.unwrapped.state, after)
+
+
+# ------------------------------------------------------------------------------------------------
+# 5. the closed-form fast-forward of the flight predictors == the reference's iteration
+# ------------------------------------------------------------------------------------------------
+def _selftest(x, y, xv, yv, full_net):
+    from pikazoo_amd import _native
+
+    lib = _native.load()
+    n = x.numel()
+    fast, it = torch.empty_like(x), torch.empty_like(x)
+    rc = lib.pz_selftest_predictor(x.data_ptr(), y.data_ptr(), xv.data_ptr(), yv.data_ptr(), n, int(full_net),
+                                   fast.data_ptr(), it.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    return fast, it
+
+
+@pytest.mark.parametrize("full_net", [True, False])
+def test_predictor_fast_forward_equals_iteration_exhaustive(full_net, oracle):
+    """Every ball state of the reachable domain: x in [20,432], y in [0,252], x velocity in [-20,20]
+    (physics.py:607-626 bounds it), y velocity in [-300,300] in steps that include every value the power
+    hit can produce (2*|yv|); about 6e8 states per predictor form."""
+    dev = torch.device("cuda:0")
+    xs = torch.arange(20, 433, dtype=torch.int32, device=dev)
+    ys = torch.arange(0, 253, dtype=torch.int32, device=dev)
+    xvs = torch.arange(-20, 21, dtype=torch.int32, device=dev)
+    gx, gy, gxv = (t.contiguous().reshape(-1) for t in torch.meshgrid(xs, ys, xvs, indexing="ij"))
+    yv_values = list(range(-130, 131)) + list(range(-300, -130, 2)) + list(range(132, 301, 2))
+    bad = 0
+    for yv in yv_values:
+        gyv = torch.full_like(gx, yv)
+        fast, it = _selftest(gx, gy, gxv, gyv, full_net)
+        bad += int((fast != it).sum().item())
+    assert bad == 0
+    # spot-check the device iteration itself against the CPU oracle
+    g = torch.Generator(device="cpu").manual_seed(5)
+    m = 3000
+    X = torch.randint(20, 433, (m,), generator=g, dtype=torch.int32)
+    Y = torch.randint(0, 253, (m,), generator=g, dtype=torch.int32)
+    XV = torch.randint(-20, 21, (m,), generator=g, dtype=torch.int32)
+    YV = torch.randint(-150, 151, (m,), generator=g, dtype=torch.int32)
+    if full_net:
+        exp = [oracle.expected_landing_x(int(X[j]), int(Y[j]), int(XV[j]), int(YV[j])) for j in range(m)]
+        sxv, syv = XV, YV
+    else:
+        # expected_landing_point_x_when_power_hit substitutes the velocities (physics.py:841-845)
+        xd = torch.randint(0, 2, (m,), generator=g, dtype=torch.int32)
+        yd = torch.randint(-1, 2, (m,), generator=g, dtype=torch.int32)
+        exp = [oracle.expected_landing_x_power_hit(int(xd[j]), int(yd[j]), int(X[j]), int(Y[j]), int(XV[j]),
+                                                   int(YV[j])) for j in range(m)]
+        sxv = torch.where(X < 216, (xd + 1) * 10, -(xd + 1) * 10).to(torch.int32)
+        syv = (YV.abs() * yd * 2).to(torch.int32)
+    fast, it = _selftest(X.to(dev), Y.to(dev), sxv.to(dev).contiguous(), syv.to(dev).contiguous(), full_net)
+    assert cpu(fast).tolist() == exp and cpu(it).tolist() == exp
+
+
+def test_predictor_extreme_inputs():
+    """Out-of-domain speeds, the iteration cap and the net-top bounce loop (x velocity 0 inside the net
+    box never lands: both forms must stop at the cap with the same x)."""
+    dev = torch.device("cuda:0")
+    cases = [(216, 180, 0, 5), (216, 100, 0, 1), (200, 0, 0, 1), (30, 252, -20, -3), (432, 0, 20, 1000),
+             (20, 0, -20, -1000), (216, 176, 1, 0), (216, 177, -1, 0), (240, 191, 0, 16), (192, 192, 0, 1),
+             (300, 10, 7, -2000), (56, 0, 0, 1), (376, 0, 0, 1)]
+    t = torch.tensor(cases, dtype=torch.int32, device=dev)
+    for full_net in (True, False):
+        fast, it = _selftest(*(t[:, k].contiguous() for k in range(4)), full_net)
+        assert torch.equal(fast, it), (full_net, fast.tolist(), it.tolist())

@@ -67,6 +67,9 @@ def main():
         "all_stores_cached": 6, "all_traffic_cached": 7, "no_frame": 8, "no_obs": 16,
         "no_frame_no_obs": 24, "no_frame_all_cached": 15, "nothing": 31,
     }
+    if p2ai:
+        variants = {"baseline": 0, "no_frame": 8, "no_landing_A": 32, "no_candidates": 64, "no_landing_B": 128,
+                    "no_A_no_B": 160, "no_predictors": 224}
     times = {k: [] for k in variants}
     K = 300
     for rnd in range(7):
