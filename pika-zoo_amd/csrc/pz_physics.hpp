@@ -337,49 +337,44 @@ __device__ __forceinline__ int predict_landing_x(int x, int y, int xv, int yv)
     constexpr int kBoxRight = kGroundHalfWidth + kNetPillarHalfWidth;  // 241: first x right of it
     int count = 0;
     for (;;) {
+        // ---- proposal + verification, written branch-free: in a divergent wave every trip pays
+        // for every path anyway, and straight-line code lets the lone wave overlap the two
+        // transcendental chains (rcp, sqrt) with the integer work.
         const bool left = x <= kBoxLeft, right = x >= kBoxRight;
         const bool outside = left || right;
         const int ymax = outside ? kBallGroundY : kNetTopTopY;
-        if ((unsigned)y <= (unsigned)ymax && abs(yv) < 4096) {
-            // plain moves available along x: up to the wall, or up to the edge of the net box
-            const int axv = abs(xv);
-            const bool toward_box = (xv > 0) ? left : right;  // only meaningful when outside
-            const int room = (xv > 0) ? ((left ? kBoxLeft : kGroundWidth) - x) : (x - (right ? kBoxRight : kBallRadius));
-            const int kx = axv ? (int)((float)room * __builtin_amdgcn_rcpf((float)axv)) + (int)(outside && toward_box)
-                               : kLoopLimit;
-            // plain moves available along y: far root of Y(K) = ymax ...
-            const float hb = (float)(2 * yv - 1);
-            const float hb2 = hb * hb;
-            int K = (int)((__builtin_amdgcn_sqrtf(hb2 + 8.0f * (float)(ymax - y)) - hb) * 0.5f);
-            // ... and, if the apex Y(-yv) would be above the ceiling, the near root of Y(K) = 0
-            if (yv < 0 && y - (__mul24(yv, yv - 1) >> 1) < 0) {
-                const float d2 = fmaxf(hb2 - 8.0f * (float)y, 0.0f);
-                K = min(K, (int)((-hb - __builtin_amdgcn_sqrtf(d2)) * 0.5f));
-            }
-            K = min(min(K, kx), kLoopLimit - 2 - count);
-            if (K >= 2) {
-                int ye = flight_height(y, yv, K);
-                if (ye > ymax) {  // the root was rounded up: one less is the exact bound
-                    K -= 1;
-                    ye = flight_height(y, yv, K);
-                }
-                const int xe = x + __mul24(K, xv);
-                const int lowest = flight_height(y, yv, min(max(-yv, 1), K));
-                bool ok = (unsigned)(xe - kBallRadius) <= (unsigned)(kGroundWidth - kBallRadius) &&
-                          (unsigned)ye <= (unsigned)ymax && lowest >= 0;
-                if (outside) {
-                    const int xl = xe - xv;  // X(K-1) must still be on the same side of the box
-                    ok = ok && (left ? xl <= kBoxLeft : xl >= kBoxRight);
-                }
-                if (ok) {
-                    x = xe;
-                    y = ye;
-                    yv += K;
-                    count += K;
-                }
-            }
-        }
-        // one iteration, exactly as the reference
+        const bool rightward = xv > 0;
+        const int axv = abs(xv);
+        // plain moves available along x: up to the wall, or up to the edge of the net box
+        const int edge = rightward ? (left ? kBoxLeft : kGroundWidth) : (right ? kBoxRight : kBallRadius);
+        const int room = rightward ? edge - x : x - edge;
+        const int toward_box = (rightward ? left : right) ? 1 : 0;  // outside and heading for the box
+        const float q = (float)room * __builtin_amdgcn_rcpf((float)axv);
+        const int kx = (axv ? (int)q : kLoopLimit) + toward_box;
+        // plain moves available along y: far root of Y(K) = ymax (NaN -> 0 when y > ymax) ...
+        const float hb = (float)(2 * yv - 1);
+        const float hb2 = hb * hb;
+        int K = (int)((__builtin_amdgcn_sqrtf(hb2 + 8.0f * (float)(ymax - y)) - hb) * 0.5f - 0.001f);
+        // ... and, if the apex Y(-yv) would be above the ceiling, the near root of Y(K) = 0
+        const int apex = y - (__mul24(yv, yv - 1) >> 1);
+        const int kc = (int)((-hb - __builtin_amdgcn_sqrtf(fmaxf(hb2 - 8.0f * (float)y, 0.0f))) * 0.5f - 0.001f);
+        K = (yv < 0 && apex < 0) ? min(K, kc) : K;
+        K = min(min(K, kx), kLoopLimit - 2 - count);
+        // exact verification
+        const int ye = flight_height(y, yv, K);
+        const int xe = x + __mul24(K, xv);
+        const int xl = xe - xv;  // X(K-1): must still be on the same side of the box when outside
+        const int lowest = flight_height(y, yv, min(max(-yv, 1), K));
+        const bool side_kept = left ? xl <= kBoxLeft : (right ? xl >= kBoxRight : true);
+        const bool ok = (K >= 2) & ((unsigned)y <= (unsigned)ymax) & (abs(yv) < 4096) &
+                        ((unsigned)(xe - kBallRadius) <= (unsigned)(kGroundWidth - kBallRadius)) &
+                        ((unsigned)ye <= (unsigned)ymax) & (lowest >= 0) & side_kept;
+        x = ok ? xe : x;
+        y = ok ? ye : y;
+        yv += ok ? K : 0;
+        count += ok ? K : 0;
+
+        // ---- one iteration, exactly as the reference
         ++count;
         const int fx = x + xv;
         if (fx < kBallRadius || fx > kGroundWidth) xv = -xv;
