@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""A/B timing of kernel build variants (diagnostic; cdna_hip_programming.md rule 24: interleaved
+rounds in ONE process, median and min reported).
+
+    python tools/ab.py --build name1=-DFLAG1 name2="-DFLAG2 -DFLAG3" ...   # here: cross-compile variants
+    python tools/ab.py [--ai] [--n 65536] name1 name2 ...                  # on the GPU box: time them
+
+A variant named "base" is always built with no extra flags.  Libraries go to
+pika-zoo_amd/lib/ab_<name>.so (git-ignored, shipped by gpurun).
+"""
+import ctypes as C
+import statistics
+import subprocess
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "pika-zoo_amd"))
+LIBDIR = REPO / "pika-zoo_amd" / "lib"
+
+
+def build(name, flags):
+    out = LIBDIR / f"ab_{name}.so"
+    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", *flags.split(),
+           f"-I{REPO / 'include'}", f"-I{REPO / 'pika-zoo_amd' / 'csrc'}", "-o", str(out),
+           str(REPO / "pika-zoo_amd" / "csrc" / "pz_kernels.hip")]
+    subprocess.check_call(cmd)
+    print("built", out.name, flags)
+
+
+def main():
+    args = sys.argv[1:]
+    if args and args[0] == "--build":
+        LIBDIR.mkdir(exist_ok=True)
+        build("base", "")
+        for spec in args[1:]:
+            name, _, flags = spec.partition("=")
+            build(name, flags)
+        return
+    import torch
+    from pikazoo_amd import _native
+
+    ai = "--ai" in args
+    wrappers = "--wrappers" in args
+    n = 65536
+    if "--n" in args:
+        n = int(args[args.index("--n") + 1])
+    names = [a for a in args if not a.startswith("--") and not a.isdigit()]
+    if "base" not in names:
+        names = ["base"] + names
+    dev = torch.device("cuda:0")
+    P = C.c_void_p
+    libs = {}
+    for nm in names:
+        lib = C.CDLL(str(LIBDIR / f"ab_{nm}.so"))
+        lib.pz_init.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P]
+        lib.pz_reset.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P]
+        lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P]
+        libs[nm] = lib
+    cfg = _native.PzConfig()
+    cfg.winning_score, cfg.auto_reset, cfg.seed, cfg.p2_computer = 15, 1, 0, int(ai)
+    if wrappers:
+        cfg.simplify_action, cfg.ballpos_reward, cfg.x_line, cfg.y_line = 1, 1, 216, 176
+        for i, v in enumerate((0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01)):
+            cfg.additional_reward[i] = v
+    state = torch.zeros((44, n), dtype=torch.int32, device=dev)
+    obs = [torch.zeros((n, 35), dtype=torch.int32, device=dev) for _ in range(2)]
+    rew = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
+    term = torch.zeros(n, dtype=torch.uint8, device=dev)
+    acts = torch.randint(0, 13 if wrappers else 18, (64, 2, n), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    base = libs["base"]
+    assert base.pz_init(state.data_ptr(), n, n, C.byref(cfg), stream) == 0
+    assert base.pz_reset(state.data_ptr(), n, n, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(), stream) == 0
+
+    def run(lib, steps):
+        for t in range(steps):
+            a = acts[t % 64]
+            lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
+                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), stream)
+
+    run(base, 700)
+    snapshot = state.clone()
+    torch.cuda.synchronize()
+    # every variant must produce the same trajectory as base
+    finals = {}
+    for nm, lib in libs.items():
+        state.copy_(snapshot)
+        run(lib, 128)
+        torch.cuda.synchronize()
+        finals[nm] = (state.clone(), obs[0].clone(), obs[1].clone(), rew[0].clone(), term.clone())
+    for nm in names:
+        same = all(torch.equal(a, b) for a, b in zip(finals[nm], finals["base"]))
+        print(f"  {nm}: trajectory identical to base: {same}")
+    K, rounds = 400, 9
+    times = {nm: [] for nm in names}
+    for _ in range(rounds):
+        for nm, lib in libs.items():
+            state.copy_(snapshot)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run(lib, K)
+            e1.record()
+            torch.cuda.synchronize()
+            times[nm].append(e0.elapsed_time(e1) * 1e3 / K)
+    print(f"n={n} p2_computer={ai} wrappers={wrappers}: us per launch, median / min over {rounds} interleaved rounds of {K}")
+    for nm in names:
+        print(f"  {nm:28s} {statistics.median(times[nm]):7.3f} {min(times[nm]):7.3f}")
+
+
+if __name__ == "__main__":
+    main()

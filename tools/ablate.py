@@ -62,11 +62,7 @@ def main():
 
     run(0, 600)  # desynchronise the games so divergence is realistic
     snapshot = state.clone()
-    variants = {
-        "baseline": 0, "loads_cached": 1, "state_stores_cached": 2, "obs_stores_cached": 4,
-        "all_stores_cached": 6, "all_traffic_cached": 7, "no_frame": 8, "no_obs": 16,
-        "no_frame_no_obs": 24, "no_frame_all_cached": 15, "nothing": 31,
-    }
+    variants = {"baseline": 0, "no_frame": 8, "no_obs": 16, "no_frame_no_obs": 24}
     if p2ai:
         variants = {"baseline": 0, "no_frame": 8, "no_landing_A": 32, "no_candidates": 64, "no_landing_B": 128,
                     "no_A_no_B": 160, "no_predictors": 224}

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of one step launch (diagnostic build with -DPZ_STAMPS; not product).
+
+    python tools/stamps.py --build ; python tools/stamps.py [--ai] [--n N]     (second on the GPU box)
+
+Stamps (100 MHz s_memrealtime, 10 ns ticks), lane 0 of every workgroup:
+ 0 start | 1 state loaded (vmcnt(0)) | 2 frame computed | 3 state/reward stores issued |
+ 4 observations staged in LDS | 5 observation stores issued | 6 all stores complete
+Prints, relative to the earliest start of the launch, the median / p95 / max over waves of each stamp.
+"""
+import ctypes as C
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "pika-zoo_amd"))
+LIB = REPO / "pika-zoo_amd" / "lib" / "stamps.so"
+
+
+def main():
+    args = sys.argv[1:]
+    if "--build" in args:
+        subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-DPZ_STAMPS=1",
+                               f"-I{REPO / 'include'}", f"-I{REPO / 'pika-zoo_amd' / 'csrc'}", "-o", str(LIB),
+                               str(REPO / "pika-zoo_amd" / "csrc" / "pz_kernels.hip")])
+        return
+    import torch
+    from pikazoo_amd import _native
+
+    ai = "--ai" in args
+    n = int(args[args.index("--n") + 1]) if "--n" in args else 65536
+    lib = C.CDLL(str(LIB))
+    P = C.c_void_p
+    lib.pz_init.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P]
+    lib.pz_reset.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P]
+    lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P]
+    lib.pz_debug_read_stamps.argtypes = [P, C.c_int64]
+    dev = torch.device("cuda:0")
+    cfg = _native.PzConfig()
+    cfg.winning_score, cfg.auto_reset, cfg.seed, cfg.p2_computer = 15, 1, 0, int(ai)
+    state = torch.zeros((44, n), dtype=torch.int32, device=dev)
+    obs = [torch.zeros((n, 35), dtype=torch.int32, device=dev) for _ in range(2)]
+    rew = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
+    term = torch.zeros(n, dtype=torch.uint8, device=dev)
+    acts = torch.randint(0, 18, (64, 2, n), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    lib.pz_init(state.data_ptr(), n, n, C.byref(cfg), stream)
+    lib.pz_reset(state.data_ptr(), n, n, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(), stream)
+
+    def run(steps):
+        for t in range(steps):
+            a = acts[t % 64]
+            lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
+                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), stream)
+
+    run(800)
+    torch.cuda.synchronize()
+    waves = min((n + 63) // 64, 8192)
+    buf = np.zeros(8192 * 8, np.uint64)
+    names = ["start", "loaded", "computed", "state stores issued", "obs staged", "obs stores issued", "all stores done"]
+    for rep in range(3):
+        run(20)  # back-to-back launches; the stamps of the last one survive
+        torch.cuda.synchronize()
+        assert lib.pz_debug_read_stamps(buf.ctypes.data, 8192 * 8) == 0
+        st = buf.reshape(8192, 8)[:waves, :7].astype(np.int64)
+        t0 = st[:, 0].min()
+        rel = (st - t0) * 0.01  # microseconds
+        print(f"launch sample {rep}: n={n} ai={ai} waves={waves}; microseconds since the first wave started")
+        for k, nm in enumerate(names):
+            c = rel[:, k]
+            print(f"  {nm:22s} min {c.min():6.2f}  median {np.median(c):6.2f}  p95 {np.percentile(c, 95):6.2f}  max {c.max():6.2f}")
+        d = np.diff(rel, axis=1)
+        print("  per-wave phase durations (median): " + ", ".join(f"{names[k + 1]} {np.median(d[:, k]):.2f}" for k in range(6)))
+
+
+if __name__ == "__main__":
+    main()
