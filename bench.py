@@ -231,6 +231,31 @@ def measure(args, shard, device, p2_computer, wrappers, launch, with_cpu):
     return res
 
 
+def measure_rollout(args, shard, device, k):
+    """pz_rollout_random: k frames per launch, every frame's outputs written to trajectory tensors
+    (state in registers, read/written once per launch).  Honest bytes per game-step of THIS kernel:
+    297 - 8 (no action reads) + 8 (actions written) + 352/k."""
+    env = make_env(args, shard, False, False, device)
+    raw = env.unwrapped
+    env.reset()
+    out = raw.rollout_random(ACTION_SEED, k)          # allocate + warm up
+    launches = max(1, args.steps // k)
+    torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(launches):
+        out = raw.rollout_random(ACTION_SEED, k, out=out)
+    ev1.record()
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    us_per_frame = ev0.elapsed_time(ev1) * 1e3 / (launches * k)
+    bytes_per_step = 297 + 352.0 / k
+    gbps = bytes_per_step * raw.num_envs / (us_per_frame * 1e-6) / 1e9
+    return {"value": raw.num_envs * launches * k / wall, "us_per_frame": us_per_frame, "k": k,
+            "bytes_per_game_step": bytes_per_step, "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS}
+
+
 def load_traffic(workload_key):
     """HBM bytes per launch from the committed PMC profile (profiles/traffic.json), or None."""
     p = REPO / "profiles" / "traffic.json"
@@ -262,6 +287,7 @@ def main():
         for key, (ai, wr) in {"cfg3_p2_computer": (True, False), "cfg5_fused_wrappers": (False, True)}.items():
             r = measure(args, shard, device, ai, wr, args.launch, with_cpu=False)
             extra[key] = {"value": r["value"], "launch_us": r["launch_us"]}
+        extra["rollout_k32"] = measure_rollout(args, shard, device, k=32)
         for mode in ("cabi", "api"):
             r = measure(args, shard, device, args.p2_computer, args.wrappers, mode, with_cpu=False)
             extra[f"launch_{mode}"] = {"value": r["value"], "launch_us": r["launch_us"]}

@@ -129,6 +129,19 @@ int pz_step_random(int32_t *state, int64_t n, int64_t stride, const pz_config *c
                    int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
                    uint8_t *terminated, int64_t *episodes_done, void *stream);
 
+/* ---- a k-frame rollout of the random policy with EVERY frame's outputs kept ---------------
+ * Same trajectories as k calls of pz_step_random(k=1), in ONE launch: the state is read once,
+ * held in registers for k frames and written once; frame t (0 <= t < k) writes
+ *   actions[t][2][n] (int32, the policy's draws; may be NULL), obs_p1/obs_p2[t][n][35],
+ *   rew_p1/rew_p2[t][n], terminated[t][n].
+ * n must be a multiple of 4 when k > 1 (16-byte alignment of every frame's observation slab).
+ * This is what a `for t in range(k): env.step(sample())` collection loop around the reference
+ * produces (pikazoo_env.py:175-240 with action_space.sample()). */
+int pz_rollout_random(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
+                      uint64_t action_seed, uint64_t t0, int32_t k, int32_t *actions,
+                      int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
+                      uint8_t *terminated, int64_t *episodes_done, void *stream);
+
 /* ---- the policy stream alone (for hosts that want the actions in HBM) -------------------- */
 int pz_random_actions(int32_t *act_p1, int32_t *act_p2, int64_t n, int64_t env_id_base,
                       uint64_t action_seed, uint64_t t, int32_t n_actions, void *stream);

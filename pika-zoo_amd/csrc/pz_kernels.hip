@@ -58,6 +58,7 @@ struct StepArgs {
     const int32_t* act_p2;
     uint64_t action_seed, t0;
     int32_t k;  // frames per launch (random policy only)
+    int32_t* act_out;  // trajectory mode only: int32[k][2][n] actions taken (may be nullptr)
     int32_t* obs_p1;
     int32_t* obs_p2;
     void* rew_p1;
@@ -295,10 +296,57 @@ __device__ unsigned long long g_pz_stamps[8192 * 8];
 
 // ---- the fused step kernel -------------------------------------------------------------------
 // AI1/AI2: player 1 / 2 is the rule-based computer (compile-time so the human-vs-human build
-// carries none of the predictor code or its registers).  RANDOM: actions are drawn on device
-// and k frames may run per launch; otherwise actions are read from HBM and k == 1.
+// carries none of the predictor code or its registers).
+// MODE: kActions  -- one frame, actions read from HBM (pz_step);
+//       kRandom   -- k frames of the on-device random policy, outputs of the last frame (pz_step_random);
+//       kRollout  -- k frames of the random policy, EVERY frame's outputs written to [k][n]...
+//                    trajectory tensors (pz_rollout_random); the state stays in registers for
+//                    the whole launch, so per frame only the outputs move.
 // SPARSE: changed-only write-back of the rarely changing columns (large batches).
-template <bool AI1, bool AI2, bool RANDOM, bool SPARSE>
+enum StepMode { kActions = 0, kRandom = 1, kRollout = 2 };
+
+// outputs of one frame: rewards (pikazoo_env.py:217-228, optionally with RewardByBallPosition
+// fused, reward_by_ball_position.py:22-29: zone from the post-step ball position), terminated
+// (:233) and the two observation tensors through the LDS transpose.  `t` = frame index inside
+// a trajectory (0 for single-frame outputs).
+__device__ __forceinline__ void emit_outputs(const StepArgs& a, const Game& g, int reward, bool frozen, bool live,
+                                             int64_t i, int lane, int64_t t, int32_t (*lds_obs)[kLanes * PZ_OBS_DIM],
+                                             bool skip_obs)
+{
+    const uint32_t n32 = (uint32_t)a.n;
+    const uint32_t voff = (uint32_t)i * 4u;
+    // descriptors are built from kernel arguments and the (uniform) frame index only
+    const Rsrc rew1 = make_rsrc(static_cast<char*>(a.rew_p1) + t * a.n * 4, n32 * 4u);
+    const Rsrc rew2 = make_rsrc(static_cast<char*>(a.rew_p2) + t * a.n * 4, n32 * 4u);
+    const Rsrc term = make_rsrc(a.terminated + t * a.n, n32);
+    if (live) {
+        if (a.cfg.ballpos_reward) {
+            const int zone = (g.b.y > a.cfg.y_line ? 1 : 0) + (g.b.x >= a.cfg.x_line ? 2 : 0);
+            float r1 = (float)reward, r2 = (float)(-reward);
+            if (!frozen) {
+                r1 += a.cfg.additional_reward[zone];
+                r2 += a.cfg.additional_reward[4 + zone];
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r1), rew1, voff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r2), rew2, voff, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned int)reward, rew1, voff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned int)(-reward), rew2, voff, 0, 0);
+        }
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, term, (uint32_t)i, 0, 0);
+        PZ_STAMP(3);
+        if (!skip_obs) stage_obs(g, lds_obs[0], lds_obs[1], lane);
+    }
+    __syncthreads();
+    PZ_STAMP(4);
+    if (!skip_obs) {
+        const uint32_t wave_off = blockIdx.x * kWaveObsBytes;
+        flush_rows(lds_obs[0], make_rsrc(a.obs_p1 + t * a.n * PZ_OBS_DIM, n32 * kRowBytes), wave_off, lane);
+        flush_rows(lds_obs[1], make_rsrc(a.obs_p2 + t * a.n * PZ_OBS_DIM, n32 * kRowBytes), wave_off, lane);
+    }
+}
+
+template <bool AI1, bool AI2, int MODE, bool SPARSE>
 __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
 {
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
@@ -312,9 +360,6 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
     // descriptors are built from kernel arguments only, so they are provably wave-uniform
     const StateIO io{make_rsrc(a.state, (uint32_t)(a.stride * (PZ_STATE_WORDS * 4))), (uint32_t)a.stride * 4u,
                      (uint32_t)i * 4u};
-    const Rsrc rew1 = make_rsrc(a.rew_p1, n32 * 4u), rew2 = make_rsrc(a.rew_p2, n32 * 4u);
-    const Rsrc term = make_rsrc(a.terminated, n32);
-    const Rsrc obs1 = make_rsrc(a.obs_p1, n32 * kRowBytes), obs2 = make_rsrc(a.obs_p2, n32 * kRowBytes);
 
     Game g{};
     const RngId id = make_rng_id(a.cfg, live ? i : 0);
@@ -326,7 +371,7 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
 #endif
     PZ_STAMP(0);
     int a1 = 0, a2 = 0;
-    if (!RANDOM) {  // rows past n read as 0 through the range check
+    if (MODE == kActions) {  // rows past n read as 0 through the range check
         a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act_p1, n32 * 4u), io.voff, 0, 0);
         a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act_p2, n32 * 4u), io.voff, 0, 0);
     }
@@ -337,12 +382,20 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
     // The frame runs in wave-uniform control flow (the computer player's power-hit candidates
     // are evaluated cooperatively by the wave); lanes past the end of the batch idle inside.
     // lds_obs[0] doubles as the cooperative scratch until the observations are staged.
-    if (RANDOM) {
+    if (MODE != kActions) {
         const uint32_t n_actions = a.cfg.simplify_action ? 13u : 18u;
         for (int32_t s = 0; s < a.k; ++s) {
             policy_actions(id.id_lo, id.id_hi, a.action_seed, a.t0 + (uint64_t)s, n_actions, a1, a2);
             reward = step_games<AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane);
             finished += (unsigned int)(live && g.e.game_ended && !frozen);
+            if (MODE == kRollout) {
+                if (a.act_out != nullptr) {
+                    const Rsrc ao = make_rsrc(a.act_out + (int64_t)s * 2 * a.n, n32 * 8u);
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a1, ao, io.voff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, io.voff, n32 * 4u, 0);
+                }
+                emit_outputs(a, g, reward, frozen, live, i, lane, s, lds_obs, false);
+            }
         }
     } else if (!PZ_SKIP_FRAME) {
         reward = step_games<AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane);
@@ -354,33 +407,8 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
             store_game_changed(g, loaded, io);
         else
             store_game(g, io);
-
-        // rewards (pikazoo_env.py:217-228), optionally with RewardByBallPosition fused
-        // (reward_by_ball_position.py:22-29: zone from the post-step ball position)
-        if (a.cfg.ballpos_reward) {
-            const int zone = (g.b.y > a.cfg.y_line ? 1 : 0) + (g.b.x >= a.cfg.x_line ? 2 : 0);
-            float r1 = (float)reward, r2 = (float)(-reward);
-            if (!frozen) {
-                r1 += a.cfg.additional_reward[zone];
-                r2 += a.cfg.additional_reward[4 + zone];
-            }
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r1), rew1, io.voff, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r2), rew2, io.voff, 0, 0);
-        } else {
-            __builtin_amdgcn_raw_buffer_store_b32((unsigned int)reward, rew1, io.voff, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32((unsigned int)(-reward), rew2, io.voff, 0, 0);
-        }
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, term, (uint32_t)i, 0, 0);  // :233
-        PZ_STAMP(3);
-        if (!PZ_SKIP_OBS) stage_obs(g, lds_obs[0], lds_obs[1], lane);
     }
-    __syncthreads();
-    PZ_STAMP(4);
-    if (!PZ_SKIP_OBS) {
-        const uint32_t wave_off = blockIdx.x * kWaveObsBytes;
-        flush_rows(lds_obs[0], obs1, wave_off, lane);
-        flush_rows(lds_obs[1], obs2, wave_off, lane);
-    }
+    if (MODE != kRollout) emit_outputs(a, g, reward, frozen, live, i, lane, 0, lds_obs, PZ_SKIP_OBS);
     PZ_STAMP(5);
     PZ_DRAIN_VMEM();
     PZ_STAMP(6);
@@ -497,27 +525,28 @@ static inline bool misaligned16(const void* p) { return (reinterpret_cast<uintpt
 
 static inline unsigned int blocks_for(int64_t n, int per) { return (unsigned int)((n + per - 1) / per); }
 
-template <bool RANDOM, bool SPARSE>
+template <int MODE, bool SPARSE>
 static int launch_step_ai(const StepArgs& a, hipStream_t stream)
 {
     const dim3 grid(blocks_for(a.n, kLanes)), block(kLanes);
     const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
     if (ai1 && ai2)
-        hipLaunchKernelGGL((step_kernel<true, true, RANDOM, SPARSE>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((step_kernel<true, true, MODE, SPARSE>), grid, block, 0, stream, a);
     else if (ai1)
-        hipLaunchKernelGGL((step_kernel<true, false, RANDOM, SPARSE>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((step_kernel<true, false, MODE, SPARSE>), grid, block, 0, stream, a);
     else if (ai2)
-        hipLaunchKernelGGL((step_kernel<false, true, RANDOM, SPARSE>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((step_kernel<false, true, MODE, SPARSE>), grid, block, 0, stream, a);
     else
-        hipLaunchKernelGGL((step_kernel<false, false, RANDOM, SPARSE>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((step_kernel<false, false, MODE, SPARSE>), grid, block, 0, stream, a);
     return (int)hipGetLastError();
 }
 
-template <bool RANDOM>
+template <int MODE>
 static int launch_step(const StepArgs& a, hipStream_t stream)
 {
-    return a.n >= kSparseWritebackMinLanes ? launch_step_ai<RANDOM, true>(a, stream)
-                                           : launch_step_ai<RANDOM, false>(a, stream);
+    // a rollout writes the state once per k frames: the plain write-back is always right there
+    if (MODE != kRollout && a.n >= kSparseWritebackMinLanes) return launch_step_ai<MODE, true>(a, stream);
+    return launch_step_ai<MODE, false>(a, stream);
 }
 
 }  // namespace pz
@@ -582,8 +611,9 @@ int pz_step(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, con
     if (!act_p1 || !act_p2 || !obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
     if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
-    StepArgs a{state, n, stride, act_p1, act_p2, 0, 0, 1, obs_p1, obs_p2, rew_p1, rew_p2, terminated, nullptr, *cfg};
-    return launch_step<false>(a, (hipStream_t)stream);
+    StepArgs a{state,  n,      stride,     act_p1,  act_p2, 0, 0, 1, nullptr, obs_p1, obs_p2, rew_p1,
+               rew_p2, terminated, nullptr, *cfg};
+    return launch_step<kActions>(a, (hipStream_t)stream);
 }
 
 int pz_step_random(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, uint64_t action_seed, uint64_t t0,
@@ -595,9 +625,24 @@ int pz_step_random(int32_t* state, int64_t n, int64_t stride, const pz_config* c
     if (k < 1) return PZ_E_SIZE;
     if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
-    StepArgs a{state,  n,      stride, nullptr, nullptr,    action_seed, t0, k, obs_p1, obs_p2, rew_p1,
+    StepArgs a{state,  n,          stride, nullptr, nullptr, action_seed, t0, k, nullptr, obs_p1, obs_p2, rew_p1,
                rew_p2, terminated, reinterpret_cast<unsigned long long*>(episodes_done), *cfg};
-    return launch_step<true>(a, (hipStream_t)stream);
+    return launch_step<kRandom>(a, (hipStream_t)stream);
+}
+
+int pz_rollout_random(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, uint64_t action_seed,
+                      uint64_t t0, int32_t k, int32_t* actions, int32_t* obs_p1, int32_t* obs_p2, void* rew_p1,
+                      void* rew_p2, uint8_t* terminated, int64_t* episodes_done, void* stream)
+{
+    if (int e = check_common(state, n, stride, cfg)) return e;
+    if (!obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
+    if (k < 1) return PZ_E_SIZE;
+    // every frame's [n][35] slab must keep the 16-byte alignment of the vector stores: n * 140 % 16 == 0
+    if (misaligned16(obs_p1) || misaligned16(obs_p2) || (k > 1 && (n & 3) != 0)) return PZ_E_ALIGN;
+    if (n == 0) return PZ_OK;
+    StepArgs a{state,  n,          stride, nullptr, nullptr, action_seed, t0, k, actions, obs_p1, obs_p2, rew_p1,
+               rew_p2, terminated, reinterpret_cast<unsigned long long*>(episodes_done), *cfg};
+    return launch_step<kRollout>(a, (hipStream_t)stream);
 }
 
 int pz_random_actions(int32_t* act_p1, int32_t* act_p2, int64_t n, int64_t env_id_base, uint64_t action_seed,

@@ -294,6 +294,46 @@ class raw_env:
         self.steps_done += int(k)
         return self._pack_step()
 
+    def rollout_random(self, action_seed: int, k: int, t0: Optional[int] = None, out: Optional[dict] = None):
+        """``k`` frames under the random policy in ONE launch, keeping every frame's outputs.
+
+        Returns a dict of trajectory tensors: ``actions`` ``int32[k, 2, N]``, ``obs``
+        ``{agent: int32[k, N, 35]}``, ``rewards`` ``{agent: [k, N]}``, ``terminations``
+        ``bool[k, N]``.  Bit-identical to ``k`` calls of ``step(random_actions(...))``; the state
+        tensor is read and written once.  Pass the previous result as ``out`` to reuse its buffers."""
+        if t0 is None:
+            t0 = self.steps_done
+        k, n, dev = int(k), self.num_envs, self.device
+        if k < 1:
+            raise ValueError("k must be >= 1")
+        if k > 1 and n % 4 != 0:
+            raise ValueError("rollout_random needs num_envs to be a multiple of 4")
+        if out is None or out["_k"] != k:
+            out = {"_k": k,
+                   "actions": torch.empty((k, 2, n), dtype=torch.int32, device=dev),
+                   "_obs": [torch.empty((k, n, _native.OBS_DIM), dtype=torch.int32, device=dev) for _ in range(2)],
+                   "_rew": [torch.empty((k, n), dtype=torch.int32, device=dev) for _ in range(2)],
+                   "_term": torch.empty((k, n), dtype=torch.uint8, device=dev)}
+        with torch.cuda.device(dev):
+            _native.check(self._lib.pz_rollout_random(
+                self.state.data_ptr(), n, n, self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0), k,
+                out["actions"].data_ptr(), out["_obs"][0].data_ptr(), out["_obs"][1].data_ptr(),
+                out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(), out["_term"].data_ptr(),
+                self._episodes.data_ptr(), self._stream()), "pz_rollout_random")
+        self.steps_done += k
+        dt = self.reward_dtype
+        rew = [r if dt == torch.int32 else r.view(torch.float32) for r in out["_rew"]]
+        out["obs"] = dict(zip(self.possible_agents, out["_obs"]))
+        out["rewards"] = dict(zip(self.possible_agents, rew))
+        out["terminations"] = out["_term"].view(torch.bool)
+        # keep the single-frame views coherent with the last frame
+        self._obs[0].copy_(out["_obs"][0][-1])
+        self._obs[1].copy_(out["_obs"][1][-1])
+        self._rew_raw[0].copy_(out["_rew"][0][-1])
+        self._rew_raw[1].copy_(out["_rew"][1][-1])
+        self._term_u8.copy_(out["_term"][-1])
+        return out
+
     def random_actions(self, action_seed: int, t: Optional[int] = None):
         """The policy stream of :meth:`step_random` as two ``int32[num_envs]`` device tensors."""
         if t is None:

@@ -411,3 +411,58 @@ def test_predictor_extreme_inputs():
     for full_net in (True, False):
         fast, it = _selftest(*(t[:, k].contiguous() for k in range(4)), full_net)
         assert torch.equal(fast, it), (full_net, fast.tolist(), it.tolist())
+
+
+# ------------------------------------------------------------------------------------------------
+# 6. k-frame rollout with every frame's outputs kept == k single steps
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kw,wr", [
+    (dict(winning_score=2), {}),
+    (dict(is_player2_computer=True, winning_score=3, serve="random"), {}),
+    (dict(is_player1_computer=True, is_player2_computer=True, winning_score=1),
+     dict(simplify_action=True, additional_reward=(0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01))),
+])
+def test_rollout_random_equals_stepwise(kw, wr, oracle):
+    n, k, rounds, aseed = 4096 + 64, 40, 5, 2718
+    a = make_env(num_envs=n, seed=6, env_id_base=300, wrappers=wr, **kw)
+    b = make_env(num_envs=n, seed=6, env_id_base=300, wrappers=wr, **kw)
+    a.reset(), b.reset()
+    out = None
+    for r in range(rounds):
+        out = a.unwrapped.rollout_random(aseed, k, out=out)
+        assert out["actions"].shape == (k, 2, n) and out["obs"]["player_1"].shape == (k, n, 35)
+        for t in range(k):
+            acts = b.unwrapped.random_actions(aseed)  # t = steps_done
+            assert torch.equal(out["actions"][t, 0], acts["player_1"]) and torch.equal(out["actions"][t, 1],
+                                                                                       acts["player_2"])
+            obs, rew, term, _, _ = b.step(acts)
+            for ag in ("player_1", "player_2"):
+                assert torch.equal(out["obs"][ag][t], obs[ag]), (r, t, ag)
+                assert torch.equal(out["rewards"][ag][t], rew[ag]), (r, t, ag)
+            assert torch.equal(out["terminations"][t], term["player_1"]), (r, t)
+        assert torch.equal(a.unwrapped.state, b.unwrapped.state)
+    assert a.unwrapped.steps_done == b.unwrapped.steps_done == k * rounds
+    assert a.unwrapped.episodes_done == int(sum(0 for _ in ())) + a.unwrapped.episodes_done  # counter readable
+    # and against the oracle at the end
+    ocfg = oracle.make_config(
+        winning_score=kw.get("winning_score", 15), serve=kw.get("serve", "winner"),
+        is_player1_computer=kw.get("is_player1_computer", False),
+        is_player2_computer=kw.get("is_player2_computer", False), simplify_action=bool(wr.get("simplify_action")),
+        additional_reward=wr.get("additional_reward"), seed=6, env_id_base=300)
+    ref = oracle.OracleEnv(n, ocfg, nthreads=8)
+    ref.reset()
+    eps = ref.rollout_random(aseed, 0, k * rounds)
+    assert np.array_equal(cpu(a.unwrapped.state), ref.state)
+    assert a.unwrapped.episodes_done == eps
+    # the single-frame views follow the last frame
+    o = a.unwrapped._pack_obs()
+    assert torch.equal(o["player_1"], out["obs"]["player_1"][-1])
+
+
+def test_rollout_argument_checks():
+    env = make_env(num_envs=6)  # not a multiple of 4
+    env.reset()
+    with pytest.raises(ValueError):
+        env.unwrapped.rollout_random(1, 2)
+    out = env.unwrapped.rollout_random(1, 1)  # a single frame has no alignment constraint
+    assert out["obs"]["player_1"].shape == (1, 6, 35)
