@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PZ_ABI_VERSION 1
+#define PZ_ABI_VERSION 2
 #define PZ_STATE_WORDS 44
 #define PZ_OBS_DIM 35
 
@@ -65,10 +65,20 @@ enum pz_error {
     PZ_E_ALIGN = -4       /* buffer not 16-byte aligned */
 };
 
-/* Constructor kwargs of pikazoo_v0.env (pikazoo_env.py:79-86) + the two fused wrappers
- * (wrappers/simplify_action.py:16-25, wrappers/reward_by_ball_position.py:7-31) + the
- * batched-env additions (auto_reset, seed, env_id_base). POD, 88 bytes, passed by pointer
- * from the host and by value to the kernels. */
+/* Constructor kwargs of pikazoo_v0.env (pikazoo_env.py:79-86) + the fused wrappers
+ * (wrappers/simplify_action.py, reward_by_ball_position.py, reward_in_normal_state.py,
+ * normalize_observation.py, record_episode_statistics.py) + the batched-env additions
+ * (auto_reset, seed, env_id_base). POD, 104 bytes, passed by pointer from the host and by
+ * value to the kernels.
+ *
+ * Reward pipeline of one frame, in the order the reference's wrapper stack would apply it:
+ *   r = +1/-1/0 (pikazoo_env.py:217-228)
+ *   [episode_stats_mode 1: statistics sum r]
+ *   [normal_state_mode 1: r == 0 -> normal_state_reward]      RewardInNormalState inside ...
+ *   [ballpos_reward:      r += additional_reward[4*i + zone]]  ... RewardByBallPosition
+ *   [normal_state_mode 2: r == 0 -> normal_state_reward]      RewardInNormalState outside it
+ *   [episode_stats_mode 2: statistics sum r]
+ * Rewards are float32 when ballpos_reward or normal_state_mode is set, else int32. */
 typedef struct pz_config {
     int32_t winning_score;        /* >= 1 */
     int32_t serve_mode;           /* enum pz_serve_mode */
@@ -81,6 +91,13 @@ typedef struct pz_config {
     float   additional_reward[8]; /* [0..3] player_1 zones, [4..7] player_2 zones */
     int32_t auto_reset;           /* 1: a finished game is reset() in place before its next frame */
     int32_t reserved;
+    int32_t normal_state_mode;    /* RewardInNormalState (reward_in_normal_state.py:10-15): 0 off,
+                                     1 applied before additional_reward, 2 after it */
+    float   normal_state_reward;  /* its constant (reward_in_normal_state.py:8) */
+    int32_t normalize_obs;        /* NormalizeObservation (normalize_observation.py:18-35): observations
+                                     are float32 (obs - low) / (high - low) */
+    int32_t episode_stats_mode;   /* RecordEpisodeStatistics (record_episode_statistics.py:27-40): 0 off,
+                                     1 sums the env's own reward, 2 the fully wrapped reward */
     uint64_t seed;                /* Philox4x32-10 key of the env RNG stream */
     int64_t env_id_base;          /* global id of lane 0 (shards of one job use disjoint ranges) */
 } pz_config;
@@ -101,21 +118,27 @@ int pz_init(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg, voi
  * flags and per-round fields are re-initialised, carry-over fields are kept, draws continue
  * from the lane's counter.  Observations of ALL lanes are written (obs_* may be NULL). */
 int pz_reset(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
-             const uint8_t *mask, int32_t *obs_p1, int32_t *obs_p2, void *stream);
+             const uint8_t *mask, int32_t *obs_p1, int32_t *obs_p2, int32_t *episode_stats,
+             void *stream);
 
-/* ---- raw_env._get_obs : pikazoo_env.py:576-624 ------------------------------------------ */
-int pz_observe(const int32_t *state, int64_t n, int64_t stride,
+/* ---- raw_env._get_obs : pikazoo_env.py:576-624 (normalize != 0: NormalizeObservation on top) */
+int pz_observe(const int32_t *state, int64_t n, int64_t stride, int32_t normalize,
                int32_t *obs_p1, int32_t *obs_p2, void *stream);
 
 /* ---- raw_env.step : pikazoo_env.py:175-240 (one frame of every game, one launch) ---------
  * act_p1/act_p2: int32[n] in [0,18) (or [0,13) with simplify_action).
  * rew_p1/rew_p2: int32[n] (+1/-1/0), or float32[n] when cfg->ballpos_reward.
  * terminated:    uint8[n] = game_ended after this frame (terminations of both agents);
- *                truncations are always False in the reference (:234) and are not written. */
+ *                truncations are always False in the reference (:234) and are not written.
+ * episode_stats: NULL, or 4-byte words [3][stride] = episode return of player 1, of player 2
+ *                (typed like the rewards) and episode length -- what RecordEpisodeStatistics
+ *                reports as infos[agent]["episode"] = {"r", "l"} on a terminal frame; zeroed by
+ *                reset (pz_reset or the in-place auto reset). Used when cfg->episode_stats_mode != 0.
+ * With cfg->normalize_obs the observation buffers receive float32 bit patterns. */
 int pz_step(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
             const int32_t *act_p1, const int32_t *act_p2,
             int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
-            uint8_t *terminated, void *stream);
+            uint8_t *terminated, int32_t *episode_stats, void *stream);
 
 /* ---- the same frame with the uniform random policy drawn on device ----------------------
  * actions of game g at step t come from Philox4x32-10(key=action_seed,
@@ -127,7 +150,8 @@ int pz_step(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
 int pz_step_random(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
                    uint64_t action_seed, uint64_t t0, int32_t k,
                    int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
-                   uint8_t *terminated, int64_t *episodes_done, void *stream);
+                   uint8_t *terminated, int32_t *episode_stats, int64_t *episodes_done,
+                   void *stream);
 
 /* ---- a k-frame rollout of the random policy with EVERY frame's outputs kept ---------------
  * Same trajectories as k calls of pz_step_random(k=1), in ONE launch: the state is read once,
@@ -140,7 +164,8 @@ int pz_step_random(int32_t *state, int64_t n, int64_t stride, const pz_config *c
 int pz_rollout_random(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
                       uint64_t action_seed, uint64_t t0, int32_t k, int32_t *actions,
                       int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
-                      uint8_t *terminated, int64_t *episodes_done, void *stream);
+                      uint8_t *terminated, int32_t *episode_stats, int64_t *episodes_done,
+                      void *stream);
 
 /* ---- the policy stream alone (for hosts that want the actions in HBM) -------------------- */
 int pz_random_actions(int32_t *act_p1, int32_t *act_p2, int64_t n, int64_t env_id_base,

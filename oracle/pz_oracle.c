@@ -612,7 +612,26 @@ static void player_info(const Player *pl, int32_t *o)
     o[12] = pl->power_hit_key_is_down_previous;
 }
 
-static void get_obs(const Game *g, int32_t *obs1, int32_t *obs2)
+/* observation_space bounds, pikazoo_env.py:485-562 (player, opponent, ball) */
+static const int OBS_LOW[35] = {32, 108, -15, -1, -2, 0, 0, 0, 0, 0, 0, 0, 0,
+                                32, 108, -15, -1, -2, 0, 0, 0, 0, 0, 0, 0, 0,
+                                20, 0, 0, 0, 0, 0, -20, -124, 0};
+static const int OBS_HIGH[35] = {400, 244, 16, 1, 3, 4, 4, 1, 1, 1, 1, 1, 1,
+                                 400, 244, 16, 1, 3, 4, 4, 1, 1, 1, 1, 1, 1,
+                                 432, 252, 432, 252, 432, 252, 20, 124, 1};
+
+/* NormalizeObservation (wrappers/normalize_observation.py:22,30): (obs - low) / (high - low),
+ * computed there in float64; the build emits float32 = the correctly rounded quotient, which
+ * equals float32(float64 quotient) for these small integers. */
+static void normalize_row(int32_t *row)
+{
+    for (int j = 0; j < 35; ++j) {
+        float f = (float)(row[j] - OBS_LOW[j]) / (float)(OBS_HIGH[j] - OBS_LOW[j]);
+        memcpy(&row[j], &f, 4);
+    }
+}
+
+static void get_obs_n(const Game *g, int32_t *obs1, int32_t *obs2, int normalize)
 {
     int32_t p1[13], p2[13], bo[9];
     player_info(&g->p[0], p1);
@@ -626,6 +645,10 @@ static void get_obs(const Game *g, int32_t *obs1, int32_t *obs2)
     }
     if (obs2) {
         memcpy(obs2, p2, sizeof p2); memcpy(obs2 + 13, p1, sizeof p1); memcpy(obs2 + 26, bo, sizeof bo);
+    }
+    if (normalize) {
+        if (obs1) normalize_row(obs1);
+        if (obs2) normalize_row(obs2);
     }
 }
 
@@ -719,17 +742,46 @@ static void store_game(const Game *g, int32_t *s, int64_t stride)
 }
 
 /* ---- raw_env.step: pikazoo_env.py:175-240, one game -------------------------------------- */
+typedef struct {
+    int32_t *ret1, *ret2, *len; /* this lane's episode-statistics words (NULL = off) */
+} Stats;
+
+static int rewards_are_float(const pzo_config *cfg) { return cfg->ballpos_reward || cfg->normal_state_mode; }
+
+static void stats_zero(const Stats *st)
+{
+    if (st && st->len) { *st->ret1 = 0; *st->ret2 = 0; *st->len = 0; } /* 0 == 0.0f bit pattern */
+}
+
+static void stats_add(const Stats *st, const pzo_config *cfg, float f1, float f2, int i1, int i2, int as_float)
+{
+    if (!st || !st->len) return;
+    (void)cfg;
+    if (as_float) {
+        float a, b;
+        memcpy(&a, st->ret1, 4); memcpy(&b, st->ret2, 4);
+        a += f1; b += f2;
+        memcpy(st->ret1, &a, 4); memcpy(st->ret2, &b, 4);
+    } else {
+        *st->ret1 += i1; *st->ret2 += i2;
+    }
+    *st->len += 1;
+}
+
 static void game_step(Game *g, const pzo_config *cfg, int a1, int a2,
-                      int32_t *obs1, int32_t *obs2, void *rew1, void *rew2, uint8_t *term)
+                      int32_t *obs1, int32_t *obs2, void *rew1, void *rew2, uint8_t *term, const Stats *st)
 {
     int frozen = 0;
     if (g->game_ended) {
         /* The reference empties `agents` on termination (:237-238) and the caller must
-         * reset() before stepping again.  auto_reset: do exactly that, in place. */
-        if (cfg->auto_reset)
+         * reset() before stepping again.  auto_reset: do exactly that, in place
+         * (RecordEpisodeStatistics.reset zeroes its sums, record_episode_statistics.py:23-25). */
+        if (cfg->auto_reset) {
             game_reset(g, cfg);
-        else
+            stats_zero(st);
+        } else {
             frozen = 1;
+        }
     }
 
     int player1_reward = 0;
@@ -769,22 +821,38 @@ static void game_step(Game *g, const pzo_config *cfg, int a1, int a2,
             player1_reward = g->is_player2_serve ? -1 : 1;
     }
 
-    get_obs(g, obs1, obs2); /* :215 */
+    get_obs_n(g, obs1, obs2, cfg->normalize_obs); /* :215 */
 
-    if (cfg->ballpos_reward) { /* reward_by_ball_position.py:22-29 */
-        int x_sign = g->ball.x >= cfg->x_line;
-        int y_sign = g->ball.y > cfg->y_line;
-        int ball_pos = 1 * y_sign + 2 * x_sign;
-        float r1 = (float)player1_reward, r2 = (float)(-player1_reward);
-        if (!frozen) {
+    const int as_float = rewards_are_float(cfg);
+    const int i1 = player1_reward, i2 = -player1_reward;
+    float r1 = (float)i1, r2 = (float)i2;
+    if (!frozen) {
+        if (cfg->episode_stats_mode == 1)
+            stats_add(st, cfg, (float)i1, (float)i2, i1, i2, as_float);
+        if (cfg->normal_state_mode == 1) { /* reward_in_normal_state.py:12-14, inside the other wrapper */
+            if (r1 == 0.0f) r1 = cfg->normal_state_reward;
+            if (r2 == 0.0f) r2 = cfg->normal_state_reward;
+        }
+        if (cfg->ballpos_reward) { /* reward_by_ball_position.py:22-29 */
+            int x_sign = g->ball.x >= cfg->x_line;
+            int y_sign = g->ball.y > cfg->y_line;
+            int ball_pos = 1 * y_sign + 2 * x_sign;
             r1 = r1 + cfg->additional_reward[0 * 4 + ball_pos];
             r2 = r2 + cfg->additional_reward[1 * 4 + ball_pos];
         }
+        if (cfg->normal_state_mode == 2) { /* the wrapper outside RewardByBallPosition */
+            if (r1 == 0.0f) r1 = cfg->normal_state_reward;
+            if (r2 == 0.0f) r2 = cfg->normal_state_reward;
+        }
+        if (cfg->episode_stats_mode == 2)
+            stats_add(st, cfg, r1, r2, i1, i2, as_float);
+    }
+    if (as_float) {
         *(float *)rew1 = r1;
         *(float *)rew2 = r2;
     } else {
-        *(int32_t *)rew1 = player1_reward;
-        *(int32_t *)rew2 = -player1_reward;
+        *(int32_t *)rew1 = i1;
+        *(int32_t *)rew2 = i2;
     }
     *term = (uint8_t)g->game_ended; /* :233 */
 }
@@ -799,63 +867,80 @@ void pzo_init(int32_t *state, int64_t n, int64_t stride, const pzo_config *cfg)
     }
 }
 
+static Stats lane_stats(int32_t *episode_stats, int64_t stride, int64_t i)
+{
+    Stats st = {0, 0, 0};
+    if (episode_stats) {
+        st.ret1 = episode_stats + i;
+        st.ret2 = episode_stats + stride + i;
+        st.len = episode_stats + 2 * stride + i;
+    }
+    return st;
+}
+
 void pzo_reset(int32_t *state, int64_t n, int64_t stride, const pzo_config *cfg,
-               const uint8_t *mask, int32_t *obs_p1, int32_t *obs_p2)
+               const uint8_t *mask, int32_t *obs_p1, int32_t *obs_p2, int32_t *episode_stats)
 {
     for (int64_t i = 0; i < n; ++i) {
         Game g;
         load_game(&g, state + i, stride, cfg, cfg->env_id_base + i);
         if (!mask || mask[i]) {
+            Stats st = lane_stats(episode_stats, stride, i);
             game_reset(&g, cfg);
+            stats_zero(&st);
             store_game(&g, state + i, stride);
         }
-        get_obs(&g, obs_p1 ? obs_p1 + i * PZO_OBS : 0, obs_p2 ? obs_p2 + i * PZO_OBS : 0);
+        get_obs_n(&g, obs_p1 ? obs_p1 + i * PZO_OBS : 0, obs_p2 ? obs_p2 + i * PZO_OBS : 0, cfg->normalize_obs);
     }
 }
 
-void pzo_observe(const int32_t *state, int64_t n, int64_t stride, int32_t *obs_p1, int32_t *obs_p2)
+void pzo_observe(const int32_t *state, int64_t n, int64_t stride, int32_t normalize, int32_t *obs_p1,
+                 int32_t *obs_p2)
 {
     pzo_config cfg;
     memset(&cfg, 0, sizeof cfg);
     for (int64_t i = 0; i < n; ++i) {
         Game g;
         load_game(&g, state + i, stride, &cfg, i);
-        get_obs(&g, obs_p1 ? obs_p1 + i * PZO_OBS : 0, obs_p2 ? obs_p2 + i * PZO_OBS : 0);
+        get_obs_n(&g, obs_p1 ? obs_p1 + i * PZO_OBS : 0, obs_p2 ? obs_p2 + i * PZO_OBS : 0, normalize);
     }
 }
 
 static void step_range(int32_t *state, int64_t lo, int64_t hi, int64_t stride, const pzo_config *cfg,
                        const int32_t *act_p1, const int32_t *act_p2, int32_t *obs_p1, int32_t *obs_p2,
-                       void *rew_p1, void *rew_p2, uint8_t *terminated)
+                       void *rew_p1, void *rew_p2, uint8_t *terminated, int32_t *episode_stats)
 {
     for (int64_t i = lo; i < hi; ++i) {
         Game g;
+        Stats st = lane_stats(episode_stats, stride, i);
         load_game(&g, state + i, stride, cfg, cfg->env_id_base + i);
         game_step(&g, cfg, act_p1[i], act_p2[i], obs_p1 + i * PZO_OBS, obs_p2 + i * PZO_OBS,
-                  (char *)rew_p1 + 4 * i, (char *)rew_p2 + 4 * i, terminated + i);
+                  (char *)rew_p1 + 4 * i, (char *)rew_p2 + 4 * i, terminated + i, &st);
         store_game(&g, state + i, stride);
     }
 }
 
 void pzo_step(int32_t *state, int64_t n, int64_t stride, const pzo_config *cfg,
               const int32_t *act_p1, const int32_t *act_p2, int32_t *obs_p1, int32_t *obs_p2,
-              void *rew_p1, void *rew_p2, uint8_t *terminated, int nthreads)
+              void *rew_p1, void *rew_p2, uint8_t *terminated, int32_t *episode_stats, int nthreads)
 {
     if (nthreads <= 1) {
-        step_range(state, 0, n, stride, cfg, act_p1, act_p2, obs_p1, obs_p2, rew_p1, rew_p2, terminated);
+        step_range(state, 0, n, stride, cfg, act_p1, act_p2, obs_p1, obs_p2, rew_p1, rew_p2, terminated,
+                   episode_stats);
         return;
     }
 #pragma omp parallel for schedule(static) num_threads(nthreads)
     for (int t = 0; t < nthreads; ++t) {
         int64_t lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
-        step_range(state, lo, hi, stride, cfg, act_p1, act_p2, obs_p1, obs_p2, rew_p1, rew_p2, terminated);
+        step_range(state, lo, hi, stride, cfg, act_p1, act_p2, obs_p1, obs_p2, rew_p1, rew_p2, terminated,
+                   episode_stats);
     }
 }
 
 void pzo_rollout_random(int32_t *state, int64_t n, int64_t stride, const pzo_config *cfg,
                         uint64_t action_seed, uint64_t t0, int32_t k,
                         int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
-                        uint8_t *terminated, int64_t *episodes_finished, int nthreads)
+                        uint8_t *terminated, int32_t *episode_stats, int64_t *episodes_finished, int nthreads)
 {
     if (nthreads < 1)
         nthreads = 1;
@@ -866,12 +951,13 @@ void pzo_rollout_random(int32_t *state, int64_t n, int64_t stride, const pzo_con
         int64_t lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
         for (int64_t i = lo; i < hi; ++i) {
             Game g;
+            Stats st = lane_stats(episode_stats, stride, i);
             load_game(&g, state + i, stride, cfg, cfg->env_id_base + i);
             for (int32_t s = 0; s < k; ++s) {
                 int32_t a1, a2;
                 pzo_random_actions(&a1, &a2, 1, cfg->env_id_base + i, action_seed, t0 + (uint64_t)s, n_actions);
                 game_step(&g, cfg, a1, a2, obs_p1 + i * PZO_OBS, obs_p2 + i * PZO_OBS,
-                          (char *)rew_p1 + 4 * i, (char *)rew_p2 + 4 * i, terminated + i);
+                          (char *)rew_p1 + 4 * i, (char *)rew_p2 + 4 * i, terminated + i, &st);
                 finished += terminated[i];
             }
             store_game(&g, state + i, stride);

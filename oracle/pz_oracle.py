@@ -61,6 +61,10 @@ class Config(C.Structure):
         ("additional_reward", C.c_float * 8),
         ("auto_reset", C.c_int32),
         ("reserved", C.c_int32),
+        ("normal_state_mode", C.c_int32),
+        ("normal_state_reward", C.c_float),
+        ("normalize_obs", C.c_int32),
+        ("episode_stats_mode", C.c_int32),
         ("seed", C.c_uint64),
         ("env_id_base", C.c_int64),
     ]
@@ -68,7 +72,12 @@ class Config(C.Structure):
 
 def make_config(winning_score=15, serve="winner", is_player1_computer=False,
                 is_player2_computer=False, simplify_action=False, additional_reward=None,
-                x_line=216, y_line=176, auto_reset=True, seed=0, env_id_base=0) -> Config:
+                x_line=216, y_line=176, auto_reset=True, seed=0, env_id_base=0,
+                normal_state_reward=None, normal_state_outside=False, normalize_obs=False,
+                episode_stats=0) -> Config:
+    """normal_state_reward: RewardInNormalState's constant (None = off); normal_state_outside: that
+    wrapper sits outside RewardByBallPosition; episode_stats: 0 off, 1 RecordEpisodeStatistics
+    directly on the env's rewards, 2 on the fully wrapped rewards."""
     cfg = Config()
     cfg.winning_score = int(winning_score)
     cfg.serve_mode = SERVE_MODES[serve]
@@ -83,6 +92,10 @@ def make_config(winning_score=15, serve="winner", is_player1_computer=False,
         for i, v in enumerate(additional_reward):
             cfg.additional_reward[i] = float(v)
     cfg.auto_reset = int(bool(auto_reset))
+    cfg.normal_state_mode = 0 if normal_state_reward is None else (2 if normal_state_outside else 1)
+    cfg.normal_state_reward = 0.0 if normal_state_reward is None else float(normal_state_reward)
+    cfg.normalize_obs = int(bool(normalize_obs))
+    cfg.episode_stats_mode = int(episode_stats)
     cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     cfg.env_id_base = int(env_id_base)
     return cfg
@@ -114,15 +127,15 @@ def lib():
         L.pzo_random_actions.restype = None
         L.pzo_init.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(Config)]
         L.pzo_init.restype = None
-        L.pzo_reset.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(Config), vp, vp, vp]
+        L.pzo_reset.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(Config), vp, vp, vp, vp]
         L.pzo_reset.restype = None
-        L.pzo_step.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(Config), vp, vp, vp, vp, vp, vp, vp, C.c_int]
+        L.pzo_step.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(Config), vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
         L.pzo_step.restype = None
         L.pzo_rollout_random.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(Config), C.c_uint64,
-                                         C.c_uint64, C.c_int32, vp, vp, vp, vp, vp,
+                                         C.c_uint64, C.c_int32, vp, vp, vp, vp, vp, vp,
                                          C.POINTER(C.c_int64), C.c_int]
         L.pzo_rollout_random.restype = None
-        L.pzo_observe.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
+        L.pzo_observe.argtypes = [vp, C.c_int64, C.c_int64, C.c_int32, vp, vp]
         L.pzo_observe.restype = None
         L.pzo_digest.argtypes = [vp, C.c_int64, C.c_int64]
         L.pzo_digest.restype = C.c_uint64
@@ -180,16 +193,32 @@ class OracleEnv:
         self.cfg = cfg
         self.nthreads = nthreads
         self.state = np.zeros((W, self.n), np.int32)
-        self.obs = [np.zeros((self.n, OBS), np.int32) for _ in range(2)]
-        rdt = np.float32 if cfg.ballpos_reward else np.int32
+        odt = np.float32 if cfg.normalize_obs else np.int32
+        self.obs = [np.zeros((self.n, OBS), odt) for _ in range(2)]
+        self.float_rewards = bool(cfg.ballpos_reward or cfg.normal_state_mode)
+        rdt = np.float32 if self.float_rewards else np.int32
         self.rew = [np.zeros(self.n, rdt) for _ in range(2)]
         self.term = np.zeros(self.n, np.uint8)
+        # RecordEpisodeStatistics words: [return p1, return p2, length] x n (returns typed like the rewards)
+        self.stats = np.zeros((3, self.n), np.int32) if cfg.episode_stats_mode else None
         lib().pzo_init(_p(self.state), self.n, self.n, C.byref(cfg))
+
+    def _stats_ptr(self):
+        return None if self.stats is None else _p(self.stats)
+
+    @property
+    def episode_returns(self):
+        r = self.stats[:2]
+        return r.view(np.float32) if self.float_rewards else r
+
+    @property
+    def episode_lengths(self):
+        return self.stats[2]
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         lib().pzo_reset(_p(self.state), self.n, self.n, C.byref(self.cfg),
-                        None if m is None else _p(m), _p(self.obs[0]), _p(self.obs[1]))
+                        None if m is None else _p(m), _p(self.obs[0]), _p(self.obs[1]), self._stats_ptr())
         return self.obs[0], self.obs[1]
 
     def step(self, a1, a2):
@@ -197,20 +226,21 @@ class OracleEnv:
         a2 = np.ascontiguousarray(a2, np.int32)
         lib().pzo_step(_p(self.state), self.n, self.n, C.byref(self.cfg), _p(a1), _p(a2),
                        _p(self.obs[0]), _p(self.obs[1]), _p(self.rew[0]), _p(self.rew[1]),
-                       _p(self.term), self.nthreads)
+                       _p(self.term), self._stats_ptr(), self.nthreads)
         return self.obs, self.rew, self.term
 
     def rollout_random(self, action_seed: int, t0: int, k: int) -> int:
         fin = C.c_int64(0)
         lib().pzo_rollout_random(_p(self.state), self.n, self.n, C.byref(self.cfg), action_seed, t0, k,
                                  _p(self.obs[0]), _p(self.obs[1]), _p(self.rew[0]), _p(self.rew[1]),
-                                 _p(self.term), C.byref(fin), self.nthreads)
+                                 _p(self.term), self._stats_ptr(), C.byref(fin), self.nthreads)
         return int(fin.value)
 
     def observe(self):
-        o1 = np.zeros((self.n, OBS), np.int32)
-        o2 = np.zeros((self.n, OBS), np.int32)
-        lib().pzo_observe(_p(self.state), self.n, self.n, _p(o1), _p(o2))
+        odt = np.float32 if self.cfg.normalize_obs else np.int32
+        o1 = np.zeros((self.n, OBS), odt)
+        o2 = np.zeros((self.n, OBS), odt)
+        lib().pzo_observe(_p(self.state), self.n, self.n, int(self.cfg.normalize_obs), _p(o1), _p(o2))
         return o1, o2
 
     def digest(self) -> int:

@@ -142,6 +142,53 @@ def install_stubs():
         sys.path.insert(0, str(REFERENCE_ROOT))
 
 
+def wrapper_stack(wrappers):
+    """Ordered (innermost first) list of (reference wrapper class name, kwargs).
+
+    Accepts the short dict form of the first fixtures ({"simplify_action": True,
+    "additional_reward": [...], "x_line": .., "y_line": ..}) or {"stack": [[name, kwargs], ...]}."""
+    wrappers = wrappers or {}
+    if "stack" in wrappers:
+        return [(n, dict(k)) for n, k in wrappers["stack"]]
+    stack = []
+    if wrappers.get("simplify_action"):
+        stack.append(("SimplifyAction", {}))
+    if wrappers.get("additional_reward") is not None:
+        stack.append(("RewardByBallPosition", dict(additional_reward=list(wrappers["additional_reward"]),
+                                                   x_line=wrappers.get("x_line", 216),
+                                                   y_line=wrappers.get("y_line", 176))))
+    return stack
+
+
+def fused_options(wrappers) -> dict:
+    """What the fused kernel / the oracle must be configured with to equal that wrapper stack."""
+    opt = dict(simplify_action=False, additional_reward=None, x_line=216, y_line=176,
+               normal_state_reward=None, normal_state_outside=False, normalize_obs=False, episode_stats=0)
+    seen_reward_wrapper = False
+    stack = wrapper_stack(wrappers)
+    for idx, (name, kw) in enumerate(stack):
+        if name == "SimplifyAction":
+            opt["simplify_action"] = True
+        elif name == "RewardByBallPosition":
+            assert not opt["normalize_obs"], "RewardByBallPosition must sit below NormalizeObservation"
+            opt.update(additional_reward=list(kw["additional_reward"]), x_line=kw.get("x_line", 216),
+                       y_line=kw.get("y_line", 176))
+            seen_reward_wrapper = True
+        elif name == "RewardInNormalState":
+            opt["normal_state_reward"] = kw["reward"]
+            opt["normal_state_outside"] = opt["additional_reward"] is not None
+            seen_reward_wrapper = True
+        elif name == "NormalizeObservation":
+            opt["normalize_obs"] = True
+        elif name == "RecordEpisodeStatistics":
+            later_reward = any(n in ("RewardByBallPosition", "RewardInNormalState") for n, _ in stack[idx + 1:])
+            assert not (seen_reward_wrapper and later_reward), "statistics between two reward wrappers"
+            opt["episode_stats"] = 2 if seen_reward_wrapper else 1
+        else:
+            raise ValueError(name)
+    return opt
+
+
 def reference_available() -> bool:
     return (REFERENCE_ROOT / "pikazoo" / "env" / "physics.py").exists()
 
@@ -159,14 +206,13 @@ def make_reference_env(seed: int, env_id: int, wrappers: dict | None = None, **k
     assert raw.np_random is shim and raw.physics.np_random is shim
     assert raw.physics.player1.np_random is shim and raw.physics.player2.np_random is shim
     env = raw
-    wrappers = wrappers or {}
-    if wrappers.get("simplify_action"):
-        from pikazoo.wrappers import SimplifyAction
-        env = SimplifyAction(env)
-    if wrappers.get("additional_reward") is not None:
-        from pikazoo.wrappers import RewardByBallPosition
-        env = RewardByBallPosition(env, tuple(wrappers["additional_reward"]),
-                                   wrappers.get("x_line", 216), wrappers.get("y_line", 176))
+    import pikazoo.wrappers as ref_wrappers
+
+    for name, kw in wrapper_stack(wrappers):
+        kw = dict(kw)
+        if "additional_reward" in kw:
+            kw["additional_reward"] = tuple(kw["additional_reward"])
+        env = getattr(ref_wrappers, name)(env, **kw)
     return env, raw, shim
 
 
@@ -215,11 +261,14 @@ def capture(name: str, lanes: int, steps: int, seed: int, action_seed: int, env_
     full=True stores every state/obs/reward; digest_every>0 stores one 64-bit digest of the
     [W, lanes] state matrix every that many steps instead (long runs for rare branches)."""
     wrappers = wrappers or {}
-    n_actions = 13 if wrappers.get("simplify_action") else 18
-    fused_reward = wrappers.get("additional_reward") is not None
+    opt = fused_options(wrappers)
+    n_actions = 13 if opt["simplify_action"] else 18
+    fused_reward = opt["additional_reward"] is not None or opt["normal_state_reward"] is not None
+    float_obs = opt["normalize_obs"]
+    has_stats = opt["episode_stats"] != 0
     envs = [make_reference_env(seed, env_id_base + i, wrappers, **env_kwargs) for i in range(lanes)]
     state_ctor = np.stack([extract_state(raw, shim) for _, raw, shim in envs], axis=1)
-    obs_reset = np.zeros((lanes, 2, po.OBS), np.int64)
+    obs_reset = np.zeros((lanes, 2, po.OBS), np.float64 if float_obs else np.int64)
     for i, (env, raw, shim) in enumerate(envs):
         obs, infos = env.reset(seed=1234 + i)  # the reference ignores seed (pikazoo_env.py:149)
         obs_reset[i, 0], obs_reset[i, 1] = obs["player_1"], obs["player_2"]
@@ -227,11 +276,13 @@ def capture(name: str, lanes: int, steps: int, seed: int, action_seed: int, env_
     state0 = np.stack([extract_state(raw, shim) for _, raw, shim in envs], axis=1)
 
     out = dict(state_ctor=state_ctor.astype(np.int32), state0=state0.astype(np.int32),
-               obs_reset=obs_reset.astype(np.int32))
+               obs_reset=obs_reset if float_obs else obs_reset.astype(np.int32))
     if full:
         actions = np.zeros((steps, 2, lanes), np.int32)
         states = np.zeros((steps, po.W, lanes), np.int32)
-        obs_all = np.zeros((steps, 2, lanes, po.OBS), np.int32)
+        obs_all = np.zeros((steps, 2, lanes, po.OBS), np.float64 if float_obs else np.int32)
+        ep_r = np.full((steps, 2, lanes), np.nan)   # infos[agent]["episode"]["r"] where present
+        ep_l = np.full((steps, lanes), -1, np.int64)  # infos[agent]["episode"]["l"] where present
         rew = np.zeros((steps, 2, lanes), np.float64)
         term = np.zeros((steps, lanes), np.uint8)
     digests = []
@@ -253,6 +304,13 @@ def capture(name: str, lanes: int, steps: int, seed: int, action_seed: int, env_
                 term[t, i] = int(terms["player_1"])
                 if not fused_reward:
                     assert isinstance(rews["player_1"], int)
+                if has_stats:
+                    assert ("episode" in infos["player_1"]) == bool(terms["player_1"])
+                    if "episode" in infos["player_1"]:
+                        ep_r[t, 0, i] = infos["player_1"]["episode"]["r"]
+                        ep_r[t, 1, i] = infos["player_2"]["episode"]["r"]
+                        ep_l[t, i] = infos["player_1"]["episode"]["l"]
+                        assert infos["player_2"]["episode"]["l"] == ep_l[t, i]
         if full:
             actions[t, 0], actions[t, 1] = a1, a2
             states[t] = cur
@@ -266,8 +324,10 @@ def capture(name: str, lanes: int, steps: int, seed: int, action_seed: int, env_
     if full:
         out.update(actions=actions.astype(np.uint8), states=states.astype(np.int16),
                    rng_counter=states[:, po.E_RNG_COUNTER, :].astype(np.int32),
-                   obs=obs_all.astype(np.int16), term=term,
+                   obs=(obs_all if float_obs else obs_all.astype(np.int16)), term=term,
                    rew=(rew if fused_reward else rew.astype(np.int8)))
+        if has_stats:
+            out.update(ep_r=ep_r, ep_l=ep_l.astype(np.int32))
         assert np.array_equal(out["states"].astype(np.int32)[:, :po.E_RNG_COUNTER],
                               states[:, :po.E_RNG_COUNTER])  # int16 is lossless here
     if digest_every:
@@ -294,6 +354,27 @@ FIXTURES = [
     ("wrappers_int_table", 4, 1500, dict(winning_score=5, serve="winner", is_player2_computer=True),
      dict(simplify_action=True, additional_reward=INT_TABLE, x_line=200, y_line=150)),
     ("simplify_only", 4, 1500, dict(winning_score=15, serve="winner"), dict(simplify_action=True)),
+]
+
+FIXTURES += [
+    ("normal_state_only", 4, 1500, dict(winning_score=3, serve="winner"),
+     dict(stack=[["RewardInNormalState", dict(reward=-0.001)]])),
+    ("normal_state_inside_ballpos", 4, 1500, dict(winning_score=3, is_player2_computer=True),
+     dict(stack=[["RewardInNormalState", dict(reward=0.25)],
+                 ["RewardByBallPosition", dict(additional_reward=list(TEST_TABLE), x_line=216, y_line=176)]])),
+    ("normal_state_outside_ballpos", 4, 1500, dict(winning_score=3, serve="alternate"),
+     dict(stack=[["RewardByBallPosition", dict(additional_reward=list(TEST_TABLE), x_line=216, y_line=176)],
+                 ["RewardInNormalState", dict(reward=0.5)]])),
+    ("normalize_observation", 4, 800, dict(winning_score=2, is_player2_computer=True),
+     dict(stack=[["NormalizeObservation", {}]])),
+    ("record_stats_raw", 4, 2500, dict(winning_score=2, serve="winner"),
+     dict(stack=[["RecordEpisodeStatistics", {}]])),
+    ("full_wrapper_stack", 4, 2500, dict(winning_score=2, serve="random", is_player2_computer=True),
+     dict(stack=[["SimplifyAction", {}],
+                 ["RewardInNormalState", dict(reward=-0.002)],
+                 ["RewardByBallPosition", dict(additional_reward=list(TEST_TABLE), x_line=216, y_line=176)],
+                 ["NormalizeObservation", {}],
+                 ["RecordEpisodeStatistics", {}]])),
 ]
 
 DIGEST_RUNS = [

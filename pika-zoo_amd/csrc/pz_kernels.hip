@@ -64,6 +64,7 @@ struct StepArgs {
     void* rew_p1;
     void* rew_p2;
     uint8_t* terminated;
+    int32_t* episode_stats;  // [3][stride] words: return p1, return p2, length (nullptr = off)
     unsigned long long* episodes_done;
     pz_config cfg;
 };
@@ -210,46 +211,74 @@ __device__ __forceinline__ RngId make_rng_id(const pz_config& cfg, int64_t lane_
 // Row layout: player(13) | opponent(13) | ball(9).  Rows go to LDS at stride 35 words (odd,
 // so the 64 lanes of a ds_write_b32 hit 32 distinct banks twice = conflict-free), then the
 // wave copies the contiguous 64x35-word span to HBM with 16-byte lanes.
-__device__ __forceinline__ void player_row(const Player& p, int32_t* __restrict__ o)
+// NORM: NormalizeObservation fused (normalize_observation.py:22,30): every entry becomes
+// float32 (v - low) / (high - low) with the bounds of pikazoo_env.py:485-562.  The reference
+// divides in float64; for these small integers the correctly rounded float32 quotient is the
+// float32 rounding of that double, so an IEEE float division reproduces it bit for bit.
+template <bool NORM>
+__device__ __forceinline__ int32_t obs_word(int v, int low, int range)
 {
-    o[0] = p.x;
-    o[1] = p.y;
-    o[2] = p.yv;
-    o[3] = p.dive;
-    o[4] = p.lying;
-    o[5] = p.frame;
-    o[6] = p.delay;
-    o[7] = p.state == 0;
-    o[8] = p.state == 1;
-    o[9] = p.state == 2;
-    o[10] = p.state == 3;
-    o[11] = p.state == 4;
-    o[12] = p.hitprev;
+    if (!NORM) return v;
+    const float f = (range == 1) ? (float)(v - low) : (float)(v - low) / (float)range;
+    return (int32_t)__float_as_uint(f);
 }
 
-__device__ __forceinline__ void ball_row(const Ball& b, int32_t* __restrict__ o)
+template <bool NORM>
+__device__ __forceinline__ void player_words(const Player& p, int32_t (&w)[13])
 {
-    o[0] = b.x;
-    o[1] = b.y;
-    o[2] = b.px;
-    o[3] = b.py;
-    o[4] = b.ppx;
-    o[5] = b.ppy;
-    o[6] = b.xv;
-    o[7] = b.yv;
-    o[8] = b.power;
+    w[0] = obs_word<NORM>(p.x, 32, 368);
+    w[1] = obs_word<NORM>(p.y, 108, 136);
+    w[2] = obs_word<NORM>(p.yv, -15, 31);
+    w[3] = obs_word<NORM>(p.dive, -1, 2);
+    w[4] = obs_word<NORM>(p.lying, -2, 5);
+    w[5] = obs_word<NORM>(p.frame, 0, 4);
+    w[6] = obs_word<NORM>(p.delay, 0, 4);
+    w[7] = obs_word<NORM>(p.state == 0, 0, 1);
+    w[8] = obs_word<NORM>(p.state == 1, 0, 1);
+    w[9] = obs_word<NORM>(p.state == 2, 0, 1);
+    w[10] = obs_word<NORM>(p.state == 3, 0, 1);
+    w[11] = obs_word<NORM>(p.state == 4, 0, 1);
+    w[12] = obs_word<NORM>(p.hitprev, 0, 1);
 }
 
-__device__ __forceinline__ void stage_obs(const Game& g, int32_t* __restrict__ s1, int32_t* __restrict__ s2, int lane)
+template <bool NORM>
+__device__ __forceinline__ void stage_obs_t(const Game& g, int32_t* __restrict__ s1, int32_t* __restrict__ s2, int lane)
 {
+    int32_t p1[13], p2[13], bw[9];
+    player_words<NORM>(g.p1, p1);
+    player_words<NORM>(g.p2, p2);
+    bw[0] = obs_word<NORM>(g.b.x, 20, 412);
+    bw[1] = obs_word<NORM>(g.b.y, 0, 252);
+    bw[2] = obs_word<NORM>(g.b.px, 0, 432);
+    bw[3] = obs_word<NORM>(g.b.py, 0, 252);
+    bw[4] = obs_word<NORM>(g.b.ppx, 0, 432);
+    bw[5] = obs_word<NORM>(g.b.ppy, 0, 252);
+    bw[6] = obs_word<NORM>(g.b.xv, -20, 40);
+    bw[7] = obs_word<NORM>(g.b.yv, -124, 248);
+    bw[8] = obs_word<NORM>(g.b.power, 0, 1);
     int32_t* r1 = s1 + lane * PZ_OBS_DIM;
     int32_t* r2 = s2 + lane * PZ_OBS_DIM;
-    player_row(g.p1, r1);
-    player_row(g.p2, r1 + 13);
-    ball_row(g.b, r1 + 26);
-    player_row(g.p2, r2);
-    player_row(g.p1, r2 + 13);
-    ball_row(g.b, r2 + 26);
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        r1[k] = p1[k];
+        r1[13 + k] = p2[k];
+        r2[k] = p2[k];
+        r2[13 + k] = p1[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        r1[26 + k] = bw[k];
+        r2[26 + k] = bw[k];
+    }
+}
+
+__device__ __forceinline__ void stage_obs(const Game& g, int32_t* __restrict__ s1, int32_t* __restrict__ s2, int lane,
+                                          bool normalize)
+{
+    if (normalize)  // wave-uniform (a config scalar)
+        stage_obs_t<true>(g, s1, s2, lane);
+    else
+        stage_obs_t<false>(g, s1, s2, lane);
 }
 
 // Copy the wave's 64 staged rows (8 960 B) to its span of an [n][35] tensor: 9 passes of
@@ -305,13 +334,60 @@ __device__ unsigned long long g_pz_stamps[8192 * 8];
 // SPARSE: changed-only write-back of the rarely changing columns (large batches).
 enum StepMode { kActions = 0, kRandom = 1, kRollout = 2 };
 
-// outputs of one frame: rewards (pikazoo_env.py:217-228, optionally with RewardByBallPosition
-// fused, reward_by_ball_position.py:22-29: zone from the post-step ball position), terminated
-// (:233) and the two observation tensors through the LDS transpose.  `t` = frame index inside
-// a trajectory (0 for single-frame outputs).
-__device__ __forceinline__ void emit_outputs(const StepArgs& a, const Game& g, int reward, bool frozen, bool live,
-                                             int64_t i, int lane, int64_t t, int32_t (*lds_obs)[kLanes * PZ_OBS_DIM],
-                                             bool skip_obs)
+// The reward pipeline of one frame (see pz_config in the header): the reference's wrapper
+// stack RewardInNormalState / RewardByBallPosition in either order, fused.
+struct Rewards {
+    int i1, i2;      // the env's own +1/-1/0 (pikazoo_env.py:217-228)
+    float f1, f2;    // after the fused reward wrappers
+};
+
+__device__ __forceinline__ Rewards shape_rewards(const pz_config& cfg, const Game& g, int reward, bool frozen)
+{
+    Rewards r{reward, -reward, (float)reward, (float)(-reward)};
+    if (frozen) return r;
+    if (cfg.normal_state_mode == 1) {  // reward_in_normal_state.py:12-14, inside RewardByBallPosition
+        r.f1 = (r.f1 == 0.0f) ? cfg.normal_state_reward : r.f1;
+        r.f2 = (r.f2 == 0.0f) ? cfg.normal_state_reward : r.f2;
+    }
+    if (cfg.ballpos_reward) {  // reward_by_ball_position.py:22-29: zone from the post-step ball position
+        const int zone = (g.b.y > cfg.y_line ? 1 : 0) + (g.b.x >= cfg.x_line ? 2 : 0);
+        r.f1 += cfg.additional_reward[zone];
+        r.f2 += cfg.additional_reward[4 + zone];
+    }
+    if (cfg.normal_state_mode == 2) {  // the wrapper outside RewardByBallPosition
+        r.f1 = (r.f1 == 0.0f) ? cfg.normal_state_reward : r.f1;
+        r.f2 = (r.f2 == 0.0f) ? cfg.normal_state_reward : r.f2;
+    }
+    return r;
+}
+
+// RecordEpisodeStatistics (record_episode_statistics.py:27-40) as three per-game words.
+struct EpisodeStats {
+    uint32_t r1, r2;  // running returns, float32 or int32 bit patterns (typed like the rewards)
+    int len;
+};
+
+__device__ __forceinline__ void stats_update(EpisodeStats& st, const pz_config& cfg, const Rewards& r, bool was_reset,
+                                             bool counted, bool as_float)
+{
+    if (was_reset) st = EpisodeStats{0u, 0u, 0};  // reset() zeroes the sums (:23-25); 0 is 0.0f too
+    if (!counted) return;
+    const bool raw = cfg.episode_stats_mode == 1;
+    if (as_float) {
+        st.r1 = __float_as_uint(__uint_as_float(st.r1) + (raw ? (float)r.i1 : r.f1));
+        st.r2 = __float_as_uint(__uint_as_float(st.r2) + (raw ? (float)r.i2 : r.f2));
+    } else {
+        st.r1 += (uint32_t)r.i1;
+        st.r2 += (uint32_t)r.i2;
+    }
+    st.len += 1;
+}
+
+// outputs of one frame: rewards, terminated (pikazoo_env.py:233) and the two observation
+// tensors through the LDS transpose.  `t` = frame index inside a trajectory (0 otherwise).
+__device__ __forceinline__ void emit_outputs(const StepArgs& a, const Game& g, const Rewards& r, bool as_float,
+                                             bool live, int64_t i, int lane, int64_t t,
+                                             int32_t (*lds_obs)[kLanes * PZ_OBS_DIM], bool skip_obs)
 {
     const uint32_t n32 = (uint32_t)a.n;
     const uint32_t voff = (uint32_t)i * 4u;
@@ -320,22 +396,11 @@ __device__ __forceinline__ void emit_outputs(const StepArgs& a, const Game& g, i
     const Rsrc rew2 = make_rsrc(static_cast<char*>(a.rew_p2) + t * a.n * 4, n32 * 4u);
     const Rsrc term = make_rsrc(a.terminated + t * a.n, n32);
     if (live) {
-        if (a.cfg.ballpos_reward) {
-            const int zone = (g.b.y > a.cfg.y_line ? 1 : 0) + (g.b.x >= a.cfg.x_line ? 2 : 0);
-            float r1 = (float)reward, r2 = (float)(-reward);
-            if (!frozen) {
-                r1 += a.cfg.additional_reward[zone];
-                r2 += a.cfg.additional_reward[4 + zone];
-            }
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r1), rew1, voff, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r2), rew2, voff, 0, 0);
-        } else {
-            __builtin_amdgcn_raw_buffer_store_b32((unsigned int)reward, rew1, voff, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32((unsigned int)(-reward), rew2, voff, 0, 0);
-        }
+        __builtin_amdgcn_raw_buffer_store_b32(as_float ? __float_as_uint(r.f1) : (unsigned int)r.i1, rew1, voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(as_float ? __float_as_uint(r.f2) : (unsigned int)r.i2, rew2, voff, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, term, (uint32_t)i, 0, 0);
         PZ_STAMP(3);
-        if (!skip_obs) stage_obs(g, lds_obs[0], lds_obs[1], lane);
+        if (!skip_obs) stage_obs(g, lds_obs[0], lds_obs[1], lane, a.cfg.normalize_obs != 0);
     }
     __syncthreads();
     PZ_STAMP(4);
@@ -360,6 +425,10 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
     // descriptors are built from kernel arguments only, so they are provably wave-uniform
     const StateIO io{make_rsrc(a.state, (uint32_t)(a.stride * (PZ_STATE_WORDS * 4))), (uint32_t)a.stride * 4u,
                      (uint32_t)i * 4u};
+    const bool as_float = a.cfg.ballpos_reward != 0 || a.cfg.normal_state_mode != 0;
+    const bool with_stats = a.episode_stats != nullptr && a.cfg.episode_stats_mode != 0;  // uniform
+    const StateIO sio{make_rsrc(a.episode_stats, with_stats ? (uint32_t)(a.stride * 12) : 0u),
+                      (uint32_t)a.stride * 4u, (uint32_t)i * 4u};
 
     Game g{};
     const RngId id = make_rng_id(a.cfg, live ? i : 0);
@@ -375,31 +444,46 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
         a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act_p1, n32 * 4u), io.voff, 0, 0);
         a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act_p2, n32 * 4u), io.voff, 0, 0);
     }
-    if (live) load_game(g, io);
+    EpisodeStats st{0u, 0u, 0};
+    if (live) {
+        load_game(g, io);
+        if (with_stats) {
+            st.r1 = (uint32_t)sio.ld(0);
+            st.r2 = (uint32_t)sio.ld(1);
+            st.len = sio.ld(2);
+        }
+    }
     const Game loaded = g;  // SPARSE: what the columns held before the frame
     PZ_DRAIN_VMEM();
     PZ_STAMP(1);
     // The frame runs in wave-uniform control flow (the computer player's power-hit candidates
     // are evaluated cooperatively by the wave); lanes past the end of the batch idle inside.
     // lds_obs[0] doubles as the cooperative scratch until the observations are staged.
+    Rewards rw{0, 0, 0.0f, 0.0f};
     if (MODE != kActions) {
         const uint32_t n_actions = a.cfg.simplify_action ? 13u : 18u;
         for (int32_t s = 0; s < a.k; ++s) {
             policy_actions(id.id_lo, id.id_hi, a.action_seed, a.t0 + (uint64_t)s, n_actions, a1, a2);
+            const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
             reward = step_games<AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane);
             finished += (unsigned int)(live && g.e.game_ended && !frozen);
+            rw = shape_rewards(a.cfg, g, reward, frozen);
+            if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
             if (MODE == kRollout) {
                 if (a.act_out != nullptr) {
                     const Rsrc ao = make_rsrc(a.act_out + (int64_t)s * 2 * a.n, n32 * 8u);
                     __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a1, ao, io.voff, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, io.voff, n32 * 4u, 0);
                 }
-                emit_outputs(a, g, reward, frozen, live, i, lane, s, lds_obs, false);
+                emit_outputs(a, g, rw, as_float, live, i, lane, s, lds_obs, false);
             }
         }
     } else if (!PZ_SKIP_FRAME) {
+        const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
         reward = step_games<AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane);
         finished = (unsigned int)(live && g.e.game_ended && !frozen);
+        rw = shape_rewards(a.cfg, g, reward, frozen);
+        if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
     }
     PZ_STAMP(2);
     if (live) {
@@ -407,8 +491,13 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
             store_game_changed(g, loaded, io);
         else
             store_game(g, io);
+        if (with_stats) {
+            sio.st(0, (int)st.r1);
+            sio.st(1, (int)st.r2);
+            sio.st(2, st.len);
+        }
     }
-    if (MODE != kRollout) emit_outputs(a, g, reward, frozen, live, i, lane, 0, lds_obs, PZ_SKIP_OBS);
+    if (MODE != kRollout) emit_outputs(a, g, rw, as_float, live, i, lane, 0, lds_obs, PZ_SKIP_OBS);
     PZ_STAMP(5);
     PZ_DRAIN_VMEM();
     PZ_STAMP(6);
@@ -435,7 +524,8 @@ __global__ __launch_bounds__(kLanes) void init_kernel(int32_t* state, int64_t n,
 }
 
 __global__ __launch_bounds__(kLanes) void reset_kernel(int32_t* state, int64_t n, int64_t stride, const pz_config cfg,
-                                                       const uint8_t* mask, int32_t* obs_p1, int32_t* obs_p2)
+                                                       const uint8_t* mask, int32_t* obs_p1, int32_t* obs_p2,
+                                                       int32_t* episode_stats)
 {
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     const int lane = threadIdx.x;
@@ -449,8 +539,13 @@ __global__ __launch_bounds__(kLanes) void reset_kernel(int32_t* state, int64_t n
             const RngId id = make_rng_id(cfg, i);
             reset_game(g, cfg, id);
             store_game(g, io);
+            if (episode_stats != nullptr) {  // RecordEpisodeStatistics.reset (:23-25)
+                episode_stats[i] = 0;
+                episode_stats[stride + i] = 0;
+                episode_stats[2 * stride + i] = 0;
+            }
         }
-        stage_obs(g, lds_obs[0], lds_obs[1], lane);
+        stage_obs(g, lds_obs[0], lds_obs[1], lane, cfg.normalize_obs != 0);
     }
     __syncthreads();
     const uint32_t wave_off = blockIdx.x * kWaveObsBytes;
@@ -459,7 +554,7 @@ __global__ __launch_bounds__(kLanes) void reset_kernel(int32_t* state, int64_t n
 }
 
 __global__ __launch_bounds__(kLanes) void observe_kernel(const int32_t* state, int64_t n, int64_t stride,
-                                                         int32_t* obs_p1, int32_t* obs_p2)
+                                                         int normalize, int32_t* obs_p1, int32_t* obs_p2)
 {
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     const int lane = threadIdx.x;
@@ -469,7 +564,7 @@ __global__ __launch_bounds__(kLanes) void observe_kernel(const int32_t* state, i
     if (i < n) {
         Game g;
         load_game(g, io);
-        stage_obs(g, lds_obs[0], lds_obs[1], lane);
+        stage_obs(g, lds_obs[0], lds_obs[1], lane, normalize != 0);
     }
     __syncthreads();
     const uint32_t wave_off = blockIdx.x * kWaveObsBytes;
@@ -517,7 +612,9 @@ static int check_common(const void* state, int64_t n, int64_t stride, const pz_c
 {
     if (state == nullptr || cfg == nullptr) return PZ_E_NULL;
     if (n < 0 || stride < n || stride > kMaxLanesPerLaunch) return PZ_E_SIZE;
-    if (cfg->winning_score < 1 || cfg->serve_mode < 0 || cfg->serve_mode > 2) return PZ_E_CONFIG;
+    if (cfg->winning_score < 1 || cfg->serve_mode < 0 || cfg->serve_mode > 2 || cfg->normal_state_mode < 0 ||
+        cfg->normal_state_mode > 2 || cfg->episode_stats_mode < 0 || cfg->episode_stats_mode > 2)
+        return PZ_E_CONFIG;
     return PZ_OK;
 }
 
@@ -582,57 +679,59 @@ int pz_init(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, voi
 }
 
 int pz_reset(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, const uint8_t* mask, int32_t* obs_p1,
-             int32_t* obs_p2, void* stream)
+             int32_t* obs_p2, int32_t* episode_stats, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
     hipLaunchKernelGGL(reset_kernel, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, state, n,
-                       stride, *cfg, mask, obs_p1, obs_p2);
+                       stride, *cfg, mask, obs_p1, obs_p2, episode_stats);
     return (int)hipGetLastError();
 }
 
-int pz_observe(const int32_t* state, int64_t n, int64_t stride, int32_t* obs_p1, int32_t* obs_p2, void* stream)
+int pz_observe(const int32_t* state, int64_t n, int64_t stride, int32_t normalize, int32_t* obs_p1, int32_t* obs_p2,
+               void* stream)
 {
     if (state == nullptr) return PZ_E_NULL;
     if (n < 0 || stride < n || stride > kMaxLanesPerLaunch) return PZ_E_SIZE;
     if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
     hipLaunchKernelGGL(observe_kernel, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, state, n,
-                       stride, obs_p1, obs_p2);
+                       stride, (int)normalize, obs_p1, obs_p2);
     return (int)hipGetLastError();
 }
 
 int pz_step(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, const int32_t* act_p1,
             const int32_t* act_p2, int32_t* obs_p1, int32_t* obs_p2, void* rew_p1, void* rew_p2, uint8_t* terminated,
-            void* stream)
+            int32_t* episode_stats, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (!act_p1 || !act_p2 || !obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
     if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
-    StepArgs a{state,  n,      stride,     act_p1,  act_p2, 0, 0, 1, nullptr, obs_p1, obs_p2, rew_p1,
-               rew_p2, terminated, nullptr, *cfg};
+    StepArgs a{state,  n,          stride,        act_p1,  act_p2, 0, 0, 1, nullptr, obs_p1, obs_p2, rew_p1,
+               rew_p2, terminated, episode_stats, nullptr, *cfg};
     return launch_step<kActions>(a, (hipStream_t)stream);
 }
 
 int pz_step_random(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, uint64_t action_seed, uint64_t t0,
                    int32_t k, int32_t* obs_p1, int32_t* obs_p2, void* rew_p1, void* rew_p2, uint8_t* terminated,
-                   int64_t* episodes_done, void* stream)
+                   int32_t* episode_stats, int64_t* episodes_done, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (!obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
     if (k < 1) return PZ_E_SIZE;
     if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
-    StepArgs a{state,  n,          stride, nullptr, nullptr, action_seed, t0, k, nullptr, obs_p1, obs_p2, rew_p1,
-               rew_p2, terminated, reinterpret_cast<unsigned long long*>(episodes_done), *cfg};
+    StepArgs a{state,  n,          stride,        nullptr, nullptr, action_seed, t0, k, nullptr, obs_p1, obs_p2, rew_p1,
+               rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), *cfg};
     return launch_step<kRandom>(a, (hipStream_t)stream);
 }
 
 int pz_rollout_random(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, uint64_t action_seed,
                       uint64_t t0, int32_t k, int32_t* actions, int32_t* obs_p1, int32_t* obs_p2, void* rew_p1,
-                      void* rew_p2, uint8_t* terminated, int64_t* episodes_done, void* stream)
+                      void* rew_p2, uint8_t* terminated, int32_t* episode_stats, int64_t* episodes_done,
+                      void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (!obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
@@ -640,8 +739,8 @@ int pz_rollout_random(int32_t* state, int64_t n, int64_t stride, const pz_config
     // every frame's [n][35] slab must keep the 16-byte alignment of the vector stores: n * 140 % 16 == 0
     if (misaligned16(obs_p1) || misaligned16(obs_p2) || (k > 1 && (n & 3) != 0)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
-    StepArgs a{state,  n,          stride, nullptr, nullptr, action_seed, t0, k, actions, obs_p1, obs_p2, rew_p1,
-               rew_p2, terminated, reinterpret_cast<unsigned long long*>(episodes_done), *cfg};
+    StepArgs a{state,  n,          stride,        nullptr, nullptr, action_seed, t0, k, actions, obs_p1, obs_p2, rew_p1,
+               rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), *cfg};
     return launch_step<kRollout>(a, (hipStream_t)stream);
 }
 

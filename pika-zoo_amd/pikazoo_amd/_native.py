@@ -11,7 +11,7 @@ from pathlib import Path
 PKG_ROOT = Path(__file__).resolve().parent.parent  # .../pika-zoo_amd
 LIB_PATH = PKG_ROOT / "lib" / "libpikazoo_hip.so"
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 STATE_WORDS = 44
 OBS_DIM = 35
 SERVE_MODES = {"winner": 0, "alternate": 1, "random": 2}
@@ -33,6 +33,10 @@ class PzConfig(C.Structure):
         ("additional_reward", C.c_float * 8),
         ("auto_reset", C.c_int32),
         ("reserved", C.c_int32),
+        ("normal_state_mode", C.c_int32),
+        ("normal_state_reward", C.c_float),
+        ("normalize_obs", C.c_int32),
+        ("episode_stats_mode", C.c_int32),
         ("seed", C.c_uint64),
         ("env_id_base", C.c_int64),
     ]
@@ -51,13 +55,13 @@ _SIGNATURES = {
     "pz_config_bytes": (C.c_int, []),
     "pz_error_string": (C.c_char_p, [C.c_int]),
     "pz_init": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P]),
-    "pz_reset": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, _P, _P, _P]),
-    "pz_observe": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P]),
-    "pz_step": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pz_reset": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, _P, _P, _P, _P]),
+    "pz_observe": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, _P, _P, _P]),
+    "pz_step": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pz_step_random": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), C.c_uint64, C.c_uint64,
-                                 C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
+                                 C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pz_rollout_random": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), C.c_uint64, C.c_uint64,
-                                    C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                    C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pz_random_actions": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _P]),
     "pz_selftest_predictor": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
 }

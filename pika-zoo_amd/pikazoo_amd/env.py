@@ -121,6 +121,7 @@ class raw_env:
         self._term = self._term_u8.view(torch.bool)
         self._trunc = torch.zeros(n, dtype=torch.bool, device=dev)  # always False (pikazoo_env.py:234)
         self._episodes = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._stats = None  # RecordEpisodeStatistics words [3, n], allocated when the wrapper is fused
         self._scores = self.state[_E_SCORE_P1:_E_SCORE_P1 + 2].t()  # live [n, 2] view of the state
         self.steps_done = 0  # frames stepped by this env (per lane)
 
@@ -167,10 +168,50 @@ class raw_env:
         assert len(additional_reward) == 8  # reward_by_ball_position.py:15
         if self._cfg.ballpos_reward:
             raise NotImplementedError("only one RewardByBallPosition can be fused")
+        if self._cfg.normalize_obs:
+            raise NotImplementedError("apply RewardByBallPosition below NormalizeObservation (it reads raw "
+                                      "ball coordinates from the observation, reward_by_ball_position.py:22)")
+        if self._cfg.episode_stats_mode == 2:
+            raise NotImplementedError("RecordEpisodeStatistics between two reward wrappers cannot be fused")
         self._cfg.ballpos_reward = 1
         self._cfg.x_line, self._cfg.y_line = int(x_line), int(y_line)
         for i, v in enumerate(additional_reward):
             self._cfg.additional_reward[i] = float(v)
+
+    def _fuse_normal_state_reward(self, reward):
+        """wrappers/reward_in_normal_state.py:10-15 inside the kernel; remembers whether it was applied
+        before or after RewardByBallPosition (the reference's result depends on the wrapper order)."""
+        if self._cfg.normal_state_mode:
+            raise NotImplementedError("only one RewardInNormalState can be fused")
+        if self._cfg.episode_stats_mode == 2:  # statistics already sum a wrapped reward: one more on top
+            raise NotImplementedError("RecordEpisodeStatistics between two reward wrappers cannot be fused")
+        self._cfg.normal_state_mode = 2 if self._cfg.ballpos_reward else 1
+        self._cfg.normal_state_reward = float(reward)
+
+    def _fuse_normalize_obs(self):
+        """wrappers/normalize_observation.py:18-35 inside the kernel: observations become float32."""
+        if self._cfg.normalize_obs:
+            raise RuntimeError("NormalizeObservation is already applied")
+        self._cfg.normalize_obs = 1
+
+    def _fuse_episode_stats(self):
+        """wrappers/record_episode_statistics.py:27-40 inside the kernel (three words per game)."""
+        if self._cfg.episode_stats_mode:
+            raise RuntimeError("RecordEpisodeStatistics is already applied")
+        wrapped = bool(self._cfg.ballpos_reward or self._cfg.normal_state_mode)
+        self._cfg.episode_stats_mode = 2 if wrapped else 1
+        self._stats = torch.zeros((3, self.num_envs), dtype=torch.int32, device=self.device)
+
+    @property
+    def episode_returns(self) -> Optional[torch.Tensor]:
+        """``[2, num_envs]`` running episode returns (player_1, player_2), typed like the rewards."""
+        if self._stats is None:
+            return None
+        return self._stats[:2].view(torch.float32) if self.reward_dtype == torch.float32 else self._stats[:2]
+
+    @property
+    def episode_lengths(self) -> Optional[torch.Tensor]:
+        return None if self._stats is None else self._stats[2]
 
     @property
     def n_actions(self) -> int:
@@ -178,12 +219,23 @@ class raw_env:
 
     @property
     def reward_dtype(self):
-        return torch.float32 if self._cfg.ballpos_reward else torch.int32
+        return torch.float32 if (self._cfg.ballpos_reward or self._cfg.normal_state_mode) else torch.int32
+
+    @property
+    def obs_dtype(self):
+        return torch.float32 if self._cfg.normalize_obs else torch.int32
+
+    def _obs_view(self, i):
+        return self._obs[i] if not self._cfg.normalize_obs else self._obs[i].view(torch.float32)
 
     # ---- spaces (pikazoo_env.py:481-568) ----------------------------------------------------------
     @functools.lru_cache(maxsize=None)
     def observation_space(self, agent=None):
         return Box(low=OBS_LOW.copy(), high=OBS_HIGH.copy(), shape=(35,), dtype=np.int32)
+
+    @functools.lru_cache(maxsize=None)
+    def normalized_observation_space(self, agent=None):
+        return Box(low=0.0, high=1.0, shape=(35,), dtype=np.float32)  # normalize_observation.py:35
 
     def action_space(self, agent):
         return self.action_spaces[agent]
@@ -194,12 +246,22 @@ class raw_env:
         return [r if dt == torch.int32 else r.view(torch.float32) for r in self._rew_raw]
 
     def _infos(self):
-        return {a: {"score": self._scores} for a in self.agents}  # aliased like pikazoo_env.py:573-574
+        infos = {a: {"score": self._scores} for a in self.agents}  # aliased like pikazoo_env.py:573-574
+        if self._stats is not None:
+            # record_episode_statistics.py:34-39: {"r", "l"} of the episode that just ended; here per
+            # lane, meaningful where terminations[agent] is True (running sums elsewhere)
+            ret = self.episode_returns
+            for i, a in enumerate(self.agents):
+                infos[a]["episode"] = {"r": ret[i], "l": self._stats[2]}
+        return infos
 
     def _pack_obs(self):
         if self.scalar_api:
-            return {a: self._obs[i][0].cpu().numpy() for i, a in enumerate(self.possible_agents)}
-        return {a: self._obs[i] for i, a in enumerate(self.possible_agents)}
+            return {a: self._obs_view(i)[0].cpu().numpy() for i, a in enumerate(self.possible_agents)}
+        return {a: self._obs_view(i) for i, a in enumerate(self.possible_agents)}
+
+    def _stats_ptr(self):
+        return None if self._stats is None else self._stats.data_ptr()
 
     def _pack_step(self):
         rew = self._rewards()
@@ -212,8 +274,13 @@ class raw_env:
         ended = bool(self._term_u8.item())
         score = self._scores[0].tolist()
         agents = self.agents
+        infos = {a: {"score": score} for a in agents}
+        if self._stats is not None and ended:
+            ret = self.episode_returns
+            for i, a in enumerate(agents):
+                infos[a]["episode"] = {"r": ret[i][0].item(), "l": int(self._stats[2][0].item())}
         out = (self._pack_obs(), {a: rew[i][0].item() for i, a in enumerate(agents)},
-               {a: ended for a in agents}, {a: False for a in agents}, {a: {"score": score} for a in agents})
+               {a: ended for a in agents}, {a: False for a in agents}, infos)
         if ended and not self.auto_reset:
             self.agents = []  # pikazoo_env.py:237-238
         return out
@@ -233,7 +300,7 @@ class raw_env:
         with torch.cuda.device(self.device):
             _native.check(self._lib.pz_reset(self.state.data_ptr(), self.num_envs, self.num_envs, self._cfg_ref,
                                              _ptr(m), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
-                                             self._stream()), "pz_reset")
+                                             self._stats_ptr(), self._stream()), "pz_reset")
         if self.scalar_api:
             return self._pack_obs(), {a: {"score": self._scores[0].tolist()} for a in self.agents}
         return self._pack_obs(), self._infos()
@@ -273,8 +340,8 @@ class raw_env:
             _native.check(self._lib.pz_step(self.state.data_ptr(), self.num_envs, self.num_envs, self._cfg_ref,
                                             a1.data_ptr(), a2.data_ptr(), self._obs[0].data_ptr(),
                                             self._obs[1].data_ptr(), self._rew_raw[0].data_ptr(),
-                                            self._rew_raw[1].data_ptr(), self._term_u8.data_ptr(), self._stream()),
-                          "pz_step")
+                                            self._rew_raw[1].data_ptr(), self._term_u8.data_ptr(), self._stats_ptr(),
+                                            self._stream()), "pz_step")
         self.steps_done += 1
         return self._pack_step()
 
@@ -289,8 +356,8 @@ class raw_env:
                                                    self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0),
                                                    int(k), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
                                                    self._rew_raw[0].data_ptr(), self._rew_raw[1].data_ptr(),
-                                                   self._term_u8.data_ptr(), self._episodes.data_ptr(),
-                                                   self._stream()), "pz_step_random")
+                                                   self._term_u8.data_ptr(), self._stats_ptr(),
+                                                   self._episodes.data_ptr(), self._stream()), "pz_step_random")
         self.steps_done += int(k)
         return self._pack_step()
 
@@ -319,11 +386,12 @@ class raw_env:
                 self.state.data_ptr(), n, n, self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0), k,
                 out["actions"].data_ptr(), out["_obs"][0].data_ptr(), out["_obs"][1].data_ptr(),
                 out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(), out["_term"].data_ptr(),
-                self._episodes.data_ptr(), self._stream()), "pz_rollout_random")
+                self._stats_ptr(), self._episodes.data_ptr(), self._stream()), "pz_rollout_random")
         self.steps_done += k
         dt = self.reward_dtype
         rew = [r if dt == torch.int32 else r.view(torch.float32) for r in out["_rew"]]
-        out["obs"] = dict(zip(self.possible_agents, out["_obs"]))
+        odt = self.obs_dtype
+        out["obs"] = dict(zip(self.possible_agents, [o if odt == torch.int32 else o.view(odt) for o in out["_obs"]]))
         out["rewards"] = dict(zip(self.possible_agents, rew))
         out["terminations"] = out["_term"].view(torch.bool)
         # keep the single-frame views coherent with the last frame
@@ -351,9 +419,11 @@ class raw_env:
         o1 = torch.empty_like(self._obs[0])
         o2 = torch.empty_like(self._obs[1])
         with torch.cuda.device(self.device):
-            _native.check(self._lib.pz_observe(self.state.data_ptr(), self.num_envs, self.num_envs, o1.data_ptr(),
-                                               o2.data_ptr(), self._stream()), "pz_observe")
-        return {self.possible_agents[0]: o1, self.possible_agents[1]: o2}
+            _native.check(self._lib.pz_observe(self.state.data_ptr(), self.num_envs, self.num_envs,
+                                               int(self._cfg.normalize_obs), o1.data_ptr(), o2.data_ptr(),
+                                               self._stream()), "pz_observe")
+        odt = self.obs_dtype
+        return {self.possible_agents[0]: o1.view(odt), self.possible_agents[1]: o2.view(odt)}
 
     # ---- checkpoint = the state tensor --------------------------------------------------------------------
     def state_dict(self):

@@ -1,0 +1,28 @@
+"""RecordEpisodeStatistics (reference: pikazoo/wrappers/record_episode_statistics.py:9-40), fused.
+
+Per game the kernel keeps the running episode return of each agent and the episode length (three
+words next to the state, zeroed by ``reset`` and by the in-place auto reset).  On the frame a game
+terminates, ``infos[agent]["episode"] = {"r": return, "l": length}`` holds that episode's totals --
+batched: ``[num_envs]`` tensors that are meaningful on the lanes where ``terminations[agent]`` is
+True (``scalar_api`` envs get the reference's Python scalars, only on terminal steps).  The sums cover
+the rewards as seen at the wrapper's position in the stack (inside or outside the reward wrappers).
+"""
+from __future__ import annotations
+
+from .base import BaseParallelWrapper
+
+
+class RecordEpisodeStatistics(BaseParallelWrapper):
+    def __init__(self, env):
+        super().__init__(env)
+        env.unwrapped._fuse_episode_stats()
+
+    @property
+    def episode_rewards(self):
+        raw = self.env.unwrapped
+        return dict(zip(raw.possible_agents, raw.episode_returns))
+
+    @property
+    def episode_lengths(self):
+        raw = self.env.unwrapped
+        return {a: raw.episode_lengths for a in raw.possible_agents}

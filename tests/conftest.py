@@ -35,6 +35,8 @@ FULL_FIXTURES = [
     "cfg2_human_human", "cfg3_p2_computer", "p1_computer", "both_computer", "serve_alternate",
     "serve_random", "winning_score_1", "winning_score_3", "cfg5_wrappers_float",
     "wrappers_int_table", "simplify_only",
+    "normal_state_only", "normal_state_inside_ballpos", "normal_state_outside_ballpos",
+    "normalize_observation", "record_stats_raw", "full_wrapper_stack",
 ]
 DIGEST_FIXTURES = ["digest_human_human", "digest_p2_computer", "digest_both_computer_random_serve"]
 
@@ -46,19 +48,36 @@ def golden_state(d, t):
     return st
 
 
+def fused_options_from_meta(meta):
+    """Fused-kernel options equivalent to the fixture's reference wrapper stack."""
+    from oracle.ref_capture import fused_options
+
+    return fused_options(meta["wrappers"])
+
+
+def apply_product_wrappers(env, wrappers):
+    """Wrap a pikazoo_amd env with the same classes, in the same order, as the reference stack."""
+    import pikazoo_amd.wrappers as W
+    from oracle.ref_capture import wrapper_stack
+
+    for name, kw in wrapper_stack(wrappers):
+        kw = dict(kw)
+        if "additional_reward" in kw:
+            kw["additional_reward"] = tuple(kw["additional_reward"])
+        env = getattr(W, name)(env, **kw)
+    return env
+
+
 def oracle_config_from_meta(meta, **over):
     from oracle import pz_oracle as po
 
     kw = dict(meta["env_kwargs"])
-    wr = meta["wrappers"] or {}
+    opt = fused_options_from_meta(meta)
     args = dict(
         winning_score=kw.get("winning_score", 15), serve=kw.get("serve", "winner"),
         is_player1_computer=kw.get("is_player1_computer", False),
         is_player2_computer=kw.get("is_player2_computer", False),
-        simplify_action=bool(wr.get("simplify_action")),
-        additional_reward=wr.get("additional_reward"), x_line=wr.get("x_line", 216),
-        y_line=wr.get("y_line", 176), seed=meta["seed"], env_id_base=meta["env_id_base"],
-        auto_reset=True)
+        seed=meta["seed"], env_id_base=meta["env_id_base"], auto_reset=True, **opt)
     args.update(over)
     return po.make_config(**args)
 

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 
     lib = C.CDLL(str(built_lib))
     names = header_functions()
-    assert len(names) >= 11
+    assert len(names) >= 13
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pikazoo_hip.h but not exported"
     assert sorted(_native.exported_names()) == names, "binding and header disagree"
@@ -43,8 +43,8 @@ def test_binding_matches_library_layout(built_lib):
     from pikazoo_amd import _native
 
     lib = _native.load()
-    assert lib.pz_abi_version() == 1 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
-    assert lib.pz_config_bytes() == C.sizeof(_native.PzConfig) == 88
+    assert lib.pz_abi_version() == 2 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
+    assert lib.pz_config_bytes() == C.sizeof(_native.PzConfig) == 104
     assert lib.pz_error_string(0) == b"ok" and b"NULL" in lib.pz_error_string(-1)
 
 

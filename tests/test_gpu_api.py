@@ -143,3 +143,85 @@ def test_wrappers_surface():
         RewardByBallPosition(pikazoo_v0.env(num_envs=2), additional_reward=(1, 2, 3))
     with pytest.raises(RuntimeError):
         SimplifyAction(env)
+
+
+def test_remaining_wrappers_surface():
+    """RewardInNormalState / NormalizeObservation / RecordEpisodeStatistics / ConvertSingleAgent: the
+    reference's class names and constructor signatures (pikazoo/wrappers/__init__.py:1-6)."""
+    from pikazoo_amd import pikazoo_v0
+    from pikazoo_amd.wrappers import (ConvertSingleAgent, NormalizeObservation, RecordEpisodeStatistics,
+                                      RewardByBallPosition, RewardInNormalState)
+
+    n = 2048
+    env = pikazoo_v0.env(num_envs=n, seed=2, winning_score=1)
+    env = RecordEpisodeStatistics(NormalizeObservation(RewardInNormalState(env, reward=-0.5)))
+    assert env.observation_space("player_1").dtype == np.float32 and env.observation_space("player_1").shape == (35,)
+    obs, infos = env.reset()
+    assert obs["player_1"].dtype == torch.float32 and float(obs["player_1"].min()) >= 0.0
+    raw = env.unwrapped
+    seen_done = 0
+    for t in range(300):
+        obs, rew, term, trunc, infos = env.step(raw.random_actions(5, t))
+        o = obs["player_1"]
+        # every column except the ball's y velocity (reference bound is only "observed") stays in [0, 1]
+        cols = [c for c in range(35) if c != 33]
+        assert float(o[:, cols].min()) >= 0.0 and float(o[:, cols].max()) <= 1.0
+        assert rew["player_1"].dtype == torch.float32
+        assert bool(((rew["player_1"] == -0.5) | (rew["player_1"].abs() == 1.0)).all())
+        ep = infos["player_1"]["episode"]
+        assert ep["l"].shape == (n,) and ep["r"].dtype == torch.float32
+        done = term["player_1"]
+        if bool(done.any()):
+            seen_done += int(done.sum())
+            # a winning_score=1 episode: l frames, all but the last paid -0.5, the last +-1
+            assert torch.allclose(ep["r"][done], (ep["l"][done] - 1).float() * -0.5 + rew["player_1"][done])
+    assert seen_done > 0
+    assert env.episode_lengths["player_1"].shape == (n,)
+
+    # order rules that cannot be fused are refused, not silently reinterpreted
+    with pytest.raises(NotImplementedError):
+        RewardByBallPosition(NormalizeObservation(pikazoo_v0.env(num_envs=4)), additional_reward=(0,) * 8)
+    with pytest.raises(NotImplementedError):
+        e = RecordEpisodeStatistics(RewardInNormalState(pikazoo_v0.env(num_envs=4), 0.1))
+        RewardByBallPosition(e, additional_reward=(0,) * 8)
+    with pytest.raises(RuntimeError):
+        NormalizeObservation(NormalizeObservation(pikazoo_v0.env(num_envs=4)))
+
+    # single-agent view: the other side plays the seeded device policy
+    single = ConvertSingleAgent(pikazoo_v0.env(num_envs=64, seed=4, winning_score=2), "player_2", opponent_seed=9)
+    o, info = single.reset()
+    assert o.shape == (64, 35) and "score" in info
+    twin = pikazoo_v0.env(num_envs=64, seed=4, winning_score=2)
+    twin.reset()
+    for t in range(100):
+        act = torch.full((64,), t % 18, dtype=torch.int32, device="cuda:0")
+        o, r, term, trunc, info = single.step(act)
+        other = twin.random_actions(9, t)["player_1"]
+        o2, r2, term2, _, _ = twin.step({"player_1": other, "player_2": act})
+        assert torch.equal(o, o2["player_2"]) and torch.equal(r, r2["player_2"]) and torch.equal(term, term2["player_2"])
+    with pytest.raises(AssertionError):
+        ConvertSingleAgent(twin, "player_3")
+
+
+def test_record_episode_statistics_scalar_api():
+    """record_episode_statistics.py:31-39 through the scalar API: the "episode" entry exists only on the
+    terminal step and carries the sums of that episode."""
+    from pikazoo_amd import pikazoo_v0
+    from pikazoo_amd.wrappers import RecordEpisodeStatistics
+
+    env = RecordEpisodeStatistics(pikazoo_v0.env(num_envs=1, scalar_api=True, auto_reset=False, winning_score=3,
+                                                 seed=21))
+    rng = np.random.default_rng(3)
+    for episode in range(3):
+        env.reset()
+        total, length = {"player_1": 0, "player_2": 0}, 0
+        while env.agents:
+            acts = {a: int(rng.integers(0, 18)) for a in env.agents}
+            obs, rew, term, trunc, infos = env.step(acts)
+            length += 1
+            for a in rew:
+                total[a] += rew[a]
+            assert ("episode" in infos["player_1"]) == term["player_1"]
+        assert infos["player_1"]["episode"] == {"r": total["player_1"], "l": length}
+        assert infos["player_2"]["episode"] == {"r": total["player_2"], "l": length}
+        assert abs(total["player_1"]) <= 3 and total["player_1"] == -total["player_2"]

@@ -21,8 +21,8 @@ pytestmark = pytest.mark.gpu
 
 
 def make_env(meta=None, **over):
+    from conftest import apply_product_wrappers
     from pikazoo_amd import pikazoo_v0
-    from pikazoo_amd.wrappers import RewardByBallPosition, SimplifyAction
 
     kw = dict(meta["env_kwargs"]) if meta else {}
     wr = (meta["wrappers"] or {}) if meta else {}
@@ -33,12 +33,7 @@ def make_env(meta=None, **over):
     kw.update(over)
     kw.setdefault("device", "cuda:0")
     kw.setdefault("validate_actions", False)
-    env = pikazoo_v0.env(**kw)
-    if wr.get("simplify_action"):
-        env = SimplifyAction(env)
-    if wr.get("additional_reward") is not None:
-        env = RewardByBallPosition(env, tuple(wr["additional_reward"]), wr.get("x_line", 216), wr.get("y_line", 176))
-    return env
+    return apply_product_wrappers(pikazoo_v0.env(**kw), wr)
 
 
 def cpu(t):
@@ -58,13 +53,17 @@ def test_hip_matches_reference_trajectory(name):
     assert np.array_equal(cpu(raw.state), d["state_ctor"])
     obs, infos = env.reset(seed=123)  # seed ignored like the reference
     assert np.array_equal(cpu(raw.state), d["state0"])
-    assert np.array_equal(cpu(obs["player_1"]), d["obs_reset"][:, 0])
-    assert np.array_equal(cpu(obs["player_2"]), d["obs_reset"][:, 1])
+    odt = np.float32 if raw.obs_dtype == torch.float32 else np.int32
+    assert np.array_equal(cpu(obs["player_1"]), d["obs_reset"][:, 0].astype(odt))
+    assert np.array_equal(cpu(obs["player_2"]), d["obs_reset"][:, 1].astype(odt))
 
     dev = raw.device
     acts = torch.as_tensor(d["actions"].astype(np.int32), device=dev)  # [T, 2, L]
     h_state = torch.empty((T, 44, L), dtype=torch.int32, device=dev)
-    h_obs = torch.empty((T, 2, L, 35), dtype=torch.int32, device=dev)
+    h_obs = torch.empty((T, 2, L, 35), dtype=raw.obs_dtype, device=dev)
+    has_stats = raw.episode_lengths is not None
+    h_epr = torch.zeros((T, 2, L), dtype=raw.reward_dtype, device=dev)
+    h_epl = torch.zeros((T, L), dtype=torch.int32, device=dev)
     h_rew = torch.empty((T, 2, L), dtype=raw.reward_dtype, device=dev)
     h_term = torch.empty((T, L), dtype=torch.bool, device=dev)
     for t in range(T):
@@ -76,6 +75,10 @@ def test_hip_matches_reference_trajectory(name):
         h_rew[t, 1].copy_(rew["player_2"])
         h_term[t].copy_(term["player_1"])
         assert term["player_1"] is term["player_2"]
+        if has_stats:
+            h_epr[t, 0].copy_(infos["player_1"]["episode"]["r"])
+            h_epr[t, 1].copy_(infos["player_2"]["episode"]["r"])
+            h_epl[t].copy_(infos["player_1"]["episode"]["l"])
     h_state, h_obs, h_rew, h_term = cpu(h_state), cpu(h_obs), cpu(h_rew), cpu(h_term)
     assert not cpu(trunc["player_1"]).any()
     for t in range(T):
@@ -83,7 +86,16 @@ def test_hip_matches_reference_trajectory(name):
         if not np.array_equal(h_state[t], st):
             f, l = np.argwhere(h_state[t] != st)[0]
             pytest.fail(f"{name}: step {t} lane {l} word {f}: hip {h_state[t][f, l]} != reference {st[f, l]}")
-    assert np.array_equal(h_obs, d["obs"].astype(np.int32).transpose(0, 1, 2, 3))
+    if raw.obs_dtype == torch.float32:  # NormalizeObservation: float32 rounding of the reference's double
+        assert np.array_equal(h_obs, d["obs"].astype(np.float32))
+    else:
+        assert np.array_equal(h_obs, d["obs"].astype(np.int32))
+    if has_stats:  # infos[agent]["episode"] = {"r", "l"} on terminal frames (record_episode_statistics.py:34-39)
+        done = d["ep_l"] >= 0
+        assert np.array_equal(done, d["term"].astype(bool))
+        assert np.array_equal(cpu(h_epl)[done], d["ep_l"][done])
+        for i in range(2):
+            np.testing.assert_allclose(cpu(h_epr)[:, i][done], d["ep_r"][:, i][done], rtol=0, atol=2e-4)
     assert np.array_equal(h_term.astype(np.uint8), d["term"])
     if raw.reward_dtype == torch.float32:
         np.testing.assert_allclose(h_rew, d["rew"], rtol=0, atol=1e-6)
@@ -122,6 +134,16 @@ CASES = {
     "cfg5_wrappers": dict(n=16384, steps=600, kw=dict(winning_score=15),
                           wr=dict(simplify_action=True,
                                   additional_reward=(0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01))),
+    "all_wrappers_fused": dict(n=8192, steps=500, kw=dict(winning_score=2, is_player2_computer=True),
+                               wr=dict(stack=[["SimplifyAction", {}], ["RewardInNormalState", dict(reward=-0.002)],
+                                              ["RewardByBallPosition",
+                                               dict(additional_reward=[0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01])],
+                                              ["NormalizeObservation", {}], ["RecordEpisodeStatistics", {}]])),
+    "stats_inside_normal_outside": dict(n=4096, steps=400, kw=dict(winning_score=1),
+                                        wr=dict(stack=[["RecordEpisodeStatistics", {}],
+                                                       ["RewardByBallPosition",
+                                                        dict(additional_reward=[1, -2, 3, -4, 5, -6, 7, -8])],
+                                                       ["RewardInNormalState", dict(reward=0.125)]])),
     "ws1_no_auto_reset": dict(n=2048, steps=500, kw=dict(winning_score=1, auto_reset=False)),
     "ragged_batch": dict(n=1000 + 37, steps=300, kw=dict(is_player2_computer=True, winning_score=3)),
 }
@@ -134,12 +156,12 @@ def test_hip_matches_oracle_random_batches(case, oracle):
     seed, base, aseed = 99, 12345, 4242
     env = make_env(num_envs=n, seed=seed, env_id_base=base, wrappers=wr, **kw)
     raw = env.unwrapped
+    from oracle.ref_capture import fused_options
     ocfg = oracle.make_config(
         winning_score=kw.get("winning_score", 15), serve=kw.get("serve", "winner"),
         is_player1_computer=kw.get("is_player1_computer", False),
         is_player2_computer=kw.get("is_player2_computer", False),
-        simplify_action=bool(wr.get("simplify_action")), additional_reward=wr.get("additional_reward"),
-        auto_reset=kw.get("auto_reset", True), seed=seed, env_id_base=base)
+        auto_reset=kw.get("auto_reset", True), seed=seed, env_id_base=base, **fused_options(wr))
     ref = oracle.OracleEnv(n, ocfg, nthreads=8)
     assert np.array_equal(cpu(raw.state), ref.state)
     obs, _ = env.reset()
@@ -165,6 +187,9 @@ def test_hip_matches_oracle_random_batches(case, oracle):
             assert np.array_equal(cpu(rew["player_2"]), rrew[1]), (case, t)
             assert np.array_equal(cpu(term["player_1"]).astype(np.uint8), rterm), (case, t)
             assert np.array_equal(cpu(infos["player_1"]["score"]), ref.state[38:40].T)
+            if ref.stats is not None:  # bit-exact, fp32 sums included (same order of the same adds)
+                assert np.array_equal(cpu(raw._stats), ref.stats), (case, t)
+                assert np.array_equal(cpu(infos["player_2"]["episode"]["l"]), ref.episode_lengths)
     assert ref.state[43].min() >= 4  # draws happened
 
 
@@ -287,10 +312,11 @@ def test_stride_larger_than_n_and_error_codes(oracle):
     term = torch.zeros(n, dtype=torch.uint8, device=dev)
     s = torch.cuda.current_stream().cuda_stream
     assert lib.pz_init(state.data_ptr(), n, stride, C.byref(cfg), s) == 0
-    assert lib.pz_reset(state.data_ptr(), n, stride, C.byref(cfg), None, obs1.data_ptr(), obs2.data_ptr(), s) == 0
+    assert lib.pz_reset(state.data_ptr(), n, stride, C.byref(cfg), None, obs1.data_ptr(), obs2.data_ptr(), None, s) == 0
     for t in range(100):
         assert lib.pz_step_random(state.data_ptr(), n, stride, C.byref(cfg), 11, t, 1, obs1.data_ptr(),
-                                  obs2.data_ptr(), rew1.data_ptr(), rew2.data_ptr(), term.data_ptr(), None, s) == 0
+                                  obs2.data_ptr(), rew1.data_ptr(), rew2.data_ptr(), term.data_ptr(), None, None,
+                                  s) == 0
     torch.cuda.synchronize()
     assert bool((state[:, n:] == -7).all()), "columns beyond n must not be touched"
     ref = oracle.OracleEnv(n, oracle.make_config(winning_score=2, is_player2_computer=True, seed=77, env_id_base=9))
@@ -305,8 +331,11 @@ def test_stride_larger_than_n_and_error_codes(oracle):
     assert lib.pz_init(state.data_ptr(), n, stride, C.byref(cfg), s) == -3
     cfg.winning_score = 2
     assert lib.pz_step_random(state.data_ptr(), n, stride, C.byref(cfg), 11, 0, 0, obs1.data_ptr(), obs2.data_ptr(),
-                              rew1.data_ptr(), rew2.data_ptr(), term.data_ptr(), None, s) == -2
-    assert lib.pz_observe(state.data_ptr(), n, stride, obs1.data_ptr() + 4, obs2.data_ptr(), s) == -4
+                              rew1.data_ptr(), rew2.data_ptr(), term.data_ptr(), None, None, s) == -2
+    assert lib.pz_observe(state.data_ptr(), n, stride, 0, obs1.data_ptr() + 4, obs2.data_ptr(), s) == -4
+    cfg.normal_state_mode = 3
+    assert lib.pz_init(state.data_ptr(), n, stride, C.byref(cfg), s) == -3
+    cfg.normal_state_mode = 0
     assert lib.pz_init(state.data_ptr(), 0, stride, C.byref(cfg), s) == 0  # empty batch is a no-op
     assert b"aligned" in lib.pz_error_string(-4)
 
@@ -444,11 +473,11 @@ def test_rollout_random_equals_stepwise(kw, wr, oracle):
     assert a.unwrapped.steps_done == b.unwrapped.steps_done == k * rounds
     assert a.unwrapped.episodes_done == int(sum(0 for _ in ())) + a.unwrapped.episodes_done  # counter readable
     # and against the oracle at the end
+    from oracle.ref_capture import fused_options
     ocfg = oracle.make_config(
         winning_score=kw.get("winning_score", 15), serve=kw.get("serve", "winner"),
         is_player1_computer=kw.get("is_player1_computer", False),
-        is_player2_computer=kw.get("is_player2_computer", False), simplify_action=bool(wr.get("simplify_action")),
-        additional_reward=wr.get("additional_reward"), seed=6, env_id_base=300)
+        is_player2_computer=kw.get("is_player2_computer", False), seed=6, env_id_base=300, **fused_options(wr))
     ref = oracle.OracleEnv(n, ocfg, nthreads=8)
     ref.reset()
     eps = ref.rollout_random(aseed, 0, k * rounds)

@@ -54,8 +54,8 @@ def main():
     for nm in names:
         lib = C.CDLL(str(LIBDIR / f"ab_{nm}.so"))
         lib.pz_init.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P]
-        lib.pz_reset.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P]
-        lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P]
+        lib.pz_reset.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P]
+        lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P, P]
         libs[nm] = lib
     cfg = _native.PzConfig()
     cfg.winning_score, cfg.auto_reset, cfg.seed, cfg.p2_computer = 15, 1, 0, int(ai)
@@ -71,13 +71,13 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     base = libs["base"]
     assert base.pz_init(state.data_ptr(), n, n, C.byref(cfg), stream) == 0
-    assert base.pz_reset(state.data_ptr(), n, n, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(), stream) == 0
+    assert base.pz_reset(state.data_ptr(), n, n, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(), None, stream) == 0
 
     def run(lib, steps):
         for t in range(steps):
             a = acts[t % 64]
             lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
-                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), stream)
+                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), None, stream)
 
     run(base, 700)
     snapshot = state.clone()

@@ -35,8 +35,8 @@ def main():
     lib = C.CDLL(str(LIB))
     P = C.c_void_p
     lib.pz_init.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P]
-    lib.pz_reset.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P]
-    lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P]
+    lib.pz_reset.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P]
+    lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P, P]
     lib.pz_debug_read_stamps.argtypes = [P, C.c_int64]
     dev = torch.device("cuda:0")
     cfg = _native.PzConfig()
@@ -48,13 +48,13 @@ def main():
     acts = torch.randint(0, 18, (64, 2, n), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     lib.pz_init(state.data_ptr(), n, n, C.byref(cfg), stream)
-    lib.pz_reset(state.data_ptr(), n, n, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(), stream)
+    lib.pz_reset(state.data_ptr(), n, n, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(), None, stream)
 
     def run(steps):
         for t in range(steps):
             a = acts[t % 64]
             lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
-                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), stream)
+                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), None, stream)
 
     run(800)
     torch.cuda.synchronize()
