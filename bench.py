@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on CPU baseline threads")
     ap.add_argument("--check-lanes", type=int, default=2048, help="lanes replayed on the CPU oracle for parity")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dist-backend", default=None,
+                    help="torch.distributed backend (default nccl = RCCL). 'gloo' + PZ_BENCH_ONE_DEVICE=1 rehearses "
+                         "the N>1 path with every rank on cuda:0 of a 1-GPU box")
     ap.add_argument("--extra", action="store_true", help="also time configs 3 and 5 and report them under 'extra'")
     return ap.parse_args()
 
@@ -217,9 +220,10 @@ def measure(args, shard, device, p2_computer, wrappers, launch, with_cpu):
     acts = pregenerate_actions(raw, total)
     torch.cuda.synchronize(device)
     wall, ev_ms = run_gpu(args, env, acts, args.warmup, args.steps, launch)
-    wall = dist.all_reduce_max(wall, device=device if shard.world_size > 1 else None)
+    cdev = device if (shard.world_size > 1 and args.dist_backend != "gloo") else None  # collectives' tensor device
+    wall = dist.all_reduce_max(wall, device=cdev)
     terminated_now = int(raw._term_u8.sum().item())
-    n_total, = dist.all_reduce_sum([raw.num_envs], device=device if shard.world_size > 1 else None)
+    n_total, = dist.all_reduce_sum([raw.num_envs], device=cdev)
     res = {
         "wall_s": wall, "event_ms": ev_ms, "n_total": n_total,
         "value": n_total * args.steps / wall,
@@ -270,7 +274,9 @@ def load_traffic(workload_key):
 
 def main():
     args = parse_args()
-    rank, world, local_rank = dist.init_from_env()
+    rank, world, local_rank = dist.init_from_env(args.dist_backend)
+    if os.environ.get("PZ_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")

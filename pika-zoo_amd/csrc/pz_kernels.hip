@@ -22,10 +22,18 @@
 
 namespace pz {
 
-constexpr int kLanes = 64;  // lanes (games) per workgroup = one wavefront
+constexpr int kLanes = PZ_WAVE_GAMES;  // lanes (games) per workgroup = one wavefront
 constexpr uint32_t kRowBytes = PZ_OBS_DIM * 4;            // 140
 constexpr uint32_t kWaveObsBytes = kLanes * kRowBytes;    // 8 960: a wave's rows are contiguous
 constexpr int kWaveObsVecs = (int)(kWaveObsBytes / 16);   // 560 16-byte pieces
+
+// cache-policy bits of the stores (aux operand: 1 = sc0, 2 = nt, 16 = sc1); tools/ab.py variants
+#ifndef PZ_STATE_AUX
+#define PZ_STATE_AUX 0
+#endif
+#ifndef PZ_OBS_AUX
+#define PZ_OBS_AUX 2  // observations are written once and not re-read by the step chain: nt, -2.4 % per launch
+#endif
 
 using Rsrc = __amdgpu_buffer_rsrc_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -47,7 +55,7 @@ struct StateIO {
     }
     __device__ __forceinline__ void st(int col, int v) const
     {
-        __builtin_amdgcn_raw_buffer_store_b32((unsigned int)v, rsrc, voff, (uint32_t)col * pitch, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned int)v, rsrc, voff, (uint32_t)col * pitch, PZ_STATE_AUX);
     }
 };
 
@@ -290,7 +298,8 @@ __device__ __forceinline__ void flush_rows(const int32_t* __restrict__ lds, Rsrc
 #pragma unroll
     for (int pass = 0; pass < (kWaveObsVecs + kLanes - 1) / kLanes; ++pass) {
         const int v = pass * kLanes + lane;
-        if (v < kWaveObsVecs) __builtin_amdgcn_raw_buffer_store_b128(src4[v], obs, (uint32_t)v * 16u, wave_off, 0);
+        if (v < kWaveObsVecs)
+            __builtin_amdgcn_raw_buffer_store_b128(src4[v], obs, (uint32_t)v * 16u, wave_off, PZ_OBS_AUX);
     }
 }
 
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
     if (a.episodes_done != nullptr) {
         // one atomic per wave: reduce the per-lane counts across the wavefront first
         unsigned int total = finished;
-        for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off, kLanes);
+        for (int off = kLanes / 2; off > 0; off >>= 1) total += __shfl_down(total, off, kLanes);
         if (lane == 0 && total != 0) atomicAdd(a.episodes_done, (unsigned long long)total);
     }
 }

@@ -14,6 +14,11 @@
 
 #include "pikazoo_hip.h"
 
+// games (active lanes) per workgroup; 64 = a full wavefront (tools/ab.py builds a 32 variant)
+#ifndef PZ_WAVE_GAMES
+#define PZ_WAVE_GAMES 64
+#endif
+
 namespace pz {
 
 // timing-only ablation hooks (tools/ablate.py builds with -DPZ_ABLATE; never defined in the product)
@@ -326,9 +331,17 @@ __device__ __forceinline__ int predict_landing_x_iterative(int x, int y, int xv,
 // with the exact integer conditions above; a failed verification falls back to the single
 // iteration, so the result is identical to the iterative form by construction.
 // pz_selftest_predictor compares the two over the whole input domain on the GPU.
+// 24-bit multiplies (full-rate v_mul_i32_i24 / v_mad_i32_i24; every operand here is far below 2^23)
+__device__ __forceinline__ int mul24(int a, int b)
+{
+    int r;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ int flight_height(int y, int yv, int m)
 {
-    return y + __mul24(m, yv) + (__mul24(m, m - 1) >> 1);
+    return y + mul24(m, yv) + (mul24(m, m - 1) >> 1);
 }
 
 template <bool FULL_NET>
@@ -352,18 +365,19 @@ __device__ __forceinline__ int predict_landing_x(int x, int y, int xv, int yv)
         const int toward_box = (rightward ? left : right) ? 1 : 0;  // outside and heading for the box
         const float q = (float)room * __builtin_amdgcn_rcpf((float)axv);
         const int kx = (axv ? (int)q : kLoopLimit) + toward_box;
-        // plain moves available along y: far root of Y(K) = ymax (NaN -> 0 when y > ymax) ...
+        // plain moves available along y: far root of Y(K) = ymax (y > ymax is rejected by `ok`) ...
+        // ... or, if the apex Y(-yv) would be above the ceiling, the near root of Y(K) = 0 (which
+        // comes first); one square root serves either: K = (s*sqrt(hb^2 + 8c) - hb) / 2
         const float hb = (float)(2 * yv - 1);
-        const float hb2 = hb * hb;
-        int K = (int)((__builtin_amdgcn_sqrtf(hb2 + 8.0f * (float)(ymax - y)) - hb) * 0.5f - 0.001f);
-        // ... and, if the apex Y(-yv) would be above the ceiling, the near root of Y(K) = 0
-        const int apex = y - (__mul24(yv, yv - 1) >> 1);
-        const int kc = (int)((-hb - __builtin_amdgcn_sqrtf(fmaxf(hb2 - 8.0f * (float)y, 0.0f))) * 0.5f - 0.001f);
-        K = (yv < 0 && apex < 0) ? min(K, kc) : K;
+        const int apex = y - (mul24(yv, yv - 1) >> 1);
+        const bool to_ceiling = (yv < 0) & (apex < 0);
+        const float c8 = 8.0f * (float)(to_ceiling ? -y : ymax - y);
+        const float root = __builtin_amdgcn_sqrtf(fmaxf(fmaf(hb, hb, c8), 0.0f));
+        int K = (int)(((to_ceiling ? -root : root) - hb) * 0.5f - 0.001f);
         K = min(min(K, kx), kLoopLimit - 2 - count);
         // exact verification
         const int ye = flight_height(y, yv, K);
-        const int xe = x + __mul24(K, xv);
+        const int xe = x + mul24(K, xv);
         const int xl = xe - xv;  // X(K-1): must still be on the same side of the box when outside
         const int lowest = flight_height(y, yv, min(max(-yv, 1), K));
         const bool side_kept = left ? xl <= kBoxLeft : (right ? xl >= kBoxRight : true);
@@ -481,7 +495,7 @@ __device__ __forceinline__ void wave_power_hit_candidates(bool need, const Ball&
     }
     __syncthreads();
     const int items = deciders * 6;
-    for (int first = 0; first < items; first += 64) {
+    for (int first = 0; first < items; first += PZ_WAVE_GAMES) {
         const int item = first + lane;
         if (item < items) {
             const int r = item / 6, c = item - 6 * r;

@@ -495,3 +495,27 @@ def test_rollout_argument_checks():
         env.unwrapped.rollout_random(1, 2)
     out = env.unwrapped.rollout_random(1, 1)  # a single frame has no alignment constraint
     assert out["obs"]["player_1"].shape == (1, 6, 35)
+
+
+# ------------------------------------------------------------------------------------------------
+# 7. long runs against the oracle (rare branches: double collisions, net-top bounces, long flights)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kw", [
+    dict(winning_score=15),
+    dict(winning_score=15, is_player2_computer=True),
+    dict(winning_score=4, is_player1_computer=True, is_player2_computer=True, serve="alternate"),
+])
+def test_long_run_digests_vs_oracle(kw, oracle):
+    """4 096 games x 20 000 frames (8.2e7 game-steps per config), state digest compared every 2 000 frames."""
+    n, chunk, chunks = 4096, 2000, 10
+    env = make_env(num_envs=n, seed=77, env_id_base=1 << 20, **kw)
+    env.reset()
+    ref = oracle.OracleEnv(n, oracle.make_config(seed=77, env_id_base=1 << 20, **kw), nthreads=8)
+    ref.reset()
+    eps = 0
+    for c in range(chunks):
+        env.unwrapped.step_random(5, t0=c * chunk, k=chunk)
+        eps += ref.rollout_random(5, c * chunk, chunk)
+        assert oracle.digest(cpu(env.unwrapped.state)) == ref.digest(), f"after {(c + 1) * chunk} frames"
+    assert np.array_equal(cpu(env.unwrapped.state), ref.state)
+    assert env.unwrapped.episodes_done == eps and eps > 0
