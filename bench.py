@@ -298,6 +298,15 @@ def main():
             r = measure(args, shard, device, ai, wr, args.launch, with_cpu=False)
             extra[key] = {"value": r["value"], "launch_us": r["launch_us"]}
         extra["rollout_k32"] = measure_rollout(args, shard, device, k=32)
+        # the same kernel at larger batches (more waves per SIMD hide each other's latency)
+        sweep = {}
+        for n_big in (262144, 524288, 1048576):
+            a2 = argparse.Namespace(**{**vars(args), "num_envs": n_big, "steps": 300, "warmup": 50})
+            r = measure(a2, dist.weak_shard(n_big, rank, world), device, False, False, "cabi", with_cpu=False)
+            gbps = BYTES_PER_ENV_STEP * n_big / (r["launch_us"] * 1e-6) / 1e9
+            sweep[str(n_big)] = {"value": r["value"], "launch_us": r["launch_us"], "achieved_GBps": gbps,
+                                 "frac_of_8TBps": gbps / HBM_PEAK_GBPS}
+        extra["batch_sweep_random_random"] = sweep
         for mode in ("cabi", "api"):
             r = measure(args, shard, device, args.p2_computer, args.wrappers, mode, with_cpu=False)
             extra[f"launch_{mode}"] = {"value": r["value"], "launch_us": r["launch_us"]}
