@@ -199,6 +199,14 @@ def cpu_baseline(args, raw_gpu, p2_computer, wrappers, total_steps):
     t0 = time.perf_counter()
     env1.rollout_random(ACTION_SEED, 0, 300)
     one_core = 4096 * 300 / (time.perf_counter() - t0)
+    # BASELINE.json configs[0]: ONE env, 10 000 steps, as the reference's own scalar loop would run it
+    env0 = po.OracleEnv(1, cfg(raw_gpu.env_id_base), nthreads=1)
+    env0.reset()
+    t0 = time.perf_counter()
+    for t in range(10000):
+        a1, a2 = po.random_actions(1, raw_gpu.env_id_base, ACTION_SEED, t, raw_gpu.n_actions)
+        env0.step(a1, a2)
+    one_env = 10000 / (time.perf_counter() - t0)
     # parity: replay the first check-lanes games for every step the GPU ran
     k = min(args.check_lanes, n)
     chk = po.OracleEnv(k, cfg(raw_gpu.env_id_base), nthreads=cores)
@@ -211,6 +219,7 @@ def cpu_baseline(args, raw_gpu, p2_computer, wrappers, total_steps):
         "sample": f"{n} games x {sample_steps} steps of the same workload, OpenMP static lane partition "
                   f"over {cores} threads ({t_spent:.1f} s)",
         "one_core_value": one_core,
+        "config1_one_env_steps_per_s": one_env,  # 1 game stepped call by call from Python (ctypes overhead-bound)
         "parity_lanes_checked": k, "parity_steps_checked": total_steps, "parity_bit_exact": parity,
     }
 

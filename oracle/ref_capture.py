@@ -377,6 +377,11 @@ FIXTURES += [
                  ["RecordEpisodeStatistics", {}]])),
 ]
 
+FIXTURES += [
+    # BASELINE.json configs[0]: one env, pikazoo_v0.env() defaults, random actions, 10 000 steps
+    ("cfg1_one_env_10k", 1, 10000, dict(), None),
+]
+
 DIGEST_RUNS = [
     ("digest_human_human", 48, 20000, dict(winning_score=15, serve="winner"), None),
     ("digest_p2_computer", 48, 20000, dict(winning_score=15, serve="winner", is_player2_computer=True), None),

@@ -36,7 +36,7 @@ FULL_FIXTURES = [
     "serve_random", "winning_score_1", "winning_score_3", "cfg5_wrappers_float",
     "wrappers_int_table", "simplify_only",
     "normal_state_only", "normal_state_inside_ballpos", "normal_state_outside_ballpos",
-    "normalize_observation", "record_stats_raw", "full_wrapper_stack",
+    "normalize_observation", "record_stats_raw", "full_wrapper_stack", "cfg1_one_env_10k",
 ]
 DIGEST_FIXTURES = ["digest_human_human", "digest_p2_computer", "digest_both_computer_random_serve"]
 
