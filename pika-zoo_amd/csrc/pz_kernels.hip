@@ -780,6 +780,10 @@ int pz_debug_read_stamps(unsigned long long* dst_host, int64_t count)
 {
     return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_pz_stamps), count * sizeof(unsigned long long));
 }
+int pz_debug_read_frame_stamps(unsigned long long* dst_host, int64_t count)
+{
+    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_pz_frame_stamps), count * sizeof(unsigned long long));
+}
 #endif
 
 }  // extern "C"

@@ -29,6 +29,21 @@ __device__ int g_pz_ablate_bits;
 #define PZ_ABLATE_SKIP(bit) false
 #endif
 
+// per-wave sub-phase stamps of the frame (tools/stamps.py builds with -DPZ_STAMPS; never in the product)
+#ifdef PZ_STAMPS
+__device__ unsigned long long g_pz_frame_stamps[8192 * 8];
+#define PZ_FRAME_STAMP(k)                                                                   \
+    do {                                                                                    \
+        if (blockIdx.x < 8192 && threadIdx.x == 0) {                                         \
+            unsigned long long t_;                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+            g_pz_frame_stamps[blockIdx.x * 8 + (k)] = t_;                                    \
+        }                                                                                   \
+    } while (0)
+#else
+#define PZ_FRAME_STAMP(k)
+#endif
+
 // pikazoo/env/physics.py:9-33
 constexpr int kGroundWidth = 432;
 constexpr int kGroundHalfWidth = 216;
@@ -236,6 +251,9 @@ __device__ __forceinline__ void reset_game(Game& g, const pz_config& cfg, const 
 // ---------------------------------------------------------------------------------------
 // Ball vs world (physics.py:359-436).  Returns true when the ball touches the ground.
 // ---------------------------------------------------------------------------------------
+// Written as selects, not branches: in a wave of 64 unsynchronised games every branch is taken
+// by some lane anyway, and a lone wave per SIMD pays an issue slot for every exec-mask
+// instruction around it (tools/stamps.py: the branchy form of this function cost 550 cycles).
 __device__ __forceinline__ bool ball_world_step(Ball& b)
 {
     b.ppx = b.px;
@@ -247,29 +265,27 @@ __device__ __forceinline__ bool ball_world_step(Ball& b)
     rot = rot < 0 ? rot + 50 : (rot > 50 ? rot - 50 : rot);
     b.rot = rot;
 
-    const int fx = b.x + b.xv;
-    if (fx < kBallRadius || fx > kGroundWidth) b.xv = -b.xv;  // asymmetric walls (:403)
-    if (b.y + b.yv < 0) b.yv = 1;
+    const int x = b.x, y = b.y;
+    int xv = b.xv, yv = b.yv;
+    const int fx = x + xv;
+    xv = ((unsigned)(fx - kBallRadius) > (unsigned)(kGroundWidth - kBallRadius)) ? -xv : xv;  // asymmetric walls (:403)
+    yv = (y + yv < 0) ? 1 : yv;
 
-    if (abs(b.x - kGroundHalfWidth) < kNetPillarHalfWidth && b.y > kNetTopTopY) {
-        if (b.y <= kNetTopBottomY) {
-            if (b.yv > 0) b.yv = -b.yv;
-        } else {
-            b.xv = (b.x < kGroundHalfWidth) ? -abs(b.xv) : abs(b.xv);
-        }
-    }
+    // net pillar (:411-419): above its top edge bounce the fall back, below it push sideways
+    const bool at_net = ((unsigned)(x - (kGroundHalfWidth - kNetPillarHalfWidth + 1)) <
+                         (unsigned)(2 * kNetPillarHalfWidth - 1)) & (y > kNetTopTopY);
+    const bool on_top = y <= kNetTopBottomY;
+    const int axv = abs(xv);
+    yv = (at_net & on_top & (yv > 0)) ? -yv : yv;
+    xv = (at_net & !on_top) ? ((x < kGroundHalfWidth) ? -axv : axv) : xv;
 
-    const int fy = b.y + b.yv;
+    const int fy = y + yv;
     const bool ground = fy > kBallGroundY;
-    if (ground) {
-        b.yv = -b.yv;
-        b.punch = b.x;
-        b.y = kBallGroundY;  // x is not advanced on the touching frame (:428-431)
-    } else {
-        b.y = fy;
-        b.x = b.x + b.xv;
-        b.yv += 1;
-    }
+    b.punch = ground ? x : b.punch;
+    b.y = ground ? kBallGroundY : fy;  // x is not advanced on the touching frame (:428-431)
+    b.x = ground ? x : x + xv;
+    b.yv = ground ? -yv : yv + 1;
+    b.xv = xv;
     return ground;
 }
 
@@ -549,71 +565,77 @@ __device__ __forceinline__ void player_move(Player& p, const Input& in)
     constexpr int kMinX = IS_P2 ? kGroundHalfWidth + kPlayerHalfLength : kPlayerHalfLength;
     constexpr int kMaxX = IS_P2 ? kGroundWidth - kPlayerHalfLength : kGroundHalfWidth - kPlayerHalfLength;
 
-    if (p.state == 4) {  // lying down after a dive: only the countdown runs (:458-462)
-        p.lying -= 1;
-        if (p.lying < -1) p.state = 0;
-        return;
-    }
+    // lying down after a dive: only the countdown runs (:458-462); computed for every lane and
+    // selected at the end (predication instead of an early return)
+    const bool lying = p.state == 4;
+    const int lie_count = p.lying - 1;
+    const int lie_state = (lie_count < -1) ? 0 : 4;
 
+    // x movement and clamp to the own half (:465-488)
     const int vx = (p.state < 3) ? in.xd * 6 : p.dive * 8;
-    p.x = min(max(p.x + vx, kMinX), kMaxX);
+    const int x = min(max(p.x + vx, kMinX), kMaxX);
 
-    if (p.state < 3 && in.yd == -1 && p.y == kPlayerGroundY) {  // jump
-        p.yv = -16;
-        p.state = 1;
-        p.frame = 0;
+    // jump (:491-499)
+    const bool jump = (p.state < 3) & (in.yd == -1) & (p.y == kPlayerGroundY);
+    int yv = jump ? -16 : p.yv;
+    int st = jump ? 1 : p.state;
+    int fr = jump ? 0 : p.frame;
+
+    // gravity / landing (:502-517)
+    const int fy = p.y + yv;
+    const bool air = fy < kPlayerGroundY, land = fy > kPlayerGroundY;
+    yv = air ? yv + 1 : (land ? 0 : yv);
+    const int y = land ? kPlayerGroundY : fy;
+    fr = land ? 0 : fr;
+    const bool dive_landed = land & (st == 3);
+    const int lying_left = dive_landed ? 3 : p.lying;
+    st = land ? (dive_landed ? 4 : 0) : st;
+
+    // power hit / dive trigger (:519-533)
+    const bool hit = in.hit == 1;
+    const bool power = hit & (st == 1);
+    const bool dive = hit & (st == 0) & (in.xd != 0);
+    int delay = power ? 5 : p.delay;
+    fr = (power | dive) ? 0 : fr;
+    st = power ? 2 : (dive ? 3 : st);
+    const int dive_dir = dive ? in.xd : p.dive;
+    yv = dive ? -5 : yv;
+
+    // animation frame machine (:535-552), one of three by state
+    int arm = p.arm;
+    {
+        // state 1: frame cycles 0,1,2
+        const int f1 = (fr + 1 >= 3) ? fr + 1 - 3 : fr + 1;  // frame is 0..2 here ((frame + 1) % 3)
+        // state 2: hold `delay` frames, then run frames 1..4 and fall back to state 1
+        const bool s2_advance = delay < 1;
+        const int f2n = fr + 1;
+        const bool s2_done = s2_advance & (f2n > 4);
+        const int f2 = s2_advance ? (s2_done ? 0 : f2n) : fr;
+        const int d2 = s2_advance ? delay : delay - 1;
+        // state 0: every 4th frame swing the arm 0..4..0
+        const int d0n = delay + 1;
+        const bool s0_tick = d0n > 3;
+        const int probe = fr + arm;
+        const int arm0 = (s0_tick & ((unsigned)probe > 4u)) ? -arm : arm;
+        const int f0 = s0_tick ? fr + arm0 : fr;
+        const int d0 = s0_tick ? 0 : d0n;
+
+        const bool is0 = st == 0, is1 = st == 1, is2 = st == 2;
+        fr = is1 ? f1 : (is2 ? f2 : (is0 ? f0 : fr));
+        delay = is2 ? d2 : (is0 ? d0 : delay);
+        arm = is0 ? arm0 : arm;
+        st = (is2 & s2_done) ? 1 : st;
     }
 
-    const int fy = p.y + p.yv;
-    p.y = fy;
-    if (fy < kPlayerGroundY) {
-        p.yv += 1;
-    } else if (fy > kPlayerGroundY) {  // landing
-        p.yv = 0;
-        p.y = kPlayerGroundY;
-        p.frame = 0;
-        if (p.state == 3) {
-            p.state = 4;
-            p.lying = 3;
-        } else {
-            p.state = 0;
-        }
-    }
-
-    if (in.hit == 1) {
-        if (p.state == 1) {  // power hit
-            p.delay = 5;
-            p.frame = 0;
-            p.state = 2;
-        } else if (p.state == 0 && in.xd != 0) {  // dive
-            p.state = 3;
-            p.frame = 0;
-            p.dive = in.xd;
-            p.yv = -5;
-        }
-    }
-
-    if (p.state == 1) {
-        p.frame = (int)((uint32_t)(p.frame + 1) % 3u);  // frame is never negative
-    } else if (p.state == 2) {
-        if (p.delay < 1) {
-            p.frame += 1;
-            if (p.frame > 4) {
-                p.frame = 0;
-                p.state = 1;
-            }
-        } else {
-            p.delay -= 1;
-        }
-    } else if (p.state == 0) {
-        p.delay += 1;
-        if (p.delay > 3) {
-            p.delay = 0;
-            const int f = p.frame + p.arm;
-            if (f < 0 || f > 4) p.arm = -p.arm;
-            p.frame = p.frame + p.arm;
-        }
-    }
+    p.x = lying ? p.x : x;
+    p.y = lying ? p.y : y;
+    p.yv = lying ? p.yv : yv;
+    p.state = lying ? lie_state : st;
+    p.frame = lying ? p.frame : fr;
+    p.arm = lying ? p.arm : arm;
+    p.delay = lying ? p.delay : delay;
+    p.dive = lying ? p.dive : dive_dir;
+    p.lying = lying ? lie_count : lying_left;
 }
 
 // is_collision_between_ball_and_player_happened (physics.py:340-356)
@@ -622,28 +644,29 @@ __device__ __forceinline__ bool ball_touches_player(const Ball& b, const Player&
     return abs(b.x - p.x) <= kPlayerHalfLength && abs(b.y - p.y) <= kPlayerHalfLength;
 }
 
-// process_collision_between_ball_and_player (physics.py:580-640)
-__device__ __forceinline__ void ball_player_collision(Ball& b, int player_x, const Input& in, int player_state,
-                                                      const RngId& id, uint32_t& rng)
+// process_collision_between_ball_and_player (physics.py:580-640), predicated on `hit` (this
+// player touches the ball and did not on the previous frame, physics.py:325-335).  Only the
+// tie-break draw (:613) is a real branch: it is rare and ticks the RNG.
+__device__ __forceinline__ void ball_player_collision(Ball& b, bool hit, int player_x, const Input& in,
+                                                      int player_state, const RngId& id, uint32_t& rng)
 {
     const int d = b.x - player_x;
-    if (d < 0)
-        b.xv = -((-d) / 3);
-    else if (d > 0)
-        b.xv = d / 3;
-    if (b.xv == 0) b.xv = rng_integers(id, rng, 3u) - 1;  // :613
+    const int third = (int)((unsigned)abs(d) / 3u);
+    int xv = (d < 0) ? -third : ((d > 0) ? third : b.xv);
+    if (hit & (xv == 0)) xv = rng_integers(id, rng, 3u) - 1;  // :613
 
     const int ayv = abs(b.yv);
-    b.yv = ayv < 15 ? -15 : -ayv;
+    int yv = ayv < 15 ? -15 : -ayv;
 
-    if (player_state == 2) {  // jumping and power hitting
-        b.xv = (b.x < kGroundHalfWidth) ? (abs(in.xd) + 1) * 10 : -(abs(in.xd) + 1) * 10;
-        b.punch = b.x;
-        b.yv = abs(b.yv) * in.yd * 2;
-        b.power = 1;
-    } else {
-        b.power = 0;
-    }
+    const bool power = player_state == 2;  // jumping and power hitting
+    const int pxv = (abs(in.xd) + 1) * 10;
+    xv = power ? ((b.x < kGroundHalfWidth) ? pxv : -pxv) : xv;
+    yv = power ? abs(yv) * in.yd * 2 : yv;
+
+    b.xv = hit ? xv : b.xv;
+    b.yv = hit ? yv : b.yv;
+    b.punch = (hit & power) ? b.x : b.punch;
+    b.power = hit ? (int)power : b.power;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -665,6 +688,7 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
     const bool active = live && !frozen;
     Input in1{0, 0, 0}, in2{0, 0, 0};
     bool ground = false;
+    PZ_FRAME_STAMP(0);
     if (active) {
         if (g.e.round_ended) {  // game_ended implies round_ended
             if (g.e.game_ended) {
@@ -676,6 +700,7 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
             g.e.round_ended = 0;
             start_round(g, cfg, id);
         }
+        PZ_FRAME_STAMP(1);
 
         // :182-184 -- every player's key state is sampled, computer-controlled or not
         if (cfg.simplify_action) {
@@ -686,8 +711,10 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
             in2 = decode_action(kFullTables, a2, g.p2.hitprev);
         }
 
+        PZ_FRAME_STAMP(2);
         // physics_engine
         ground = ball_world_step(g.b);
+        PZ_FRAME_STAMP(3);
 
         if (AI1 || AI2) {
             // :314-315 recomputes the landing point before each player; the ball does not move
@@ -704,6 +731,7 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
         computer_decide_finish<false>(hs, ex, g.p1, g.p2, in1);
     }
     if (active) player_move<false>(g.p1, in1);
+    PZ_FRAME_STAMP(4);
     if (AI2) {
         HitScan hs{false, false};
         int ex[6] = {0, 0, 0, 0, 0, 0};
@@ -715,46 +743,33 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
     int reward = 0;
     if (active) {
         player_move<true>(g.p2, in2);
+        PZ_FRAME_STAMP(5);
 
-        bool hit_processed = false;
-        {
-            const bool touch = ball_touches_player(g.b, g.p1);
-            if (touch && !g.p1.coll) {
-                ball_player_collision(g.b, g.p1.x, in1, g.p1.state, id, g.e.rng);
-                hit_processed = true;
-            }
-            g.p1.coll = touch;
-        }
-        {
-            const bool touch = ball_touches_player(g.b, g.p2);
-            if (touch && !g.p2.coll) {
-                ball_player_collision(g.b, g.p2.x, in2, g.p2.state, id, g.e.rng);
-                hit_processed = true;
-            }
-            g.p2.coll = touch;
-        }
+        // physics.py:319-335: player 1 first, then player 2 against the possibly changed velocities
+        const bool touch1 = ball_touches_player(g.b, g.p1), hit1 = touch1 & (g.p1.coll == 0);
+        ball_player_collision(g.b, hit1, g.p1.x, in1, g.p1.state, id, g.e.rng);
+        g.p1.coll = touch1;
+        const bool touch2 = ball_touches_player(g.b, g.p2), hit2 = touch2 & (g.p2.coll == 0);
+        ball_player_collision(g.b, hit2, g.p2.x, in2, g.p2.state, id, g.e.rng);
+        g.p2.coll = touch2;
+        const bool hit_processed = hit1 | hit2;
         if ((AI1 || AI2) && hit_processed) {
             // :331-332 -- when both players hit in one frame the second evaluation overwrites the
             // first, so a single one after both collisions leaves the same value.
             g.b.ex = PZ_ABLATE_SKIP(128) ? g.b.x : predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
         }
 
+        PZ_FRAME_STAMP(6);
         // scoring / round end / game end (:190-210); round_ended and game_ended are both 0 here
-        if (ground) {
-            if (g.b.punch < kGroundHalfWidth) {
-                g.e.p2serve = 1;
-                g.e.s2 += 1;
-                if (g.e.s2 >= cfg.winning_score) g.e.game_ended = 1;
-                reward = -1;
-            } else {
-                g.e.p2serve = 0;
-                g.e.s1 += 1;
-                if (g.e.s1 >= cfg.winning_score) g.e.game_ended = 1;
-                reward = 1;
-            }
-            g.e.round_ended = 1;
-        }
+        const bool p2_scores = ground & (g.b.punch < kGroundHalfWidth), p1_scores = ground & !p2_scores;
+        g.e.s1 += p1_scores;
+        g.e.s2 += p2_scores;
+        g.e.p2serve = ground ? (int)p2_scores : g.e.p2serve;
+        g.e.game_ended = ground & ((p2_scores ? g.e.s2 : g.e.s1) >= cfg.winning_score);
+        g.e.round_ended = ground;
+        reward = ground ? (p2_scores ? -1 : 1) : 0;
     }
+    PZ_FRAME_STAMP(7);
     return reward;
 }
 

@@ -74,6 +74,16 @@ def main():
             print(f"  {nm:22s} min {c.min():6.2f}  median {np.median(c):6.2f}  p95 {np.percentile(c, 95):6.2f}  max {c.max():6.2f}")
         d = np.diff(rel, axis=1)
         print("  per-wave phase durations (median): " + ", ".join(f"{names[k + 1]} {np.median(d[:, k]):.2f}" for k in range(6)))
+        fb = np.zeros(8192 * 8, np.uint64)
+        lib.pz_debug_read_frame_stamps.argtypes = [P, C.c_int64]
+        assert lib.pz_debug_read_frame_stamps(fb.ctypes.data, 8192 * 8) == 0
+        fs = fb.reshape(8192, 8)[:waves].astype(np.int64)
+        fd = np.diff(fs, axis=1)  # shader-clock cycles (s_memtime)
+        fnames = ["round start", "action decode", "ball-world", "AI1 + player 1", "AI2 + player 2", "collisions",
+                  "scoring"]
+        print("  frame sub-phases, shader cycles per wave (median / p95): " +
+              ", ".join(f"{fnames[k]} {int(np.median(fd[:, k]))}/{int(np.percentile(fd[:, k], 95))}" for k in range(7)) +
+              f"; whole frame {int(np.median(fs[:, 7] - fs[:, 0]))}")
 
 
 if __name__ == "__main__":
