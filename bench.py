@@ -284,8 +284,21 @@ def load_traffic(workload_key):
     return None
 
 
+def ensure_built():
+    """Build libpikazoo_hip.so if the tree does not carry it (hipcc is on every box of this image)."""
+    if not _native.LIB_PATH.exists():
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("pz_build", REPO / "pika-zoo_amd" / "build.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+
+
 def main():
     args = parse_args()
+    if int(os.environ.get("RANK", "0")) == 0:
+        ensure_built()
     rank, world, local_rank = dist.init_from_env(args.dist_backend)
     if os.environ.get("PZ_BENCH_ONE_DEVICE") == "1":
         local_rank = 0

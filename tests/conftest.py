@@ -25,6 +25,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Make sure the in-tree HIP library exists and is current (hipcc cross-compiles without a GPU).
+    This only *builds* the product; nothing falls back to the CPU if the build is impossible."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("pz_build", REPO / "pika-zoo_amd" / "build.py")
+    pz_build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pz_build)
+    try:
+        pz_build.build()
+    except Exception as exc:  # noqa: BLE001 - the tests that need the library will say so loudly
+        print(f"[conftest] could not build libpikazoo_hip.so: {exc}")
+
+
 def load_golden(name):
     d = dict(np.load(GOLDEN / f"{name}.npz"))
     d["meta"] = json.loads(bytes(d["meta"]).decode())
