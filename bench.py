@@ -128,7 +128,8 @@ def run_gpu(args, env, acts, warmup, steps, launch):
                 stream.synchronize()
                 state_before = raw.state.clone()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=stream):
+                # thread_local: the RCCL watchdog thread of a multi-rank run may poll events while we capture
+                with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                     launch_range(warmup, warmup + steps, torch.cuda.current_stream(raw.device))
                 graph.replay()                 # untimed first replay (graph upload), then rewind
                 raw.state.copy_(state_before)
@@ -232,7 +233,7 @@ def measure(args, shard, device, p2_computer, wrappers, launch, with_cpu):
     acts = pregenerate_actions(raw, total)
     torch.cuda.synchronize(device)
     wall, ev_ms = run_gpu(args, env, acts, args.warmup, args.steps, launch)
-    cdev = device if (shard.world_size > 1 and args.dist_backend != "gloo") else None  # collectives' tensor device
+    cdev = dist.collective_device(device)  # counters live on the GPU under nccl (RCCL), on the CPU under gloo
     wall = dist.all_reduce_max(wall, device=cdev)
     terminated_now = int(raw._term_u8.sum().item())
     n_total, = dist.all_reduce_sum([raw.num_envs], device=cdev)
@@ -362,7 +363,7 @@ def main():
         if extra:
             out["extra"] = extra
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -46,7 +46,9 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # under a launcher (WORLD_SIZE set, even to 1) the group is created, so a 1-rank torchrun run
+    # exercises exactly the code path of the N-rank runs
+    if "WORLD_SIZE" in os.environ and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -63,18 +65,25 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
 def all_reduce_sum(values, device=None) -> list[int]:
     """SUM over ranks of a short list of integer counters (one tiny all-reduce)."""
     t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(v) for v in t.tolist()]
 
 
 def all_reduce_max(value: float, device=None) -> float:
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
+
+
+def collective_device(gpu_device):
+    """Device the counters of all_reduce_* must live on: the GPU under nccl (RCCL), the CPU under gloo."""
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return gpu_device
+    return None
