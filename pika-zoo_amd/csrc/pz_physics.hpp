@@ -340,8 +340,9 @@ __device__ __forceinline__ int predict_landing_x_iterative(int x, int y, int xv,
 //     Y(m) <= ymax        for m = 0..K    (convex: check both ends)
 //     count + K <= 998                    (the cap test of iterations 0..K-1 stays false)
 // where ymax = 252 (only landing ends the stretch) if the ball is outside the net box
-// (x <= 191 or x >= 241) and X(0..K-1) stay on that side of it, else ymax = 176 (above the
-// net top, where the box cannot apply).  Then x = X(K), y = Y(K), yv += K, count += K.
+// (x <= 191 or x >= 241) and X(0..K-1) stay on that side of it -- or, for the power-hit
+// predictor, if the ball rises during the whole stretch (its net rule only acts on yv > 0) --
+// else ymax = 176 (above the net top, where the box cannot apply).  Then x = X(K), y = Y(K), yv += K, count += K.
 // K is *proposed* in float (distance to the wall or the box edge times 1/|xv|; roots of
 // Y(K) = ymax and, for a ball whose apex would cross the ceiling, of Y(K) = 0) and *verified*
 // with the exact integer conditions above; a failed verification falls back to the single
@@ -370,9 +371,13 @@ __device__ __forceinline__ int predict_landing_x(int x, int y, int xv, int yv)
         // ---- proposal + verification, written branch-free: in a divergent wave every trip pays
         // for every path anyway, and straight-line code lets the lone wave overlap the two
         // transcendental chains (rcp, sqrt) with the integer work.
-        const bool left = x <= kBoxLeft, right = x >= kBoxRight;
-        const bool outside = left || right;
-        const int ymax = outside ? kBallGroundY : kNetTopTopY;
+        // The simplified net rule of the power-hit predictor only flips a positive y velocity, so
+        // while the ball rises (yv + j <= 0 for the whole stretch, i.e. K <= 1 - yv) the box is inert
+        // and the stretch may run through it.
+        const bool ascending = !FULL_NET && yv < 0;
+        const bool left = !ascending & (x <= kBoxLeft), right = !ascending & (x >= kBoxRight);
+        const bool outside = left | right;  // outside the box, and the box matters
+        const int ymax = (outside | ascending) ? kBallGroundY : kNetTopTopY;
         const bool rightward = xv > 0;
         const int axv = abs(xv);
         // plain moves available along x: up to the wall, or up to the edge of the net box
@@ -391,6 +396,7 @@ __device__ __forceinline__ int predict_landing_x(int x, int y, int xv, int yv)
         const float root = __builtin_amdgcn_sqrtf(fmaxf(fmaf(hb, hb, c8), 0.0f));
         int K = (int)(((to_ceiling ? -root : root) - hb) * 0.5f - 0.001f);
         K = min(min(K, kx), kLoopLimit - 2 - count);
+        K = ascending ? min(K, 1 - yv) : K;
         // exact verification
         const int ye = flight_height(y, yv, K);
         const int xe = x + mul24(K, xv);
