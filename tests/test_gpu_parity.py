@@ -519,3 +519,23 @@ def test_long_run_digests_vs_oracle(kw, oracle):
         assert oracle.digest(cpu(env.unwrapped.state)) == ref.digest(), f"after {(c + 1) * chunk} frames"
     assert np.array_equal(cpu(env.unwrapped.state), ref.state)
     assert env.unwrapped.episodes_done == eps and eps > 0
+
+
+def test_wide_seeds_and_step_index_wraparound(oracle):
+    """64-bit seeds, game ids above 2^32 and a policy step index that crosses 2^32 (counter word 3)."""
+    n = 1024
+    seed, aseed, base = 0xFEDCBA9876543210, 0x0123456789ABCDEF, (1 << 40) + 12345
+    t0 = (1 << 32) - 5
+    env = make_env(num_envs=n, seed=seed, env_id_base=base, is_player2_computer=True, winning_score=1)
+    ref = oracle.OracleEnv(n, oracle.make_config(seed=seed, env_id_base=base, is_player2_computer=True,
+                                                 winning_score=1), nthreads=4)
+    env.reset(), ref.reset()
+    env.unwrapped.step_random(aseed, t0=t0, k=300)
+    ref.rollout_random(aseed, t0, 300)
+    assert np.array_equal(cpu(env.unwrapped.state), ref.state)
+    a = env.unwrapped.random_actions(aseed, t0 + 4)
+    b = env.unwrapped.random_actions(aseed, t0 + 5)  # = 2^32: high word of t becomes 1
+    r4 = oracle.random_actions(n, base, aseed, t0 + 4)
+    r5 = oracle.random_actions(n, base, aseed, t0 + 5)
+    assert np.array_equal(cpu(a["player_1"]), r4[0]) and np.array_equal(cpu(b["player_2"]), r5[1])
+    assert not torch.equal(a["player_1"], b["player_1"])
