@@ -249,21 +249,28 @@ def measure(args, shard, device, p2_computer, wrappers, launch, with_cpu):
     return res
 
 
-def measure_rollout(args, shard, device, k):
-    """pz_rollout_random: k frames per launch, every frame's outputs written to trajectory tensors
-    (state in registers, read/written once per launch).  Honest bytes per game-step of THIS kernel:
-    297 - 8 (no action reads) + 8 (actions written) + 352/k."""
+def measure_rollout(args, shard, device, k, tape=False):
+    """pz_rollout_random (or, tape=True, pz_step_many on a pre-generated action tape): k frames per
+    launch, every frame's outputs written to trajectory tensors (state in registers, read/written once
+    per launch).  Honest bytes per game-step of THESE kernels: 297 (8 of them action words written
+    resp. read) + 352/k."""
     env = make_env(args, shard, False, False, device)
     raw = env.unwrapped
     env.reset()
-    out = raw.rollout_random(ACTION_SEED, k)          # allocate + warm up
     launches = max(1, args.steps // k)
+    tapes = None
+    if tape:
+        acts = pregenerate_actions(raw, (launches + 1) * k).view(launches + 1, k, 2, raw.num_envs)
+        tapes = [acts[j] for j in range(launches + 1)]
+        out = raw.step_many(tapes[0])
+    else:
+        out = raw.rollout_random(ACTION_SEED, k)          # allocate + warm up
     torch.cuda.synchronize(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(launches):
-        out = raw.rollout_random(ACTION_SEED, k, out=out)
+    for j in range(launches):
+        out = raw.step_many(tapes[j + 1], out=out) if tape else raw.rollout_random(ACTION_SEED, k, out=out)
     ev1.record()
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
@@ -321,6 +328,7 @@ def main():
             r = measure(args, shard, device, ai, wr, args.launch, with_cpu=False)
             extra[key] = {"value": r["value"], "launch_us": r["launch_us"]}
         extra["rollout_k32"] = measure_rollout(args, shard, device, k=32)
+        extra["step_many_k32"] = measure_rollout(args, shard, device, k=32, tape=True)
         # the same kernel at larger batches (more waves per SIMD hide each other's latency)
         sweep = {}
         for n_big in (262144, 524288, 1048576):

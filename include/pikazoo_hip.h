@@ -167,6 +167,16 @@ int pz_rollout_random(int32_t *state, int64_t n, int64_t stride, const pz_config
                       uint8_t *terminated, int32_t *episode_stats, int64_t *episodes_done,
                       void *stream);
 
+/* ---- k frames of GIVEN actions in one launch, every frame's outputs kept -------------------
+ * actions: int32[k][2][n] (frame, agent, game) -- e.g. a recorded action tape or an open-loop
+ * plan; outputs as in pz_rollout_random.  Identical to k calls of pz_step on the k slices.
+ * n must be a multiple of 4 when k > 1. */
+int pz_step_many(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
+                 const int32_t *actions, int32_t k,
+                 int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
+                 uint8_t *terminated, int32_t *episode_stats, int64_t *episodes_done,
+                 void *stream);
+
 /* ---- the policy stream alone (for hosts that want the actions in HBM) -------------------- */
 int pz_random_actions(int32_t *act_p1, int32_t *act_p2, int64_t n, int64_t env_id_base,
                       uint64_t action_seed, uint64_t t, int32_t n_actions, void *stream);

@@ -339,9 +339,11 @@ __device__ unsigned long long g_pz_stamps[8192 * 8];
 //       kRandom   -- k frames of the on-device random policy, outputs of the last frame (pz_step_random);
 //       kRollout  -- k frames of the random policy, EVERY frame's outputs written to [k][n]...
 //                    trajectory tensors (pz_rollout_random); the state stays in registers for
-//                    the whole launch, so per frame only the outputs move.
+//                    the whole launch, so per frame only the outputs move;
+//       kTape     -- the same with the actions of every frame read from an int32[k][2][n] tape
+//                    (pz_step_many).
 // SPARSE: changed-only write-back of the rarely changing columns (large batches).
-enum StepMode { kActions = 0, kRandom = 1, kRollout = 2 };
+enum StepMode { kActions = 0, kRandom = 1, kRollout = 2, kTape = 3 };
 
 // The reward pipeline of one frame (see pz_config in the header): the reference's wrapper
 // stack RewardInNormalState / RewardByBallPosition in either order, fused.
@@ -471,15 +473,31 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
     Rewards rw{0, 0, 0.0f, 0.0f};
     if (MODE != kActions) {
         const uint32_t n_actions = a.cfg.simplify_action ? 13u : 18u;
+        int next1 = 0, next2 = 0;
+        if (MODE == kTape) {  // frame 0 of the action tape (rows past n read as 0)
+            const Rsrc tape = make_rsrc(a.act_p1, n32 * 8u);
+            next1 = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, 0, 0);
+            next2 = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, n32 * 4u, 0);
+        }
         for (int32_t s = 0; s < a.k; ++s) {
-            policy_actions(id.id_lo, id.id_hi, a.action_seed, a.t0 + (uint64_t)s, n_actions, a1, a2);
+            if (MODE == kTape) {
+                // software pipeline: the next frame's actions are fetched while this frame computes (a
+                // lone wave has nothing else to hide the load behind); the last fetch re-reads frame k-1
+                a1 = next1;
+                a2 = next2;
+                const Rsrc tape = make_rsrc(a.act_p1 + (int64_t)min(s + 1, a.k - 1) * 2 * a.n, n32 * 8u);
+                next1 = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, 0, 0);
+                next2 = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, n32 * 4u, 0);
+            } else {
+                policy_actions(id.id_lo, id.id_hi, a.action_seed, a.t0 + (uint64_t)s, n_actions, a1, a2);
+            }
             const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
             reward = step_games<AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane);
             finished += (unsigned int)(live && g.e.game_ended && !frozen);
             rw = shape_rewards(a.cfg, g, reward, frozen);
             if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
-            if (MODE == kRollout) {
-                if (a.act_out != nullptr) {
+            if (MODE == kRollout || MODE == kTape) {
+                if (MODE == kRollout && a.act_out != nullptr) {
                     const Rsrc ao = make_rsrc(a.act_out + (int64_t)s * 2 * a.n, n32 * 8u);
                     __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a1, ao, io.voff, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, io.voff, n32 * 4u, 0);
@@ -506,7 +524,7 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
             sio.st(2, st.len);
         }
     }
-    if (MODE != kRollout) emit_outputs(a, g, rw, as_float, live, i, lane, 0, lds_obs, PZ_SKIP_OBS);
+    if (MODE != kRollout && MODE != kTape) emit_outputs(a, g, rw, as_float, live, i, lane, 0, lds_obs, PZ_SKIP_OBS);
     PZ_STAMP(5);
     PZ_DRAIN_VMEM();
     PZ_STAMP(6);
@@ -651,7 +669,7 @@ template <int MODE>
 static int launch_step(const StepArgs& a, hipStream_t stream)
 {
     // a rollout writes the state once per k frames: the plain write-back is always right there
-    if (MODE != kRollout && a.n >= kSparseWritebackMinLanes) return launch_step_ai<MODE, true>(a, stream);
+    if (MODE != kRollout && MODE != kTape && a.n >= kSparseWritebackMinLanes) return launch_step_ai<MODE, true>(a, stream);
     return launch_step_ai<MODE, false>(a, stream);
 }
 
@@ -751,6 +769,20 @@ int pz_rollout_random(int32_t* state, int64_t n, int64_t stride, const pz_config
     StepArgs a{state,  n,          stride,        nullptr, nullptr, action_seed, t0, k, actions, obs_p1, obs_p2, rew_p1,
                rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), *cfg};
     return launch_step<kRollout>(a, (hipStream_t)stream);
+}
+
+int pz_step_many(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, const int32_t* actions, int32_t k,
+                 int32_t* obs_p1, int32_t* obs_p2, void* rew_p1, void* rew_p2, uint8_t* terminated,
+                 int32_t* episode_stats, int64_t* episodes_done, void* stream)
+{
+    if (int e = check_common(state, n, stride, cfg)) return e;
+    if (!actions || !obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
+    if (k < 1) return PZ_E_SIZE;
+    if (misaligned16(obs_p1) || misaligned16(obs_p2) || (k > 1 && (n & 3) != 0)) return PZ_E_ALIGN;
+    if (n == 0) return PZ_OK;
+    StepArgs a{state,  n,          stride,        actions, nullptr, 0, 0, k, nullptr, obs_p1, obs_p2, rew_p1,
+               rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), *cfg};
+    return launch_step<kTape>(a, (hipStream_t)stream);
 }
 
 int pz_random_actions(int32_t* act_p1, int32_t* act_p2, int64_t n, int64_t env_id_base, uint64_t action_seed,

@@ -62,6 +62,8 @@ _SIGNATURES = {
                                  C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pz_rollout_random": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), C.c_uint64, C.c_uint64,
                                     C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pz_step_many": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, C.c_int32, _P, _P, _P, _P, _P, _P,
+                               _P, _P]),
     "pz_random_actions": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _P]),
     "pz_selftest_predictor": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
 }

@@ -415,9 +415,40 @@ class raw_env:
                 out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(), out["_term"].data_ptr(),
                 self._stats_ptr(), self._episodes.data_ptr(), self._stream()), "pz_rollout_random")
         self.steps_done += k
-        dt = self.reward_dtype
+        return self._finish_trajectory(out)
+
+    def step_many(self, actions: torch.Tensor, out: Optional[dict] = None):
+        """``k`` frames of GIVEN actions (``int32[k, 2, N]``: frame, agent, game) in ONE launch, keeping
+        every frame's outputs; same result dict as :meth:`rollout_random`.  Bit-identical to ``k`` calls
+        of :meth:`step` on the ``k`` slices (a recorded action tape, an open-loop plan ...)."""
+        n, dev = self.num_envs, self.device
+        if actions.dim() != 3 or actions.shape[1] != 2 or actions.shape[2] != n:
+            raise ValueError(f"actions must have shape [k, 2, {n}]")
+        if actions.dtype != torch.int32 or actions.device != dev or not actions.is_contiguous():
+            actions = actions.to(device=dev, dtype=torch.int32).contiguous()
+        k = int(actions.shape[0])
+        if k > 1 and n % 4 != 0:
+            raise ValueError("step_many needs num_envs to be a multiple of 4")
+        if self.validate_actions and (int(actions.min().item()) < 0 or int(actions.max().item()) >= self.n_actions):
+            raise IndexError(f"action out of range [0, {self.n_actions})")
+        if out is None or out["_k"] != k:
+            out = {"_k": k,
+                   "_obs": [torch.empty((k, n, _native.OBS_DIM), dtype=torch.int32, device=dev) for _ in range(2)],
+                   "_rew": [torch.empty((k, n), dtype=torch.int32, device=dev) for _ in range(2)],
+                   "_term": torch.empty((k, n), dtype=torch.uint8, device=dev)}
+        out["actions"] = actions
+        with torch.cuda.device(dev):
+            _native.check(self._lib.pz_step_many(
+                self.state.data_ptr(), n, n, self._cfg_ref, actions.data_ptr(), k, out["_obs"][0].data_ptr(),
+                out["_obs"][1].data_ptr(), out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(),
+                out["_term"].data_ptr(), self._stats_ptr(), self._episodes.data_ptr(), self._stream()),
+                "pz_step_many")
+        self.steps_done += k
+        return self._finish_trajectory(out)
+
+    def _finish_trajectory(self, out):
+        dt, odt = self.reward_dtype, self.obs_dtype
         rew = [r if dt == torch.int32 else r.view(torch.float32) for r in out["_rew"]]
-        odt = self.obs_dtype
         out["obs"] = dict(zip(self.possible_agents, [o if odt == torch.int32 else o.view(odt) for o in out["_obs"]]))
         out["rewards"] = dict(zip(self.possible_agents, rew))
         out["terminations"] = out["_term"].view(torch.bool)

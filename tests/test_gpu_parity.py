@@ -539,3 +539,30 @@ def test_wide_seeds_and_step_index_wraparound(oracle):
     r5 = oracle.random_actions(n, base, aseed, t0 + 5)
     assert np.array_equal(cpu(a["player_1"]), r4[0]) and np.array_equal(cpu(b["player_2"]), r5[1])
     assert not torch.equal(a["player_1"], b["player_1"])
+
+
+def test_step_many_equals_single_steps(oracle):
+    """pz_step_many: k frames of GIVEN actions per launch == k calls of pz_step on the slices."""
+    n, k = 2048, 64
+    kw = dict(num_envs=n, seed=31, env_id_base=9, is_player1_computer=True, winning_score=2)
+    wr = dict(stack=[["RewardInNormalState", dict(reward=0.5)], ["RecordEpisodeStatistics", {}]])
+    a, b = make_env(wrappers=wr, **kw), make_env(wrappers=wr, **kw)
+    a.reset(), b.reset()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    out = None
+    for r in range(3):
+        tape = torch.randint(0, 18, (k, 2, n), generator=g, dtype=torch.int32).to("cuda:0")
+        out = a.unwrapped.step_many(tape, out=out)
+        for t in range(k):
+            obs, rew, term, _, infos = b.step({"player_1": tape[t, 0], "player_2": tape[t, 1]})
+            for ag in ("player_1", "player_2"):
+                assert torch.equal(out["obs"][ag][t], obs[ag]) and torch.equal(out["rewards"][ag][t], rew[ag])
+            assert torch.equal(out["terminations"][t], term["player_1"])
+        assert torch.equal(a.unwrapped.state, b.unwrapped.state)
+        assert torch.equal(a.unwrapped._stats, b.unwrapped._stats)
+    with pytest.raises(ValueError):
+        a.unwrapped.step_many(torch.zeros((2, 2, n + 1), dtype=torch.int32, device="cuda:0"))
+    va = make_env(num_envs=8, validate_actions=True)
+    va.reset()
+    with pytest.raises(IndexError):
+        va.unwrapped.step_many(torch.full((2, 2, 8), 18, dtype=torch.int32, device="cuda:0"))
