@@ -140,3 +140,27 @@ def test_two_rank_sharding_equals_single_process(tmp_path, oracle):
     assert np.array_equal(got, whole.state)
     steps, episodes, tmax = (tmp_path / "agg.txt").read_text().split()
     assert int(steps) == 96 * 300 and int(episodes) == eps and float(tmax) == 2.0
+
+
+def test_argument_validation_without_a_gpu(built_lib):
+    """Argument errors are reported before anything touches the device (no launch on these paths)."""
+    from pikazoo_amd import _native
+
+    lib = _native.load()
+    cfg = _native.PzConfig()
+    cfg.winning_score, cfg.serve_mode = 15, 0
+    fake = C.c_void_p(4096)  # never dereferenced: every call below returns before a launch
+    assert lib.pz_init(None, 0, 0, C.byref(cfg), None) == -1            # PZ_E_NULL
+    assert lib.pz_init(fake, -1, 0, C.byref(cfg), None) == -2           # PZ_E_SIZE
+    assert lib.pz_init(fake, 8, 4, C.byref(cfg), None) == -2            # stride < n
+    assert lib.pz_init(fake, 0, 24_403_224, C.byref(cfg), None) == -2   # more games than one launch addresses
+    assert lib.pz_init(fake, 0, 24_403_223, C.byref(cfg), None) == 0    # empty batch: no-op
+    cfg.serve_mode = 3
+    assert lib.pz_init(fake, 0, 0, C.byref(cfg), None) == -3            # PZ_E_CONFIG
+    cfg.serve_mode, cfg.winning_score = 0, 0
+    assert lib.pz_init(fake, 0, 0, C.byref(cfg), None) == -3
+    cfg.winning_score = 1
+    assert lib.pz_step(fake, 0, 0, C.byref(cfg), None, fake, fake, fake, fake, fake, fake, None, None) == -1
+    assert lib.pz_step_random(fake, 0, 0, C.byref(cfg), 1, 0, 0, fake, fake, fake, fake, fake, None, None, None) == -2
+    assert lib.pz_observe(fake, 0, 0, 0, C.c_void_p(4100), fake, None) == -4   # PZ_E_ALIGN
+    assert lib.pz_step(fake, 0, 0, C.byref(cfg), fake, fake, fake, fake, fake, fake, fake, None, None) == 0
