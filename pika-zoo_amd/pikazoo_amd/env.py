@@ -14,7 +14,6 @@ without a GPU raises.
 from __future__ import annotations
 
 import ctypes as C
-import functools
 from typing import Dict, Optional
 
 import numpy as np
@@ -131,6 +130,7 @@ class raw_env:
         self.steps_done = 0  # frames stepped by this env (per lane)
 
         self.action_spaces = {a: Discrete(18) for a in self.possible_agents}
+        self._spaces = {}
         with torch.cuda.device(self.device):
             _native.check(self._lib.pz_init(self.state.data_ptr(), n, n, self._cfg_ref, self._stream()), "pz_init")
 
@@ -234,13 +234,19 @@ class raw_env:
         return self._obs[i] if not self._cfg.normalize_obs else self._obs[i].view(torch.float32)
 
     # ---- spaces (pikazoo_env.py:481-568) ----------------------------------------------------------
-    @functools.lru_cache(maxsize=None)
     def observation_space(self, agent=None):
-        return Box(low=OBS_LOW.copy(), high=OBS_HIGH.copy(), shape=(35,), dtype=np.int32)
+        # the reference lru_caches this method (pikazoo_env.py:481): same object on every call; cached per
+        # instance here (an lru_cache on the method would pin the env and its device tensors forever)
+        sp = self._spaces.get("obs")
+        if sp is None:
+            sp = self._spaces["obs"] = Box(low=OBS_LOW.copy(), high=OBS_HIGH.copy(), shape=(35,), dtype=np.int32)
+        return sp
 
-    @functools.lru_cache(maxsize=None)
     def normalized_observation_space(self, agent=None):
-        return Box(low=0.0, high=1.0, shape=(35,), dtype=np.float32)  # normalize_observation.py:35
+        sp = self._spaces.get("norm")
+        if sp is None:  # normalize_observation.py:35
+            sp = self._spaces["norm"] = Box(low=0.0, high=1.0, shape=(35,), dtype=np.float32)
+        return sp
 
     def action_space(self, agent):
         return self.action_spaces[agent]
