@@ -3,4 +3,4 @@
     from pikazoo_amd import pikazoo_v0
     env = pikazoo_v0.env(num_envs=65536, device="cuda:0", is_player2_computer=True)
 """
-from .version import __version__  # noqa: F401
+from ._version import VERSION, __version__  # noqa: F401

@@ -506,7 +506,3 @@ class raw_env:
     def close(self):
         pass
 
-
-def env(**kwargs):
-    """``pikazoo_v0.env(**kwargs)`` (pikazoo/env/pikazoo_env.py:27-29)."""
-    return raw_env(**kwargs)
