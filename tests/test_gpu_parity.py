@@ -566,3 +566,26 @@ def test_step_many_equals_single_steps(oracle):
     va.reset()
     with pytest.raises(IndexError):
         va.unwrapped.step_many(torch.full((2, 2, 8), 18, dtype=torch.int32, device="cuda:0"))
+
+
+def test_large_batch_offsets(oracle):
+    """2^24 games in one launch (3 GB of state, 2 x 2.3 GB of observations): the 32-bit buffer offsets near
+    their upper range, checked against the oracle on slices at the start, middle and end of the batch."""
+    n, seed, base, aseed = 1 << 24, 5, 3, 17
+    env = make_env(num_envs=n, seed=seed, env_id_base=base, winning_score=1)
+    raw = env.unwrapped
+    env.reset()
+    for t in range(6):
+        obs, rew, term, _, _ = env.step_random(aseed)
+    for lo in (0, n // 2 - 256, n - 512):
+        ref = oracle.OracleEnv(512, oracle.make_config(winning_score=1, seed=seed, env_id_base=base + lo))
+        ref.reset()
+        for t in range(6):
+            a1, a2 = oracle.random_actions(512, base + lo, aseed, t)
+            robs, rrew, rterm = ref.step(a1, a2)
+        assert np.array_equal(cpu(raw.state[:, lo:lo + 512]), ref.state), lo
+        assert np.array_equal(cpu(obs["player_1"][lo:lo + 512]), robs[0]), lo
+        assert np.array_equal(cpu(obs["player_2"][lo:lo + 512]), robs[1]), lo
+        assert np.array_equal(cpu(rew["player_2"][lo:lo + 512]), rrew[1]), lo
+    del env, raw, obs, rew, term
+    torch.cuda.empty_cache()
