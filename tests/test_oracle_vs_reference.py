@@ -1,0 +1,63 @@
+"""Live check of the oracle against the UNMODIFIED reference, in the build container only.
+
+The reference checkout (/root/reference) does not exist on the GPU box; there this module is skipped and the
+committed fixtures (tests/golden/, produced by the same harness) carry the parity pin.  Here it re-runs the
+capture harness on fresh seeds, so the pin does not rest on the committed files alone.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import ref_capture as rc
+
+pytestmark = pytest.mark.skipif(not rc.reference_available(), reason="reference checkout not mounted")
+
+TABLE = [0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01]
+LIVE = [
+    ("human_human", dict(winning_score=5, serve="winner"), None),
+    ("p1_computer_random_serve", dict(winning_score=3, serve="random", is_player1_computer=True), None),
+    ("both_computer_alternate", dict(winning_score=2, serve="alternate", is_player1_computer=True,
+                                     is_player2_computer=True), None),
+    ("wrapper_stack", dict(winning_score=2, is_player2_computer=True),
+     dict(stack=[["SimplifyAction", {}], ["RecordEpisodeStatistics", {}],
+                 ["RewardByBallPosition", dict(additional_reward=TABLE)],
+                 ["RewardInNormalState", dict(reward=0.03125)], ["NormalizeObservation", {}]])),
+]
+
+
+@pytest.mark.parametrize("name,kw,wr", LIVE)
+def test_oracle_tracks_live_reference(oracle, name, kw, wr):
+    lanes, steps, seed, aseed, base = 6, 2500, 424242, 31, 99
+    d = rc.capture(name, lanes, steps, seed=seed, action_seed=aseed, env_id_base=base, env_kwargs=kw,
+                   wrappers=wr, full=True)
+    meta = json.loads(bytes(d["meta"]).decode())
+    opt = rc.fused_options(wr)
+    cfg = oracle.make_config(winning_score=kw.get("winning_score", 15), serve=kw.get("serve", "winner"),
+                             is_player1_computer=kw.get("is_player1_computer", False),
+                             is_player2_computer=kw.get("is_player2_computer", False), seed=seed,
+                             env_id_base=base, **opt)
+    env = oracle.OracleEnv(lanes, cfg)
+    assert np.array_equal(env.state, d["state_ctor"])
+    env.reset()
+    assert np.array_equal(env.state, d["state0"])
+    float_obs, float_rew = bool(cfg.normalize_obs), env.float_rewards
+    for t in range(steps):
+        a = d["actions"][t].astype(np.int32)
+        obs, rew, term = env.step(a[0], a[1])
+        st = d["states"][t].astype(np.int32)
+        st[43] = d["rng_counter"][t]
+        assert np.array_equal(env.state, st), (name, t)
+        exp = d["obs"][t].astype(np.float32) if float_obs else d["obs"][t]
+        assert np.array_equal(obs[0], exp[0]) and np.array_equal(obs[1], exp[1]), (name, t)
+        assert np.array_equal(term, d["term"][t]), (name, t)
+        if float_rew:
+            np.testing.assert_allclose(rew[0], d["rew"][t, 0], rtol=0, atol=1e-6)
+        else:
+            assert np.array_equal(rew[0], d["rew"][t, 0]) and np.array_equal(rew[1], d["rew"][t, 1])
+        if cfg.episode_stats_mode:
+            done = d["ep_l"][t] >= 0
+            if done.any():
+                assert np.array_equal(env.episode_lengths[done], d["ep_l"][t][done])
+                np.testing.assert_allclose(env.episode_returns[:, done], d["ep_r"][t][:, done], rtol=0, atol=2e-4)
+    assert meta["episodes"] == int(d["term"].sum()) and meta["episodes"] > 0
