@@ -341,9 +341,10 @@ __device__ unsigned long long g_pz_stamps[8192 * 8];
 //                    trajectory tensors (pz_rollout_random); the state stays in registers for
 //                    the whole launch, so per frame only the outputs move;
 //       kTape     -- the same with the actions of every frame read from an int32[k][2][n] tape
-//                    (pz_step_many).
+//                    (pz_step_many), fetched 16 frames at a time into LDS.
 // SPARSE: changed-only write-back of the rarely changing columns (large batches).
 enum StepMode { kActions = 0, kRandom = 1, kRollout = 2, kTape = 3 };
+constexpr int kTapeChunk = 16;  // frames of the action tape fetched at once by pz_step_many
 
 // The reward pipeline of one frame (see pz_config in the header): the reference's wrapper
 // stack RewardInNormalState / RewardByBallPosition in either order, fused.
@@ -426,6 +427,7 @@ template <bool AI1, bool AI2, int MODE, bool SPARSE>
 __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
 {
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
+    __shared__ int32_t tape_lds[MODE == kTape ? kTapeChunk * 2 * kLanes : 1];  // parked action tape (kTape only)
 
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * kLanes;
@@ -473,21 +475,25 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
     Rewards rw{0, 0, 0.0f, 0.0f};
     if (MODE != kActions) {
         const uint32_t n_actions = a.cfg.simplify_action ? 13u : 18u;
-        int next1 = 0, next2 = 0;
-        if (MODE == kTape) {  // frame 0 of the action tape (rows past n read as 0)
-            const Rsrc tape = make_rsrc(a.act_p1, n32 * 8u);
-            next1 = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, 0, 0);
-            next2 = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, n32 * 4u, 0);
-        }
         for (int32_t s = 0; s < a.k; ++s) {
             if (MODE == kTape) {
-                // software pipeline: the next frame's actions are fetched while this frame computes (a
-                // lone wave has nothing else to hide the load behind); the last fetch re-reads frame k-1
-                a1 = next1;
-                a2 = next2;
-                const Rsrc tape = make_rsrc(a.act_p1 + (int64_t)min(s + 1, a.k - 1) * 2 * a.n, n32 * 8u);
-                next1 = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, 0, 0);
-                next2 = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, n32 * 4u, 0);
+                // The tape is fetched kTapeChunk frames at a time and parked in LDS: a per-frame global load
+                // would put a full memory latency on every frame of a lone wave, and its wait (vmcnt is
+                // in-order) would also drain that frame's stores; LDS reads only touch lgkmcnt.
+                const int slot = s % kTapeChunk;
+                if (slot == 0) {
+                    const int frames = min(kTapeChunk, a.k - s);
+                    for (int f = 0; f < frames; ++f) {  // rows past n read as 0 through the range check
+                        const Rsrc tape = make_rsrc(a.act_p1 + (int64_t)(s + f) * 2 * a.n, n32 * 8u);
+                        tape_lds[(f * 2 + 0) * kLanes + lane] =
+                            (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, 0, 0);
+                        tape_lds[(f * 2 + 1) * kLanes + lane] =
+                            (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, n32 * 4u, 0);
+                    }
+                    __syncthreads();
+                }
+                a1 = tape_lds[(slot * 2 + 0) * kLanes + lane];
+                a2 = tape_lds[(slot * 2 + 1) * kLanes + lane];
             } else {
                 policy_actions(id.id_lo, id.id_hi, a.action_seed, a.t0 + (uint64_t)s, n_actions, a1, a2);
             }
