@@ -589,3 +589,78 @@ def test_large_batch_offsets(oracle):
         assert np.array_equal(cpu(rew["player_2"][lo:lo + 512]), rrew[1]), lo
     del env, raw, obs, rew, term
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------
+# 8. randomized configuration sweep straight through the C ABI (odd sizes, stride > n, every flag mix)
+# ------------------------------------------------------------------------------------------------
+def test_randomized_config_sweep_vs_oracle(oracle):
+    import random
+
+    from pikazoo_amd import _native
+
+    lib = _native.load()
+    rnd = random.Random(20241008)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for trial in range(40):
+        n = rnd.choice([1, 2, 3, 31, 63, 64, 65, 100, 127, 128, 129, 255, 300, 511, 640, 700])
+        stride = n + rnd.choice([0, 0, 1, 7, 64, 130])
+        k = dict(winning_score=rnd.choice([1, 1, 2, 3]), serve=rnd.choice(["winner", "alternate", "random"]),
+                 is_player1_computer=rnd.random() < 0.4, is_player2_computer=rnd.random() < 0.4,
+                 simplify_action=rnd.random() < 0.5,
+                 additional_reward=[rnd.choice([0.0, 0.5, -0.25, 1.0, -1.0]) for _ in range(8)] if rnd.random() < 0.5
+                 else None,
+                 x_line=rnd.choice([216, 100, 300]), y_line=rnd.choice([176, 60, 240]),
+                 normal_state_reward=rnd.choice([None, None, 0.125, -0.5]), normal_state_outside=rnd.random() < 0.5,
+                 normalize_obs=rnd.random() < 0.4, episode_stats=rnd.choice([0, 0, 1, 2]),
+                 auto_reset=rnd.random() < 0.8, seed=rnd.getrandbits(64), env_id_base=rnd.getrandbits(40))
+        if k["normal_state_reward"] is None or k["additional_reward"] is None:
+            k["normal_state_outside"] = False  # "outside" only means something relative to RewardByBallPosition
+        ocfg = oracle.make_config(**k)
+        cfg = _native.PzConfig.from_buffer_copy(ocfg)  # identical layout (checked by the CPU tests)
+        ref = oracle.OracleEnv(n, ocfg, nthreads=2)
+        state = torch.full((44, stride), -99, dtype=torch.int32, device=dev)
+        stats = torch.full((3, stride), 0, dtype=torch.int32, device=dev) if k["episode_stats"] else None
+        obs = [torch.zeros((n, 35), dtype=torch.int32, device=dev) for _ in range(2)]
+        rew = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
+        term = torch.zeros(n, dtype=torch.uint8, device=dev)
+        sp = None if stats is None else stats.data_ptr()
+        assert lib.pz_init(state.data_ptr(), n, stride, C.byref(cfg), stream) == 0
+        assert lib.pz_reset(state.data_ptr(), n, stride, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(), sp,
+                            stream) == 0
+        ref.reset()
+        n_act = 13 if k["simplify_action"] else 18
+        aseed = rnd.getrandbits(64)
+        t = 0
+        for phase in range(4):
+            mode = rnd.choice(["step", "random", "random_k"])
+            if mode == "step":
+                for _ in range(15):
+                    a1, a2 = oracle.random_actions(n, k["env_id_base"], aseed, t, n_act)
+                    d1, d2 = torch.as_tensor(a1, device=dev), torch.as_tensor(a2, device=dev)
+                    assert lib.pz_step(state.data_ptr(), n, stride, C.byref(cfg), d1.data_ptr(), d2.data_ptr(),
+                                       obs[0].data_ptr(), obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(),
+                                       term.data_ptr(), sp, stream) == 0
+                    ref.step(a1, a2)
+                    t += 1
+            else:
+                kk = 1 if mode == "random" else rnd.choice([2, 5, 17])
+                reps = 12 if mode == "random" else 2
+                for _ in range(reps):
+                    assert lib.pz_step_random(state.data_ptr(), n, stride, C.byref(cfg), aseed, t, kk,
+                                              obs[0].data_ptr(), obs[1].data_ptr(), rew[0].data_ptr(),
+                                              rew[1].data_ptr(), term.data_ptr(), sp, None, stream) == 0
+                    ref.rollout_random(aseed, t, kk)
+                    t += kk
+            torch.cuda.synchronize()
+            ctx = (trial, phase, mode, n, stride, k)
+            assert np.array_equal(cpu(state[:, :n]), ref.state), ctx
+            assert bool((state[:, n:] == -99).all()), ctx
+            assert np.array_equal(cpu(obs[0]), ref.obs[0].view(np.int32)) and np.array_equal(cpu(obs[1]),
+                                                                                           ref.obs[1].view(np.int32)), ctx
+            assert np.array_equal(cpu(rew[0]), ref.rew[0].view(np.int32)) and np.array_equal(cpu(rew[1]),
+                                                                                           ref.rew[1].view(np.int32)), ctx
+            assert np.array_equal(cpu(term), ref.term), ctx
+            if stats is not None:
+                assert np.array_equal(cpu(stats[:, :n]), ref.stats), ctx
