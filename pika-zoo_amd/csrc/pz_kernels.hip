@@ -280,6 +280,31 @@ __device__ __forceinline__ void stage_obs_t(const Game& g, int32_t* __restrict__
     }
 }
 
+// one agent's row: [own player | opponent | ball] (pair kernel: each wave packs its own agent's tensor)
+template <bool NORM>
+__device__ __forceinline__ void stage_one_obs_t(const Player& me, const Player& opp, const Ball& b,
+                                                int32_t* __restrict__ dst, int lane)
+{
+    int32_t pa[13], pb[13];
+    player_words<NORM>(me, pa);
+    player_words<NORM>(opp, pb);
+    int32_t* r = dst + lane * PZ_OBS_DIM;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        r[k] = pa[k];
+        r[13 + k] = pb[k];
+    }
+    r[26] = obs_word<NORM>(b.x, 20, 412);
+    r[27] = obs_word<NORM>(b.y, 0, 252);
+    r[28] = obs_word<NORM>(b.px, 0, 432);
+    r[29] = obs_word<NORM>(b.py, 0, 252);
+    r[30] = obs_word<NORM>(b.ppx, 0, 432);
+    r[31] = obs_word<NORM>(b.ppy, 0, 252);
+    r[32] = obs_word<NORM>(b.xv, -20, 40);
+    r[33] = obs_word<NORM>(b.yv, -124, 248);
+    r[34] = obs_word<NORM>(b.power, 0, 1);
+}
+
 __device__ __forceinline__ void stage_obs(const Game& g, int32_t* __restrict__ s1, int32_t* __restrict__ s2, int lane,
                                           bool normalize)
 {
@@ -543,6 +568,123 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
     }
 }
 
+// ---- the pair kernel: two waves per 64 games, split by player (see step_games_pair) ---------------
+// Used for single-frame human-vs-human launches below the sparse write-back threshold -- the bench
+// headline.  Wave ROLE loads/stores its own player's 13 columns, its half of the ball columns (both
+// waves load all 12), player 1's wave also the 6 env columns, the episode statistics and `terminated`;
+// each wave writes its own agent's reward and observation tensor.
+template <int ROLE>
+__device__ __forceinline__ void pair_body(const StepArgs& a, int32_t (*lds_obs)[kLanes * PZ_OBS_DIM],
+                                          int32_t* __restrict__ xchg, int lane)
+{
+    const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
+    const bool live = i < a.n;
+    const uint32_t n32 = (uint32_t)a.n;
+    const StateIO io{make_rsrc(a.state, (uint32_t)(a.stride * (PZ_STATE_WORDS * 4))), (uint32_t)a.stride * 4u,
+                     (uint32_t)i * 4u};
+    const bool as_float = a.cfg.ballpos_reward != 0 || a.cfg.normal_state_mode != 0;
+    const bool with_stats = ROLE == 0 && a.episode_stats != nullptr && a.cfg.episode_stats_mode != 0;
+    const StateIO sio{make_rsrc(a.episode_stats, with_stats ? (uint32_t)(a.stride * 12) : 0u),
+                      (uint32_t)a.stride * 4u, (uint32_t)i * 4u};
+    constexpr int kOwn = ROLE * PZ_P_WORDS, kOther = (1 - ROLE) * PZ_P_WORDS;
+
+    Game g{};
+    const RngId id = make_rng_id(a.cfg, live ? i : 0);
+    const int a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act_p1, n32 * 4u), io.voff, 0, 0);
+    const int a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act_p2, n32 * 4u), io.voff, 0, 0);
+    EpisodeStats st{0u, 0u, 0};
+    if (live) {
+        g.e.round_ended = io.ld(PZ_E_ROUND_ENDED);
+        g.e.game_ended = io.ld(PZ_E_GAME_ENDED);
+        g.e.rng = (uint32_t)io.ld(PZ_E_RNG_DRAW_COUNTER);
+        g.e.s1 = io.ld(PZ_E_SCORE_P1);
+        g.e.s2 = io.ld(PZ_E_SCORE_P2);
+        g.e.p2serve = io.ld(PZ_E_IS_PLAYER2_SERVE);
+        g.b.x = io.ld(PZ_B_X);
+        g.b.y = io.ld(PZ_B_Y);
+        g.b.xv = io.ld(PZ_B_X_VELOCITY);
+        g.b.yv = io.ld(PZ_B_Y_VELOCITY);
+        g.b.power = io.ld(PZ_B_IS_POWER_HIT);
+        g.b.px = io.ld(PZ_B_PREVIOUS_X);
+        g.b.py = io.ld(PZ_B_PREVIOUS_Y);
+        g.b.ppx = io.ld(PZ_B_PREVIOUS_PREVIOUS_X);
+        g.b.ppy = io.ld(PZ_B_PREVIOUS_PREVIOUS_Y);
+        g.b.rot = io.ld(PZ_B_FINE_ROTATION);
+        g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);
+        g.b.punch = io.ld(PZ_B_PUNCH_EFFECT_X);
+        load_player(ROLE == 0 ? g.p1 : g.p2, io, kOwn);
+        (ROLE == 0 ? g.p2 : g.p1).coll = io.ld(kOther + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED);
+        if (with_stats) {
+            st.r1 = (uint32_t)sio.ld(0);
+            st.r2 = (uint32_t)sio.ld(1);
+            st.len = sio.ld(2);
+        }
+    }
+    const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
+    bool frozen = false;
+    const int reward = step_games_pair<ROLE>(g, a.cfg, id, a1, a2, live, frozen, xchg, lane);
+    const Rewards rw = shape_rewards(a.cfg, g, reward, frozen);
+    if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
+
+    if (live) {
+        store_player(ROLE == 0 ? g.p1 : g.p2, io, kOwn);
+        if (ROLE == 0) {
+            io.st(PZ_B_X, g.b.x);
+            io.st(PZ_B_Y, g.b.y);
+            io.st(PZ_B_X_VELOCITY, g.b.xv);
+            io.st(PZ_B_Y_VELOCITY, g.b.yv);
+            io.st(PZ_B_IS_POWER_HIT, g.b.power);
+            io.st(PZ_B_PUNCH_EFFECT_X, g.b.punch);
+            io.st(PZ_E_SCORE_P1, g.e.s1);
+            io.st(PZ_E_SCORE_P2, g.e.s2);
+            io.st(PZ_E_IS_PLAYER2_SERVE, g.e.p2serve);
+            io.st(PZ_E_ROUND_ENDED, g.e.round_ended);
+            io.st(PZ_E_GAME_ENDED, g.e.game_ended);
+            io.st(PZ_E_RNG_DRAW_COUNTER, (int32_t)g.e.rng);
+            if (with_stats) {
+                sio.st(0, (int)st.r1);
+                sio.st(1, (int)st.r2);
+                sio.st(2, st.len);
+            }
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, make_rsrc(a.terminated, n32),
+                                                 (uint32_t)i, 0, 0);
+        } else {
+            io.st(PZ_B_PREVIOUS_X, g.b.px);
+            io.st(PZ_B_PREVIOUS_Y, g.b.py);
+            io.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
+            io.st(PZ_B_PREVIOUS_PREVIOUS_Y, g.b.ppy);
+            io.st(PZ_B_FINE_ROTATION, g.b.rot);
+            io.st(PZ_B_EXPECTED_LANDING_POINT_X, g.b.ex);
+        }
+        const Rsrc rew = make_rsrc(ROLE == 0 ? a.rew_p1 : a.rew_p2, n32 * 4u);
+        const unsigned int bits = as_float ? __float_as_uint(ROLE == 0 ? rw.f1 : rw.f2)
+                                           : (unsigned int)(ROLE == 0 ? rw.i1 : rw.i2);
+        __builtin_amdgcn_raw_buffer_store_b32(bits, rew, io.voff, 0, 0);
+        const Player& me = ROLE == 0 ? g.p1 : g.p2;
+        const Player& opp = ROLE == 0 ? g.p2 : g.p1;
+        if (a.cfg.normalize_obs)
+            stage_one_obs_t<true>(me, opp, g.b, lds_obs[ROLE], lane);
+        else
+            stage_one_obs_t<false>(me, opp, g.b, lds_obs[ROLE], lane);
+    }
+    __syncthreads();
+    flush_rows(lds_obs[ROLE], make_rsrc(ROLE == 0 ? a.obs_p1 : a.obs_p2, n32 * kRowBytes),
+               blockIdx.x * kWaveObsBytes, lane);
+}
+
+__global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(const StepArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
+    __shared__ int32_t xchg[2 * kLanes * 9];
+    // the wave index is uniform by construction; readfirstlane makes that visible to the compiler
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & (kLanes - 1);
+    if (role == 0)
+        pair_body<0>(a, lds_obs, xchg, lane);
+    else
+        pair_body<1>(a, lds_obs, xchg, lane);
+}
+
 // ---- constructor / reset / observe / policy kernels --------------------------------------------
 __global__ __launch_bounds__(kLanes) void init_kernel(int32_t* state, int64_t n, int64_t stride, const pz_config cfg)
 {
@@ -674,6 +816,12 @@ static int launch_step_ai(const StepArgs& a, hipStream_t stream)
 template <int MODE>
 static int launch_step(const StepArgs& a, hipStream_t stream)
 {
+#ifndef PZ_NO_PAIR_KERNEL
+    if (MODE == kActions && a.n < kSparseWritebackMinLanes && a.cfg.p1_computer == 0 && a.cfg.p2_computer == 0) {
+        hipLaunchKernelGGL(step_pair_kernel, dim3(blocks_for(a.n, kLanes)), dim3(2 * kLanes), 0, stream, a);
+        return (int)hipGetLastError();
+    }
+#endif
     // a rollout writes the state once per k frames: the plain write-back is always right there
     if (MODE != kRollout && MODE != kTape && a.n >= kSparseWritebackMinLanes) return launch_step_ai<MODE, true>(a, stream);
     return launch_step_ai<MODE, false>(a, stream);

@@ -779,4 +779,112 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
     return reward;
 }
 
+// ---------------------------------------------------------------------------------------
+// The same frame for a PAIR of waves per 64 games (human-vs-human, single frame).
+// A lone wave per SIMD only fills every second issue slot, and its ~1 250 instructions run one
+// after the other.  Here the work of a workgroup's 64 games is split between two waves that
+// sit on different SIMDs: wave ROLE owns player ROLE+1 -- its new-round draw, its movement, its
+// state columns, its agent's reward and observation tensor -- and both redo the cheap shared
+// parts (round bookkeeping, action decode, ball-world step, ball-player collisions, scoring),
+// which are deterministic, so the two copies stay identical.  One LDS exchange per frame hands
+// the moved player to the partner.  `g` holds: the own player complete, of the partner only
+// `coll` (and whatever the exchange fills in), ball and env complete.
+// xchg: 2 * 64 * 9 words of LDS.  Contains exactly one __syncthreads().
+// ---------------------------------------------------------------------------------------
+template <int ROLE>
+__device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2,
+                                               bool live, bool& frozen, int32_t* __restrict__ xchg, int lane)
+{
+    Player& own = ROLE == 0 ? g.p1 : g.p2;
+    Player& other = ROLE == 0 ? g.p2 : g.p1;
+    frozen = live && g.e.game_ended && !cfg.auto_reset;
+    const bool active = live && !frozen;
+    Input in1{0, 0, 0}, in2{0, 0, 0};
+    bool ground = false;
+    if (active) {
+        if (g.e.round_ended) {  // reset (:149-164) or new round (:176-180); game_ended implies round_ended
+            if (g.e.game_ended) {
+                g.e.game_ended = 0;
+                g.e.p2serve = 0;
+                g.e.s1 = 0;
+                g.e.s2 = 0;
+            }
+            g.e.round_ended = 0;
+            // draw order of the reference: player 1 boldness, player 2 boldness [, serve]; each wave
+            // evaluates its own player's draw (index rng + ROLE)
+            uint32_t own_draw = g.e.rng + (uint32_t)ROLE;
+            player_new_round(own, ROLE == 0 ? 36 : kGroundWidth - 36, id, own_draw);
+            other.x = ROLE == 0 ? kGroundWidth - 36 : 36;
+            other.y = kPlayerGroundY;
+            other.yv = 0;
+            other.coll = 0;
+            other.state = 0;
+            other.frame = 0;
+            other.delay = 0;
+            g.e.rng += 2u;
+            ball_new_round(g.b, get_server(cfg, g.e, id));  // a random serve is drawn by both waves
+        }
+        int other_prev = 0;  // the partner's key edge is only needed by the partner
+        if (cfg.simplify_action) {
+            in1 = decode_action(kSimpleTablesP1, a1, ROLE == 0 ? g.p1.hitprev : other_prev);
+            in2 = decode_action(kSimpleTablesP2, a2, ROLE == 1 ? g.p2.hitprev : other_prev);
+        } else {
+            in1 = decode_action(kFullTables, a1, ROLE == 0 ? g.p1.hitprev : other_prev);
+            in2 = decode_action(kFullTables, a2, ROLE == 1 ? g.p2.hitprev : other_prev);
+        }
+
+        ground = ball_world_step(g.b);
+        player_move<ROLE == 1>(own, ROLE == 0 ? in1 : in2);
+    }
+    // hand the own player to the partner wave: everything the collisions and the observations read
+    // (frozen games exchange their unchanged players, so their observations stay complete)
+    constexpr int kXchgWords = 9;  // odd pitch: conflict-free LDS rows
+    if (live) {
+        int32_t* mine = xchg + (ROLE * 64 + lane) * kXchgWords;
+        mine[0] = own.x;
+        mine[1] = own.y;
+        mine[2] = own.yv;
+        mine[3] = own.state;
+        mine[4] = own.frame;
+        mine[5] = own.delay;
+        mine[6] = own.dive;
+        mine[7] = own.lying;
+        mine[8] = own.hitprev;
+    }
+    __syncthreads();
+    if (live) {
+        const int32_t* theirs = xchg + ((1 - ROLE) * 64 + lane) * kXchgWords;
+        other.x = theirs[0];
+        other.y = theirs[1];
+        other.yv = theirs[2];
+        other.state = theirs[3];
+        other.frame = theirs[4];
+        other.delay = theirs[5];
+        other.dive = theirs[6];
+        other.lying = theirs[7];
+        other.hitprev = theirs[8];
+    }
+    int reward = 0;
+    if (active) {
+
+        // physics.py:319-335: player 1 first, then player 2 against the possibly changed velocities
+        const bool touch1 = ball_touches_player(g.b, g.p1), hit1 = touch1 & (g.p1.coll == 0);
+        ball_player_collision(g.b, hit1, g.p1.x, in1, g.p1.state, id, g.e.rng);
+        g.p1.coll = touch1;
+        const bool touch2 = ball_touches_player(g.b, g.p2), hit2 = touch2 & (g.p2.coll == 0);
+        ball_player_collision(g.b, hit2, g.p2.x, in2, g.p2.state, id, g.e.rng);
+        g.p2.coll = touch2;
+
+        // scoring / round end / game end (:190-210)
+        const bool p2_scores = ground & (g.b.punch < kGroundHalfWidth), p1_scores = ground & !p2_scores;
+        g.e.s1 += p1_scores;
+        g.e.s2 += p2_scores;
+        g.e.p2serve = ground ? (int)p2_scores : g.e.p2serve;
+        g.e.game_ended = ground & ((p2_scores ? g.e.s2 : g.e.s1) >= cfg.winning_score);
+        g.e.round_ended = ground;
+        reward = ground ? (p2_scores ? -1 : 1) : 0;
+    }
+    return reward;
+}
+
 }  // namespace pz

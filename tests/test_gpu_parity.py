@@ -664,3 +664,23 @@ def test_randomized_config_sweep_vs_oracle(oracle):
             assert np.array_equal(cpu(term), ref.term), ctx
             if stats is not None:
                 assert np.array_equal(cpu(stats[:, :n]), ref.stats), ctx
+
+
+def test_single_wave_and_pair_kernels_agree_across_the_size_switch(oracle):
+    """Human-vs-human pz_step uses the two-waves-per-64-games kernel below 262 144 games and the single-wave
+    kernel with the changed-only write-back from there on: both sides of the switch against the oracle."""
+    for n in (262144 - 64, 262144):
+        env = make_env(num_envs=n, seed=44, env_id_base=7, winning_score=1)
+        env.reset()
+        for t in range(12):
+            obs, rew, term, _, _ = env.step(env.unwrapped.random_actions(21, t))
+        for lo in (0, n - 1024):
+            ref = oracle.OracleEnv(1024, oracle.make_config(winning_score=1, seed=44, env_id_base=7 + lo), nthreads=4)
+            ref.reset()
+            for t in range(12):
+                a1, a2 = oracle.random_actions(1024, 7 + lo, 21, t)
+                robs, rrew, rterm = ref.step(a1, a2)
+            assert np.array_equal(cpu(env.unwrapped.state[:, lo:lo + 1024]), ref.state), (n, lo)
+            assert np.array_equal(cpu(obs["player_2"][lo:lo + 1024]), robs[1]), (n, lo)
+            assert np.array_equal(cpu(rew["player_1"][lo:lo + 1024]), rrew[0]), (n, lo)
+            assert np.array_equal(cpu(term["player_1"][lo:lo + 1024]).astype(np.uint8), rterm), (n, lo)
