@@ -358,7 +358,9 @@ def main():
                             f"(Philox policy stream pre-generated in HBM), winning_score=15, serve=winner, "
                             f"auto-reset, p2_computer={args.p2_computer}, fused_wrappers={args.wrappers}",
                 "num_envs_per_gpu": args.num_envs, "num_envs_total": main_res["n_total"],
-                "launch": args.launch, "kernel": "pz::step_kernel<AI1,AI2,false> via pz_step",
+                "launch": args.launch,
+                "kernel": ("pz::step_kernel<AI1,AI2,kActions,SPARSE> via pz_step"
+                           if args.p2_computer or args.num_envs >= 262144 else "pz::step_pair_kernel via pz_step"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
