@@ -271,9 +271,19 @@ static int process_collision_between_ball_and_world_and_set_ball_position(Ball *
     return 0;
 }
 
+/* Diagnostic builds only (tools/flight_trips.c defines PZO_FLIGHT_TRACE and the hook): every call of
+ * the two flight predictors is reported, so trip counts of alternative formulations can be modelled
+ * on states sampled from play. */
+#ifdef PZO_FLIGHT_TRACE
+void pzo_flight_trace(int kind, int x, int y, int xv, int yv);
+#else
+#define pzo_flight_trace(kind, x, y, xv, yv) ((void)0)
+#endif
+
 /* ---- calculate_expected_landing_point_x_for: physics.py:643-686 ----------------------- */
 static int landing_x(int x, int y, int xv, int yv)
 {
+    pzo_flight_trace(0, x, y, xv, yv);
     int loop_counter = 0;
     for (;;) {
         loop_counter += 1;
@@ -357,6 +367,7 @@ static int decide_whether_input_power_hit(Game *g, const Player *pl, const Ball 
                                           const Player *other, UserInput *in)
 {
     int ascending = rng_integers(g, 2) == 0; /* :795 */
+    pzo_flight_trace(1, b->x, b->y, 0, iabs(b->y_velocity));
     for (int x_direction = 1; x_direction > -1; --x_direction) {
         for (int j = 0; j < 3; ++j) {
             int y_direction = ascending ? (-1 + j) : (1 - j); /* :797 vs :808 */

@@ -324,30 +324,35 @@ __device__ __forceinline__ int predict_landing_x_iterative(int x, int y, int xv,
 }
 
 // Fast-forward form.  On a GPU the predictor's cost is its longest lane (a wave -- and at one
-// wave per SIMD the whole launch -- waits for the slowest flight), so the free-flight stretches
-// are jumped in closed form instead of being iterated (mean 17 / max ~110 iterations become
-// mean 2.3 / max ~16 loop trips for the landing predictor, 29 / ~215 become 4.6 / ~35 for the
-// power-hit predictor on states sampled from play).
+// wave per SIMD the whole launch -- waits for the slowest flight), so the loop runs once per
+// *event* of the flight (wall flip, ceiling clamp, hit on the net box, landing) instead of once
+// per frame: per wave and launch the longest lane needs 5.7 trips instead of 56 iterations for
+// the landing predictor and 4.3 instead of 54 for the power-hit candidates (tools/flight_trips.c,
+// states sampled from play).
 //
-// With Y(m) = y + m*yv + m(m-1)/2 and X(m) = x + m*xv the state after m "plain" iterations
-// (no wall flip, no ceiling clamp, not in the net box, no landing, cap not reached), the next
-// K iterations are all plain exactly when
+// With Y(m) = y + m*yv + m(m-1)/2 and X(m) = x + m*xv the state after m "plain" iterations (no
+// wall flip, no ceiling clamp, no box hit, no landing, cap not reached), iterations 1..K are all
+// plain exactly when
 //     20 <= X(m) <= 432   for m = 1..K    (linear: check m = K; X(0) is in range)
 //     0  <= Y(m)          for m = 1..K    (convex: check its lowest point m = clamp(-yv, 1, K);
 //                                           y itself can be negative -- the net-top bounce runs
 //                                           after the ceiling clamp and can throw a very fast
 //                                           ball above 0)
-//     Y(m) <= ymax        for m = 0..K    (convex: check both ends)
+//     Y(m) <= 252         for m = 0..K    (convex: check both ends)
+//     Y(m) <= 176 for every m in 0..K-1 with 192 <= X(m) <= 240   (iteration m+1 tests the box at
+//                                           position m.)  X is linear, so these m form one interval
+//                                           [m1, m2]; Y is convex, so its ends suffice.  The
+//                                           power-hit form's box only acts on a falling ball, so
+//                                           there the interval starts no earlier than m = 1 - yv.
 //     count + K <= 998                    (the cap test of iterations 0..K-1 stays false)
-// where ymax = 252 (only landing ends the stretch) if the ball is outside the net box
-// (x <= 191 or x >= 241) and X(0..K-1) stay on that side of it -- or, for the power-hit
-// predictor, if the ball rises during the whole stretch (its net rule only acts on yv > 0) --
-// else ymax = 176 (above the net top, where the box cannot apply).  Then x = X(K), y = Y(K), yv += K, count += K.
-// K is *proposed* in float (distance to the wall or the box edge times 1/|xv|; roots of
-// Y(K) = ymax and, for a ball whose apex would cross the ceiling, of Y(K) = 0) and *verified*
-// with the exact integer conditions above; a failed verification falls back to the single
-// iteration, so the result is identical to the iterative form by construction.
-// pz_selftest_predictor compares the two over the whole input domain on the GPU.
+// Then x = X(K), y = Y(K), yv += K, count += K, and the single reference iteration that follows is
+// the event itself.  K, m1 and m2 are *proposed* in float (distances times 1/|xv|; roots of
+// Y(K) = 252 or, for a ball whose apex would cross the ceiling, of Y(K) = 0; if the ball would be
+// inside the box on its way, the first offending position instead) and *verified* with the exact
+// integer conditions above (for m1 and m2: X(m1 - 1) has not reached the columns, X(m2 + 1) has
+// left them); a failed verification falls back to the single iteration, so the result is
+// identical to the iterative form by construction.  pz_selftest_predictor compares the two over
+// the whole input domain on the GPU.
 // 24-bit multiplies (full-rate v_mul_i32_i24 / v_mad_i32_i24; every operand here is far below 2^23)
 __device__ __forceinline__ int mul24(int a, int b)
 {
@@ -361,51 +366,59 @@ __device__ __forceinline__ int flight_height(int y, int yv, int m)
     return y + mul24(m, yv) + (mul24(m, m - 1) >> 1);
 }
 
+// far root K of Y(K) = target (near root if `near`), rounded down with a small safety margin
+__device__ __forceinline__ int flight_root(float hb, float hb2, int dy, bool near)
+{
+    const float root = __builtin_amdgcn_sqrtf(fmaxf(fmaf(8.0f, (float)dy, hb2), 0.0f));
+    return (int)(((near ? -root : root) - hb) * 0.5f - 0.001f);
+}
+
 template <bool FULL_NET>
 __device__ __forceinline__ int predict_landing_x(int x, int y, int xv, int yv)
 {
-    constexpr int kBoxLeft = kGroundHalfWidth - kNetPillarHalfWidth;   // 191: last x left of the box
-    constexpr int kBoxRight = kGroundHalfWidth + kNetPillarHalfWidth;  // 241: first x right of it
+    constexpr int kColsFirst = kGroundHalfWidth - kNetPillarHalfWidth + 1;  // 192: |x - 216| < 25
+    constexpr int kColsLast = kGroundHalfWidth + kNetPillarHalfWidth - 1;   // 240
     int count = 0;
     for (;;) {
         // ---- proposal + verification, written branch-free: in a divergent wave every trip pays
-        // for every path anyway, and straight-line code lets the lone wave overlap the two
+        // for every path anyway, and straight-line code lets the lone wave overlap the
         // transcendental chains (rcp, sqrt) with the integer work.
-        // The simplified net rule of the power-hit predictor only flips a positive y velocity, so
-        // while the ball rises (yv + j <= 0 for the whole stretch, i.e. K <= 1 - yv) the box is inert
-        // and the stretch may run through it.
-        const bool ascending = !FULL_NET && yv < 0;
-        const bool left = !ascending & (x <= kBoxLeft), right = !ascending & (x >= kBoxRight);
-        const bool outside = left | right;  // outside the box, and the box matters
-        const int ymax = (outside | ascending) ? kBallGroundY : kNetTopTopY;
         const bool rightward = xv > 0;
         const int axv = abs(xv);
-        // plain moves available along x: up to the wall, or up to the edge of the net box
-        const int edge = rightward ? (left ? kBoxLeft : kGroundWidth) : (right ? kBoxRight : kBallRadius);
-        const int room = rightward ? edge - x : x - edge;
-        const int toward_box = (rightward ? left : right) ? 1 : 0;  // outside and heading for the box
-        const float q = (float)room * __builtin_amdgcn_rcpf((float)axv);
-        const int kx = (axv ? (int)q : kLoopLimit) + toward_box;
-        // plain moves available along y: far root of Y(K) = ymax (y > ymax is rejected by `ok`) ...
-        // ... or, if the apex Y(-yv) would be above the ceiling, the near root of Y(K) = 0 (which
-        // comes first); one square root serves either: K = (s*sqrt(hb^2 + 8c) - hb) / 2
-        const float hb = (float)(2 * yv - 1);
+        const float r = __builtin_amdgcn_rcpf((float)max(axv, 1));
+        // plain moves available along x up to the wall (a still ball: `room`, which is harmless)
+        const int room = rightward ? kGroundWidth - x : x - kBallRadius;
+        const int kw = (int)fmaf((float)room, r, 0.001f);
+        // plain moves available along y: far root of Y(K) = 252, or, if the apex Y(-yv) would be
+        // above the ceiling, the near root of Y(K) = 0 (which comes first)
+        const float hb = (float)(2 * yv - 1), hb2 = hb * hb;
         const int apex = y - (mul24(yv, yv - 1) >> 1);
         const bool to_ceiling = (yv < 0) & (apex < 0);
-        const float c8 = 8.0f * (float)(to_ceiling ? -y : ymax - y);
-        const float root = __builtin_amdgcn_sqrtf(fmaxf(fmaf(hb, hb, c8), 0.0f));
-        int K = (int)(((to_ceiling ? -root : root) - hb) * 0.5f - 0.001f);
-        K = min(min(K, kx), kLoopLimit - 2 - count);
-        K = ascending ? min(K, 1 - yv) : K;
+        const int ky = flight_root(hb, hb2, to_ceiling ? -y : kBallGroundY - y, to_ceiling);
+        int K = max(min(min(kw, ky), kLoopLimit - 2 - count), 0);
+        // positions m1..m2 inside the columns of the net box, in travel coordinates: the ball is d1
+        // short of the first column and d2 short of the last one and advances |xv| per iteration
+        const int d1 = rightward ? kColsFirst - x : x - kColsLast;
+        const int d2 = d1 + (kColsLast - kColsFirst);
+        const int m1 = max((int)fmaf((float)(d1 + axv - 1), r, 0.001f), 0);
+        const int m2 = (int)floorf(fmaf((float)d2, r, 0.001f));  // < 0: already past
+        const int lo = FULL_NET ? m1 : max(m1, 1 - yv);
+        const int ylo = flight_height(y, yv, lo);
+        const bool lo_hits = ylo > kNetTopTopY;
+        // first offending position: lo itself, or the first one past the far root of Y = 176 if the
+        // ball sinks below the net top while over the box; it limits K if it is inside the columns
+        const int first_hit = lo_hits ? lo : max(lo, flight_root(hb, hb2, kNetTopTopY - y, false) + 1);
+        K = first_hit <= m2 ? min(K, first_hit) : K;
         // exact verification
         const int ye = flight_height(y, yv, K);
         const int xe = x + mul24(K, xv);
-        const int xl = xe - xv;  // X(K-1): must still be on the same side of the box when outside
         const int lowest = flight_height(y, yv, min(max(-yv, 1), K));
-        const bool side_kept = left ? xl <= kBoxLeft : (right ? xl >= kBoxRight : true);
-        const bool ok = (K >= 2) & ((unsigned)y <= (unsigned)ymax) & (abs(yv) < 4096) &
+        const int hi = min(m2, K - 1);
+        const bool box_ok = (lo > hi) | (!lo_hits & (flight_height(y, yv, hi) <= kNetTopTopY));
+        const bool cols_ok = ((m1 == 0) | (mul24(m1 - 1, axv) < d1)) & ((m2 >= K - 1) | (mul24(m2 + 1, axv) > d2));
+        const bool ok = (K >= 1) & (y <= kBallGroundY) & (abs(yv) < 4096) &
                         ((unsigned)(xe - kBallRadius) <= (unsigned)(kGroundWidth - kBallRadius)) &
-                        ((unsigned)ye <= (unsigned)ymax) & (lowest >= 0) & side_kept;
+                        ((unsigned)ye <= (unsigned)kBallGroundY) & (lowest >= 0) & box_ok & cols_ok;
         x = ok ? xe : x;
         y = ok ? ye : y;
         yv += ok ? K : 0;
