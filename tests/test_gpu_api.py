@@ -225,3 +225,64 @@ def test_record_episode_statistics_scalar_api():
         assert infos["player_1"]["episode"] == {"r": total["player_1"], "l": length}
         assert infos["player_2"]["episode"] == {"r": total["player_2"], "l": length}
         assert abs(total["player_1"]) <= 3 and total["player_1"] == -total["player_2"]
+
+
+def _fresh(n, seed, **kw):
+    from pikazoo_amd import pikazoo_v0
+
+    env = pikazoo_v0.env(num_envs=n, seed=seed, validate_actions=False, **kw)
+    env.reset()
+    return env
+
+
+def test_calls_are_ordered_on_the_callers_stream_and_envs_are_independent():
+    """include/pikazoo_hip.h: every entry point is asynchronous on the stream it is given and the
+    library keeps no global state -- two environments driven from two side streams at the same time
+    must produce what each produces alone on the default stream."""
+    n, steps = 8192, 200
+    acts = torch.randint(0, 18, (steps, 2, n), dtype=torch.int32, device="cuda")
+    alone = []
+    for seed, kw in ((3, {}), (4, {"is_player2_computer": True})):
+        env = _fresh(n, seed, **kw)
+        for t in range(steps):
+            env.step({"player_1": acts[t, 0], "player_2": acts[t, 1]})
+        alone.append(env.state.clone())
+    torch.cuda.synchronize()
+
+    envs = [_fresh(n, 3), _fresh(n, 4, is_player2_computer=True)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for t in range(steps):
+        for env, s in zip(envs, streams):
+            with torch.cuda.stream(s):
+                env.step({"player_1": acts[t, 0], "player_2": acts[t, 1]})
+    for s in streams:
+        s.synchronize()
+    for env, want in zip(envs, alone):
+        assert torch.equal(env.state, want)
+
+
+def test_graph_replay_equals_eager_launches():
+    """bench.py replays K captured pz_step launches (hipGraph); the replayed trajectory must be the
+    eager one, including the outputs left in the environment's buffers."""
+    n, k = 65536, 64
+    acts = torch.randint(0, 18, (k, 2, n), dtype=torch.int32, device="cuda")
+    eager = _fresh(n, 9)
+    for t in range(k):
+        obs, rew, term, _, _ = eager.step({"player_1": acts[t, 0], "player_2": acts[t, 1]})
+    want_state = eager.state.clone()
+    want_obs, want_rew, want_term = obs["player_1"].clone(), rew["player_1"].clone(), term["player_1"].clone()
+
+    env = _fresh(n, 9)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+            for t in range(k):
+                obs, rew, term, _, _ = env.step({"player_1": acts[t, 0], "player_2": acts[t, 1]})
+        graph.replay()
+    side.synchronize()
+    assert torch.equal(env.state, want_state)
+    assert torch.equal(obs["player_1"], want_obs) and torch.equal(rew["player_1"], want_rew)
+    assert torch.equal(term["player_1"], want_term)
