@@ -378,14 +378,18 @@ __device__ __forceinline__ int predict_landing_x(int x, int y, int xv, int yv)
 {
     constexpr int kColsFirst = kGroundHalfWidth - kNetPillarHalfWidth + 1;  // 192: |x - 216| < 25
     constexpr int kColsLast = kGroundHalfWidth + kNetPillarHalfWidth - 1;   // 240
+    // Inputs outside what the 24-bit products are sized for, or below the ground line (neither is
+    // produced by play), take the plain loop.  Inside the range |yv| cannot grow past it: a flight
+    // only gains speed while falling 252 rows at most.
+    if (abs(yv) >= 2048 || y > kBallGroundY) return predict_landing_x_iterative<FULL_NET>(x, y, xv, yv);
+    const int axv = abs(xv);  // invariant: the rules only ever flip the sign of xv
+    const float r = __builtin_amdgcn_rcpf((float)max(axv, 1));
     int count = 0;
     for (;;) {
         // ---- proposal + verification, written branch-free: in a divergent wave every trip pays
         // for every path anyway, and straight-line code lets the lone wave overlap the
         // transcendental chains (rcp, sqrt) with the integer work.
         const bool rightward = xv > 0;
-        const int axv = abs(xv);
-        const float r = __builtin_amdgcn_rcpf((float)max(axv, 1));
         // plain moves available along x up to the wall (a still ball: `room`, which is harmless)
         const int room = rightward ? kGroundWidth - x : x - kBallRadius;
         const int kw = (int)fmaf((float)room, r, 0.001f);
@@ -412,12 +416,11 @@ __device__ __forceinline__ int predict_landing_x(int x, int y, int xv, int yv)
         // exact verification
         const int ye = flight_height(y, yv, K);
         const int xe = x + mul24(K, xv);
-        const int lowest = flight_height(y, yv, min(max(-yv, 1), K));
+        const int lowest = yv < 0 ? (K >= -yv ? apex : ye) : y + yv;  // Y(clamp(-yv, 1, K))
         const int hi = min(m2, K - 1);
         const bool box_ok = (lo > hi) | (!lo_hits & (flight_height(y, yv, hi) <= kNetTopTopY));
         const bool cols_ok = ((m1 == 0) | (mul24(m1 - 1, axv) < d1)) & ((m2 >= K - 1) | (mul24(m2 + 1, axv) > d2));
-        const bool ok = (K >= 1) & (y <= kBallGroundY) & (abs(yv) < 4096) &
-                        ((unsigned)(xe - kBallRadius) <= (unsigned)(kGroundWidth - kBallRadius)) &
+        const bool ok = (K >= 1) & ((unsigned)(xe - kBallRadius) <= (unsigned)(kGroundWidth - kBallRadius)) &
                         ((unsigned)ye <= (unsigned)kBallGroundY) & (lowest >= 0) & box_ok & cols_ok;
         x = ok ? xe : x;
         y = ok ? ye : y;
