@@ -314,17 +314,24 @@ __device__ __forceinline__ void stage_obs(const Game& g, int32_t* __restrict__ s
         stage_obs_t<false>(g, s1, s2, lane);
 }
 
-// Copy the wave's 64 staged rows (8 960 B) to its span of an [n][35] tensor: 9 passes of
-// 16 B per lane.  `wave_off` = byte offset of the span (uniform); the descriptor ends at row n,
-// so the rows of lanes past the end of the batch are dropped by the range check.
-__device__ __forceinline__ void flush_rows(const int32_t* __restrict__ lds, Rsrc obs, uint32_t wave_off, int lane)
+// Copy the wave's 64 staged rows (8 960 B) to its span of an [n][35] tensor (`tensor_bytes` = n rows):
+// 9 passes of 16 B per lane.  The span gets its own descriptor, which ends at row n, so the rows of
+// lanes past the end of the batch are dropped by the range check -- and the stores carry no SGPR offset.
+// That matters: for a buffer store of more than 64 bits WITH an SGPR offset the compiler assumes no
+// wait state is needed before a VALU write of the store's data registers (LLVM
+// GCNHazardRecognizer::createsVALUHazard) and schedules e.g. the next address computation into
+// them; on gfx950 a quarter of the wave then stores the new value (seen as address bits in
+// observation words).  tests/test_cabi_and_host.py scans the built code object for that pattern.
+__device__ __forceinline__ void flush_rows(const int32_t* __restrict__ lds, const void* tensor, uint32_t tensor_bytes,
+                                           int lane)
 {
+    const uint32_t wave_off = blockIdx.x * kWaveObsBytes;
+    const Rsrc span = make_rsrc(static_cast<const char*>(tensor) + wave_off, tensor_bytes - wave_off);
     const u32x4* src4 = reinterpret_cast<const u32x4*>(lds);
 #pragma unroll
     for (int pass = 0; pass < (kWaveObsVecs + kLanes - 1) / kLanes; ++pass) {
         const int v = pass * kLanes + lane;
-        if (v < kWaveObsVecs)
-            __builtin_amdgcn_raw_buffer_store_b128(src4[v], obs, (uint32_t)v * 16u, wave_off, PZ_OBS_AUX);
+        if (v < kWaveObsVecs) __builtin_amdgcn_raw_buffer_store_b128(src4[v], span, (uint32_t)v * 16u, 0, PZ_OBS_AUX);
     }
 }
 
@@ -442,19 +449,74 @@ __device__ __forceinline__ void emit_outputs(const StepArgs& a, const Game& g, c
     __syncthreads();
     PZ_STAMP(4);
     if (!skip_obs) {
-        const uint32_t wave_off = blockIdx.x * kWaveObsBytes;
-        flush_rows(lds_obs[0], make_rsrc(a.obs_p1 + t * a.n * PZ_OBS_DIM, n32 * kRowBytes), wave_off, lane);
-        flush_rows(lds_obs[1], make_rsrc(a.obs_p2 + t * a.n * PZ_OBS_DIM, n32 * kRowBytes), wave_off, lane);
+        flush_rows(lds_obs[0], a.obs_p1 + t * a.n * PZ_OBS_DIM, n32 * kRowBytes, lane);
+        flush_rows(lds_obs[1], a.obs_p2 + t * a.n * PZ_OBS_DIM, n32 * kRowBytes, lane);
     }
 }
 
-template <bool AI1, bool AI2, int MODE, bool SPARSE>
-__global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
+// The scout wave of step_kernel<..., SCOUT>: for its workgroup's 64 games it loads just what decides
+// whether a computer player will scan the power-hit directions this frame (the ball, the computer
+// players' x / y / state, the two round flags), advances the ball like the frame will, and evaluates the
+// six candidate flights of every such game cooperatively -- while the main wave is still loading the
+// 44 columns, starting rounds and predicting the landing point.  A game whose round (re)starts this
+// frame never scans (its players are put back on the ground), so the scout skips it.
+template <bool AI1, bool AI2>
+__device__ __forceinline__ void scout_candidates(const StepArgs& a, int32_t* __restrict__ cand,
+                                                 int32_t* __restrict__ scratch, int lane)
 {
+    const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
+    const StateIO io{make_rsrc(a.state, (uint32_t)(a.stride * (PZ_STATE_WORDS * 4))), (uint32_t)a.stride * 4u,
+                     (uint32_t)i * 4u};
+    Ball b{};
+    Player p1{}, p2{};
+    bool need = false;
+    if (i < a.n) {
+        const int round_ended = io.ld(PZ_E_ROUND_ENDED);  // game_ended implies round_ended
+        b.x = io.ld(PZ_B_X);
+        b.y = io.ld(PZ_B_Y);
+        b.xv = io.ld(PZ_B_X_VELOCITY);
+        b.yv = io.ld(PZ_B_Y_VELOCITY);
+        if (AI1) {
+            p1.x = io.ld(PZ_P_X);
+            p1.y = io.ld(PZ_P_Y);
+            p1.state = io.ld(PZ_P_STATE);
+        }
+        if (AI2) {
+            p2.x = io.ld(PZ_P_WORDS + PZ_P_X);
+            p2.y = io.ld(PZ_P_WORDS + PZ_P_Y);
+            p2.state = io.ld(PZ_P_WORDS + PZ_P_STATE);
+        }
+        if (!round_ended) {
+            ball_world_step(b);
+            need = (AI1 && power_hit_scan_needed(p1, b)) || (AI2 && power_hit_scan_needed(p2, b));
+        }
+    }
+    int ex[6] = {0, 0, 0, 0, 0, 0};
+    wave_power_hit_candidates<false>(need, b, ex, scratch, lane);
+    if (need) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) cand[lane * kCandPitch + c] = ex[c];
+    }
+}
+
+// SCOUT (single-frame launches with a computer player, below the sparse write-back threshold): the
+// workgroup has a second wave that only evaluates the power-hit candidates (scout_candidates).
+template <bool AI1, bool AI2, int MODE, bool SPARSE, bool SCOUT = false>
+__global__ __launch_bounds__(SCOUT ? 2 * kLanes : kLanes) void step_kernel(const StepArgs a)
+{
+    static_assert(!SCOUT || (MODE == kActions && (AI1 || AI2)), "the scout wave serves single-frame AI launches");
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     __shared__ int32_t tape_lds[MODE == kTape ? kTapeChunk * 2 * kLanes : 1];  // parked action tape (kTape only)
+    __shared__ int32_t cand[SCOUT ? kLanes * kCandPitch : 1];
+    __shared__ int32_t scout_scratch[SCOUT ? 576 : 1];
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kLanes - 1);
+    if (SCOUT && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) {
+        scout_candidates<AI1, AI2>(a, cand, scout_scratch, lane);
+        __syncthreads();  // step_games: candidates handed over
+        __syncthreads();  // emit_outputs: observation rows staged (this wave has none)
+        return;
+    }
     const int64_t base = (int64_t)blockIdx.x * kLanes;
     const int64_t i = base + lane;
     const bool live = i < a.n;
@@ -538,7 +600,7 @@ __global__ __launch_bounds__(kLanes) void step_kernel(const StepArgs a)
         }
     } else if (!PZ_SKIP_FRAME) {
         const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
-        reward = step_games<AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane);
+        reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane, cand);
         finished = (unsigned int)(live && g.e.game_ended && !frozen);
         rw = shape_rewards(a.cfg, g, reward, frozen);
         if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
@@ -668,8 +730,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, int32_t (*lds_obs)[
             stage_one_obs_t<false>(me, opp, g.b, lds_obs[ROLE], lane);
     }
     __syncthreads();
-    flush_rows(lds_obs[ROLE], make_rsrc(ROLE == 0 ? a.obs_p1 : a.obs_p2, n32 * kRowBytes),
-               blockIdx.x * kWaveObsBytes, lane);
+    flush_rows(lds_obs[ROLE], ROLE == 0 ? a.obs_p1 : a.obs_p2, n32 * kRowBytes, lane);
 }
 
 __global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(const StepArgs a)
@@ -723,9 +784,8 @@ __global__ __launch_bounds__(kLanes) void reset_kernel(int32_t* state, int64_t n
         stage_obs(g, lds_obs[0], lds_obs[1], lane, cfg.normalize_obs != 0);
     }
     __syncthreads();
-    const uint32_t wave_off = blockIdx.x * kWaveObsBytes;
-    if (obs_p1 != nullptr) flush_rows(lds_obs[0], make_rsrc(obs_p1, (uint32_t)n * kRowBytes), wave_off, lane);
-    if (obs_p2 != nullptr) flush_rows(lds_obs[1], make_rsrc(obs_p2, (uint32_t)n * kRowBytes), wave_off, lane);
+    if (obs_p1 != nullptr) flush_rows(lds_obs[0], obs_p1, (uint32_t)n * kRowBytes, lane);
+    if (obs_p2 != nullptr) flush_rows(lds_obs[1], obs_p2, (uint32_t)n * kRowBytes, lane);
 }
 
 __global__ __launch_bounds__(kLanes) void observe_kernel(const int32_t* state, int64_t n, int64_t stride,
@@ -742,9 +802,8 @@ __global__ __launch_bounds__(kLanes) void observe_kernel(const int32_t* state, i
         stage_obs(g, lds_obs[0], lds_obs[1], lane, normalize != 0);
     }
     __syncthreads();
-    const uint32_t wave_off = blockIdx.x * kWaveObsBytes;
-    if (obs_p1 != nullptr) flush_rows(lds_obs[0], make_rsrc(obs_p1, (uint32_t)n * kRowBytes), wave_off, lane);
-    if (obs_p2 != nullptr) flush_rows(lds_obs[1], make_rsrc(obs_p2, (uint32_t)n * kRowBytes), wave_off, lane);
+    if (obs_p1 != nullptr) flush_rows(lds_obs[0], obs_p1, (uint32_t)n * kRowBytes, lane);
+    if (obs_p2 != nullptr) flush_rows(lds_obs[1], obs_p2, (uint32_t)n * kRowBytes, lane);
 }
 
 __global__ __launch_bounds__(256) void random_actions_kernel(int32_t* act_p1, int32_t* act_p2, int64_t n,
@@ -820,6 +879,19 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
     if (MODE == kActions && a.n < kSparseWritebackMinLanes && a.cfg.p1_computer == 0 && a.cfg.p2_computer == 0) {
         hipLaunchKernelGGL(step_pair_kernel, dim3(blocks_for(a.n, kLanes)), dim3(2 * kLanes), 0, stream, a);
         return (int)hipGetLastError();
+    }
+#endif
+#if !defined(PZ_NO_SCOUT_WAVE) && !defined(PZ_ABLATE) && !defined(PZ_STAMPS)
+    if (MODE == kActions && a.n < kSparseWritebackMinLanes) {  // a computer player is present (else: pair kernel)
+        const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
+        const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
+        if (ai1 && ai2)
+            hipLaunchKernelGGL((step_kernel<true, true, kActions, false, true>), grid, block, 0, stream, a);
+        else if (ai1)
+            hipLaunchKernelGGL((step_kernel<true, false, kActions, false, true>), grid, block, 0, stream, a);
+        else if (ai2)
+            hipLaunchKernelGGL((step_kernel<false, true, kActions, false, true>), grid, block, 0, stream, a);
+        if (ai1 || ai2) return (int)hipGetLastError();
     }
 #endif
     // a rollout writes the state once per k frames: the plain write-back is always right there

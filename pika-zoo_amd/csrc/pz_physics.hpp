@@ -516,9 +516,32 @@ __device__ __forceinline__ HitScan computer_decide_begin(Player& p, const Ball& 
 __device__ __forceinline__ int candidate_xdir(int c) { return c < 3 ? 1 : 0; }
 __device__ __forceinline__ int candidate_ydir(int c) { return (c < 3 ? c : c - 3) - 1; }
 
+// LDS hand-over between the lanes of ONE wave.  LONE_WAVE: the workgroup is this wave, so the
+// workgroup barrier is the cheapest correct statement of it.  Otherwise (the scout wave of
+// step_kernel<..., SCOUT>) the other wave must not be involved: a wave's LDS instructions execute
+// in issue order, so only the compiler has to be kept from reordering them.
+template <bool LONE_WAVE>
+__device__ __forceinline__ void wave_lds_handover()
+{
+    if (LONE_WAVE) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The lanes whose computer player will scan the power-hit directions this frame (:757-758 via
+// :796-816): a pure function of the player before its move and of the ball after the world step.
+__device__ __forceinline__ bool power_hit_scan_needed(const Player& p, const Ball& b)
+{
+    return (p.state == 1 || p.state == 2) && abs(b.x - p.x) < 48 && abs(b.y - p.y) < 48;
+}
+
 // Wave-cooperative evaluation of expected_landing_point_x_when_power_hit (:820-884) for the six
-// candidates of every lane with `need`.  Must be called by all 64 lanes of the (single-wave)
-// workgroup in uniform control flow.  scratch: >= 576 words of LDS.
+// candidates of every lane with `need`.  Must be called by all 64 lanes of a wave in uniform
+// control flow.  scratch: >= 576 words of LDS owned by this wave.
+template <bool LONE_WAVE = true>
 __device__ __forceinline__ void wave_power_hit_candidates(bool need, const Ball& b, int (&ex)[6],
                                                           int32_t* __restrict__ scratch, int lane)
 {
@@ -531,7 +554,7 @@ __device__ __forceinline__ void wave_power_hit_candidates(bool need, const Ball&
         scratch[64 + rank] = b.y;
         scratch[128 + rank] = abs(b.yv);
     }
-    __syncthreads();
+    wave_lds_handover<LONE_WAVE>();
     const int items = deciders * 6;
     for (int first = 0; first < items; first += PZ_WAVE_GAMES) {
         const int item = first + lane;
@@ -544,12 +567,12 @@ __device__ __forceinline__ void wave_power_hit_candidates(bool need, const Ball&
             scratch[192 + item] = PZ_ABLATE_SKIP(64) ? sx : predict_landing_x<false>(sx, sy, sxv, syv);
         }
     }
-    __syncthreads();
+    wave_lds_handover<LONE_WAVE>();
     if (need) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) ex[c] = scratch[192 + rank * 6 + c];
     }
-    __syncthreads();  // scratch is reused (observation staging)
+    wave_lds_handover<LONE_WAVE>();  // scratch is reused (observation staging)
 }
 
 template <bool IS_P2>
@@ -698,9 +721,15 @@ __device__ __forceinline__ void ball_player_collision(Ball& b, bool hit, int pla
 // the end of the batch.  Returns player_1's reward (+1/-1/0); player_2's is its negation.
 // `frozen` (auto_reset off and the game already over) leaves the game untouched.
 // ---------------------------------------------------------------------------------------
-template <bool AI1, bool AI2>
+// SCOUT: a second wave of the workgroup (scout_candidates) evaluates the power-hit candidates while
+// this wave loads, starts rounds and predicts the landing point; they are picked up from `cand`
+// ([64][kCandPitch] words of LDS) behind one workgroup barrier.
+constexpr int kCandPitch = 7;  // six landing points per game, odd pitch
+
+template <bool AI1, bool AI2, bool SCOUT = false>
 __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
-                                          bool& frozen, int32_t* __restrict__ scratch, int lane)
+                                          bool& frozen, int32_t* __restrict__ scratch, int lane,
+                                          const int32_t* __restrict__ cand = nullptr)
 {
     // The reference empties `agents` on termination (:237-238) and expects reset() before the
     // next step; auto_reset applies reset() (:149-164) in place.  Both that and the new-round
@@ -749,7 +778,15 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
         HitScan hs{false, false};
         int ex[6] = {0, 0, 0, 0, 0, 0};
         if (active) hs = computer_decide_begin<false>(g.p1, g.b, in1, id, g.e.rng);
-        wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
+        if (SCOUT) {
+            __syncthreads();  // the scout's candidates are in place
+            if (hs.need) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) ex[c] = cand[lane * kCandPitch + c];
+            }
+        } else {
+            wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
+        }
         computer_decide_finish<false>(hs, ex, g.p1, g.p2, in1);
     }
     if (active) player_move<false>(g.p1, in1);
@@ -758,7 +795,15 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
         HitScan hs{false, false};
         int ex[6] = {0, 0, 0, 0, 0, 0};
         if (active) hs = computer_decide_begin<true>(g.p2, g.b, in2, id, g.e.rng);
-        wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
+        if (SCOUT) {
+            if (!AI1) __syncthreads();  // (with two computer players the barrier above already passed)
+            if (hs.need) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) ex[c] = cand[lane * kCandPitch + c];
+            }
+        } else {
+            wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
+        }
         computer_decide_finish<true>(hs, ex, g.p2, g.p1, in2);
     }
 

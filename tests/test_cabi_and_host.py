@@ -164,3 +164,38 @@ def test_argument_validation_without_a_gpu(built_lib):
     assert lib.pz_step_random(fake, 0, 0, C.byref(cfg), 1, 0, 0, fake, fake, fake, fake, fake, None, None, None) == -2
     assert lib.pz_observe(fake, 0, 0, 0, C.c_void_p(4100), fake, None) == -4   # PZ_E_ALIGN
     assert lib.pz_step(fake, 0, 0, C.byref(cfg), fake, fake, fake, fake, fake, fake, fake, None, None) == 0
+
+
+def test_no_vmem_store_data_hazard_in_device_code(built_lib, tmp_path):
+    """A buffer store of more than 64 bits must not be followed directly by a VALU write of its data
+    registers.  The compiler only guards that pattern for stores without an SGPR offset (LLVM
+    GCNHazardRecognizer::createsVALUHazard); on gfx950 a store WITH one was seen picking up the new
+    value in a quarter of the wave (observation words holding address bits).  flush_rows therefore
+    uses per-wave descriptors with no SGPR offset; this scans the shipped code object so that a future
+    kernel change cannot bring the pattern back unnoticed."""
+    import shutil
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    lib = shutil.copy(built_lib, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, cwd=tmp_path, capture_output=True)
+    objs = [p for p in tmp_path.iterdir() if "gfx950" in p.name]
+    assert len(objs) == 1, [p.name for p in tmp_path.iterdir()]
+    asm = subprocess.run([objdump, "-d", str(objs[0])], check=True, capture_output=True, text=True).stdout
+    ins = [m.group(1) for m in (re.match(r"^\s+([a-z_0-9]+ .*?)\s*//", line) for line in asm.splitlines()) if m]
+    stores = hazards = 0
+    for k, text in enumerate(ins):
+        m = re.match(r"(?:buffer|global|flat|scratch)_store_dwordx[34] (?:v\d+, |off, )?v\[(\d+):(\d+)\]", text)
+        m = m or re.match(r"buffer_store_dwordx[34] v\[(\d+):(\d+)\]", text)
+        if not m:
+            continue
+        stores += 1
+        lo, hi = int(m.group(1)), int(m.group(2))
+        for nxt in ins[k + 1:k + 3]:  # two issue slots cover the one (gfx90a: two) required wait states
+            w = re.match(r"v_(?!cmp|nop|readfirstlane|readlane)\w+ (?:v\[(\d+):(\d+)\]|v(\d+))", nxt)
+            if w:
+                a, b = (int(w.group(1)), int(w.group(2))) if w.group(1) else (int(w.group(3)),) * 2
+                hazards += not (b < lo or a > hi)
+    assert stores > 100, "the scan did not see the observation stores"
+    assert hazards == 0

@@ -666,18 +666,24 @@ def test_randomized_config_sweep_vs_oracle(oracle):
                 assert np.array_equal(cpu(stats[:, :n]), ref.stats), ctx
 
 
-def test_single_wave_and_pair_kernels_agree_across_the_size_switch(oracle):
-    """Human-vs-human pz_step uses the two-waves-per-64-games kernel below 262 144 games and the single-wave
-    kernel with the changed-only write-back from there on: both sides of the switch against the oracle."""
+@pytest.mark.parametrize("kw,steps", [
+    (dict(winning_score=1), 12),
+    (dict(winning_score=1, is_player2_computer=True), 60),
+    (dict(winning_score=1, is_player1_computer=True, is_player2_computer=True, serve="random"), 60),
+])
+def test_two_wave_and_single_wave_kernels_agree_across_the_size_switch(kw, steps, oracle):
+    """Below 262 144 games pz_step runs two waves per 64 games (human-vs-human: split by player; with a
+    computer player: a scout wave for the power-hit candidates); from there on the single-wave kernel with
+    the changed-only write-back: both sides of the switch against the oracle."""
     for n in (262144 - 64, 262144):
-        env = make_env(num_envs=n, seed=44, env_id_base=7, winning_score=1)
+        env = make_env(num_envs=n, seed=44, env_id_base=7, **kw)
         env.reset()
-        for t in range(12):
+        for t in range(steps):
             obs, rew, term, _, _ = env.step(env.unwrapped.random_actions(21, t))
         for lo in (0, n - 1024):
-            ref = oracle.OracleEnv(1024, oracle.make_config(winning_score=1, seed=44, env_id_base=7 + lo), nthreads=4)
+            ref = oracle.OracleEnv(1024, oracle.make_config(seed=44, env_id_base=7 + lo, **kw), nthreads=4)
             ref.reset()
-            for t in range(12):
+            for t in range(steps):
                 a1, a2 = oracle.random_actions(1024, 7 + lo, 21, t)
                 robs, rrew, rterm = ref.step(a1, a2)
             assert np.array_equal(cpu(env.unwrapped.state[:, lo:lo + 1024]), ref.state), (n, lo)
