@@ -137,7 +137,8 @@ __device__ __forceinline__ void store_player(const Player& p, const StateIO& io,
     io.st(c0 + PZ_P_POWER_HIT_KEY_IS_DOWN_PREVIOUS, p.hitprev);
 }
 
-__device__ __forceinline__ void store_game(const Game& g, const StateIO& io)
+// skip_ex: the lane's expected_landing_point_x is stored by the scout wave (step_games<..., SCOUT>)
+__device__ __forceinline__ void store_game(const Game& g, const StateIO& io, bool skip_ex = false)
 {
     store_player(g.p1, io, 0);
     store_player(g.p2, io, PZ_P_WORDS);
@@ -151,7 +152,7 @@ __device__ __forceinline__ void store_game(const Game& g, const StateIO& io)
     io.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
     io.st(PZ_B_PREVIOUS_PREVIOUS_Y, g.b.ppy);
     io.st(PZ_B_FINE_ROTATION, g.b.rot);
-    io.st(PZ_B_EXPECTED_LANDING_POINT_X, g.b.ex);
+    if (!skip_ex) io.st(PZ_B_EXPECTED_LANDING_POINT_X, g.b.ex);
     io.st(PZ_B_PUNCH_EFFECT_X, g.b.punch);
     io.st(PZ_E_SCORE_P1, g.e.s1);
     io.st(PZ_E_SCORE_P2, g.e.s2);
@@ -499,8 +500,22 @@ __device__ __forceinline__ void scout_candidates(const StepArgs& a, int32_t* __r
     }
 }
 
+// The scout's second job: the landing point of the balls a player hit this frame (physics.py:331-332),
+// posted by the main wave at the end of its frame; the scout stores the state column itself, beside the
+// main wave's scoring, write-back and observation pack.
+__device__ __forceinline__ void scout_landing_after_hits(const StepArgs& a, const int32_t* __restrict__ hits, int lane)
+{
+    const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
+    const StateIO io{make_rsrc(a.state, (uint32_t)(a.stride * (PZ_STATE_WORDS * 4))), (uint32_t)a.stride * 4u,
+                     (uint32_t)i * 4u};
+    const int32_t* slot = hits + lane * kHitPitch;
+    if (slot[0] != 0)  // only ever set for lanes inside the batch
+        io.st(PZ_B_EXPECTED_LANDING_POINT_X, predict_landing_x<true>(slot[1], slot[2], slot[3], slot[4]));
+}
+
 // SCOUT (single-frame launches with a computer player, below the sparse write-back threshold): the
-// workgroup has a second wave that only evaluates the power-hit candidates (scout_candidates).
+// workgroup has a second wave for the flight predictions that can run beside the frame
+// (scout_candidates, scout_landing_after_hits).
 template <bool AI1, bool AI2, int MODE, bool SPARSE, bool SCOUT = false>
 __global__ __launch_bounds__(SCOUT ? 2 * kLanes : kLanes) void step_kernel(const StepArgs a)
 {
@@ -508,12 +523,15 @@ __global__ __launch_bounds__(SCOUT ? 2 * kLanes : kLanes) void step_kernel(const
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     __shared__ int32_t tape_lds[MODE == kTape ? kTapeChunk * 2 * kLanes : 1];  // parked action tape (kTape only)
     __shared__ int32_t cand[SCOUT ? kLanes * kCandPitch : 1];
+    __shared__ int32_t hits[SCOUT ? kLanes * kHitPitch : 1];
     __shared__ int32_t scout_scratch[SCOUT ? 576 : 1];
 
     const int lane = threadIdx.x & (kLanes - 1);
     if (SCOUT && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) {
         scout_candidates<AI1, AI2>(a, cand, scout_scratch, lane);
         __syncthreads();  // step_games: candidates handed over
+        __syncthreads();  // step_games: collided balls posted
+        scout_landing_after_hits(a, hits, lane);
         __syncthreads();  // emit_outputs: observation rows staged (this wave has none)
         return;
     }
@@ -534,6 +552,7 @@ __global__ __launch_bounds__(SCOUT ? 2 * kLanes : kLanes) void step_kernel(const
     const RngId id = make_rng_id(a.cfg, live ? i : 0);
     int reward = 0;
     bool frozen = false;
+    bool ex_pending = false;  // SCOUT: the scout wave stores this lane's expected_landing_point_x
     unsigned int finished = 0;
 #ifdef PZ_ABLATE
     g_pz_ablate_bits = a.cfg.reserved;  // every lane stores the same value; read by the predictor hooks
@@ -600,7 +619,8 @@ __global__ __launch_bounds__(SCOUT ? 2 * kLanes : kLanes) void step_kernel(const
         }
     } else if (!PZ_SKIP_FRAME) {
         const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
-        reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane, cand);
+        reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane,
+                                             ScoutLink{cand, hits}, &ex_pending);
         finished = (unsigned int)(live && g.e.game_ended && !frozen);
         rw = shape_rewards(a.cfg, g, reward, frozen);
         if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
@@ -610,7 +630,7 @@ __global__ __launch_bounds__(SCOUT ? 2 * kLanes : kLanes) void step_kernel(const
         if (SPARSE)
             store_game_changed(g, loaded, io);
         else
-            store_game(g, io);
+            store_game(g, io, ex_pending);
         if (with_stats) {
             sio.st(0, (int)st.r1);
             sio.st(1, (int)st.r2);

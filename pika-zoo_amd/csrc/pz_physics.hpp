@@ -721,15 +721,24 @@ __device__ __forceinline__ void ball_player_collision(Ball& b, bool hit, int pla
 // the end of the batch.  Returns player_1's reward (+1/-1/0); player_2's is its negation.
 // `frozen` (auto_reset off and the game already over) leaves the game untouched.
 // ---------------------------------------------------------------------------------------
-// SCOUT: a second wave of the workgroup (scout_candidates) evaluates the power-hit candidates while
-// this wave loads, starts rounds and predicts the landing point; they are picked up from `cand`
-// ([64][kCandPitch] words of LDS) behind one workgroup barrier.
+// SCOUT: a second wave of the workgroup takes the flight predictions that can run beside this one
+// (pz_kernels.hip: scout_candidates, scout_landing_after_hits):
+//   * the power-hit candidates, evaluated while this wave loads, starts rounds and predicts the landing
+//     point; picked up from link.cand behind one workgroup barrier;
+//   * the landing point after a ball-player collision (:331-332), which nothing in the frame reads any
+//     more: the collided ball is posted in link.hits behind a second barrier at the end of the frame,
+//     the scout predicts and stores the state column itself, and `ex_pending` tells the caller not to.
 constexpr int kCandPitch = 7;  // six landing points per game, odd pitch
+constexpr int kHitPitch = 5;   // flag, x, y, x velocity, y velocity
+struct ScoutLink {
+    const int32_t* cand;  // LDS [64][kCandPitch]
+    int32_t* hits;        // LDS [64][kHitPitch]
+};
 
 template <bool AI1, bool AI2, bool SCOUT = false>
 __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
                                           bool& frozen, int32_t* __restrict__ scratch, int lane,
-                                          const int32_t* __restrict__ cand = nullptr)
+                                          const ScoutLink link = ScoutLink{nullptr, nullptr}, bool* ex_pending = nullptr)
 {
     // The reference empties `agents` on termination (:237-238) and expects reset() before the
     // next step; auto_reset applies reset() (:149-164) in place.  Both that and the new-round
@@ -782,7 +791,7 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
             __syncthreads();  // the scout's candidates are in place
             if (hs.need) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) ex[c] = cand[lane * kCandPitch + c];
+                for (int c = 0; c < 6; ++c) ex[c] = link.cand[lane * kCandPitch + c];
             }
         } else {
             wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
@@ -799,7 +808,7 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
             if (!AI1) __syncthreads();  // (with two computer players the barrier above already passed)
             if (hs.need) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) ex[c] = cand[lane * kCandPitch + c];
+                for (int c = 0; c < 6; ++c) ex[c] = link.cand[lane * kCandPitch + c];
             }
         } else {
             wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
@@ -808,6 +817,7 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
     }
 
     int reward = 0;
+    bool hit_for_scout = false;
     if (active) {
         player_move<true>(g.p2, in2);
         PZ_FRAME_STAMP(5);
@@ -823,7 +833,10 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
         if ((AI1 || AI2) && hit_processed) {
             // :331-332 -- when both players hit in one frame the second evaluation overwrites the
             // first, so a single one after both collisions leaves the same value.
-            g.b.ex = PZ_ABLATE_SKIP(128) ? g.b.x : predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
+            if (SCOUT)
+                hit_for_scout = true;
+            else
+                g.b.ex = PZ_ABLATE_SKIP(128) ? g.b.x : predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
         }
 
         PZ_FRAME_STAMP(6);
@@ -835,6 +848,18 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
         g.e.game_ended = ground & ((p2_scores ? g.e.s2 : g.e.s1) >= cfg.winning_score);
         g.e.round_ended = ground;
         reward = ground ? (p2_scores ? -1 : 1) : 0;
+    }
+    if (SCOUT) {
+        int32_t* slot = link.hits + lane * kHitPitch;
+        slot[0] = hit_for_scout;
+        if (hit_for_scout) {
+            slot[1] = g.b.x;
+            slot[2] = g.b.y;
+            slot[3] = g.b.xv;
+            slot[4] = g.b.yv;
+        }
+        __syncthreads();  // collided balls posted
+        *ex_pending = hit_for_scout;
     }
     PZ_FRAME_STAMP(7);
     return reward;
