@@ -249,12 +249,12 @@ def measure(args, shard, device, p2_computer, wrappers, launch, with_cpu):
     return res
 
 
-def measure_rollout(args, shard, device, k, tape=False):
+def measure_rollout(args, shard, device, k, tape=False, p2_computer=False):
     """pz_rollout_random (or, tape=True, pz_step_many on a pre-generated action tape): k frames per
     launch, every frame's outputs written to trajectory tensors (state in registers, read/written once
     per launch).  Honest bytes per game-step of THESE kernels: 297 (8 of them action words written
     resp. read) + 352/k."""
-    env = make_env(args, shard, False, False, device)
+    env = make_env(args, shard, p2_computer, False, device)
     raw = env.unwrapped
     env.reset()
     launches = max(1, args.steps // k)
@@ -329,6 +329,7 @@ def main():
             extra[key] = {"value": r["value"], "launch_us": r["launch_us"]}
         extra["rollout_k32"] = measure_rollout(args, shard, device, k=32)
         extra["step_many_k32"] = measure_rollout(args, shard, device, k=32, tape=True)
+        extra["rollout_k32_p2_computer"] = measure_rollout(args, shard, device, k=32, p2_computer=True)
         # the same kernel at larger batches (more waves per SIMD hide each other's latency)
         sweep = {}
         for n_big in (262144, 524288, 1048576):

@@ -604,7 +604,13 @@ __global__ __launch_bounds__(SCOUT ? 2 * kLanes : kLanes) void step_kernel(const
                 policy_actions(id.id_lo, id.id_hi, a.action_seed, a.t0 + (uint64_t)s, n_actions, a1, a2);
             }
             const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
-            reward = step_games<AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane);
+#ifdef PZ_PREDICT_EVERY_HIT
+            const bool last_frame = true;
+#else
+            const bool last_frame = s == a.k - 1;
+#endif
+            reward = step_games<AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane, ScoutLink{nullptr, nullptr},
+                                          nullptr, last_frame);
             finished += (unsigned int)(live && g.e.game_ended && !frozen);
             rw = shape_rewards(a.cfg, g, reward, frozen);
             if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);

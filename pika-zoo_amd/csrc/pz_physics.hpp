@@ -738,7 +738,8 @@ struct ScoutLink {
 template <bool AI1, bool AI2, bool SCOUT = false>
 __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
                                           bool& frozen, int32_t* __restrict__ scratch, int lane,
-                                          const ScoutLink link = ScoutLink{nullptr, nullptr}, bool* ex_pending = nullptr)
+                                          const ScoutLink link = ScoutLink{nullptr, nullptr}, bool* ex_pending = nullptr,
+                                          const bool last_frame = true)
 {
     // The reference empties `agents` on termination (:237-238) and expects reset() before the
     // next step; auto_reset applies reset() (:149-164) in place.  Both that and the new-round
@@ -830,14 +831,6 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
         ball_player_collision(g.b, hit2, g.p2.x, in2, g.p2.state, id, g.e.rng);
         g.p2.coll = touch2;
         const bool hit_processed = hit1 | hit2;
-        if ((AI1 || AI2) && hit_processed) {
-            // :331-332 -- when both players hit in one frame the second evaluation overwrites the
-            // first, so a single one after both collisions leaves the same value.
-            if (SCOUT)
-                hit_for_scout = true;
-            else
-                g.b.ex = PZ_ABLATE_SKIP(128) ? g.b.x : predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
-        }
 
         PZ_FRAME_STAMP(6);
         // scoring / round end / game end (:190-210); round_ended and game_ended are both 0 here
@@ -848,6 +841,19 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
         g.e.game_ended = ground & ((p2_scores ? g.e.s2 : g.e.s1) >= cfg.winning_score);
         g.e.round_ended = ground;
         reward = ground ? (p2_scores ? -1 : 1) : 0;
+
+        // :331-332 -- the landing point is predicted again after a processed collision (when both
+        // players hit in one frame the second evaluation overwrites the first, so one after both
+        // collisions leaves the same value).  Nothing in this frame reads it any more, and the next
+        // frame of an active game starts by predicting it afresh (:314-315): between the frames of one
+        // launch (`last_frame` false) it only has to be evaluated for a game that freezes here.
+        const bool ex_observable = last_frame | (g.e.game_ended != 0 && cfg.auto_reset == 0);
+        if ((AI1 || AI2) && hit_processed && ex_observable) {
+            if (SCOUT)
+                hit_for_scout = true;
+            else
+                g.b.ex = PZ_ABLATE_SKIP(128) ? g.b.x : predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
+        }
     }
     if (SCOUT) {
         int32_t* slot = link.hits + lane * kHitPitch;

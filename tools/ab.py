@@ -3,7 +3,8 @@
 rounds in ONE process, median and min reported).
 
     python tools/ab.py --build name1=-DFLAG1 name2="-DFLAG2 -DFLAG3" ...   # here: cross-compile variants
-    python tools/ab.py [--ai] [--n 65536] name1 name2 ...                  # on the GPU box: time them
+    python tools/ab.py [--ai] [--n 65536] [--rollout K] name1 name2 ...    # on the GPU box: time them
+                                                                           # (--rollout: pz_rollout_random, K frames/launch)
 
 A variant named "base" is always built with no extra flags.  Libraries go to
 pika-zoo_amd/lib/ab_<name>.so (git-ignored, shipped by gpurun).
@@ -45,6 +46,7 @@ def main():
     n = 65536
     if "--n" in args:
         n = int(args[args.index("--n") + 1])
+    rollout = int(args[args.index("--rollout") + 1]) if "--rollout" in args else 0
     names = [a for a in args if not a.startswith("--") and not a.isdigit()]
     if "base" not in names:
         names = ["base"] + names
@@ -56,6 +58,8 @@ def main():
         lib.pz_init.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P]
         lib.pz_reset.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P]
         lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P, P]
+        lib.pz_rollout_random.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), C.c_uint64, C.c_uint64,
+                                          C.c_int32, P, P, P, P, P, P, P, P, P]
         libs[nm] = lib
     cfg = _native.PzConfig()
     cfg.winning_score, cfg.auto_reset, cfg.seed, cfg.p2_computer = 15, 1, 0, int(ai)
@@ -73,11 +77,27 @@ def main():
     assert base.pz_init(state.data_ptr(), n, n, C.byref(cfg), stream) == 0
     assert base.pz_reset(state.data_ptr(), n, n, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(), None, stream) == 0
 
+    if rollout:
+        k = rollout
+        t_obs = [torch.zeros((k, n, 35), dtype=torch.int32, device=dev) for _ in range(2)]
+        t_rew = [torch.zeros((k, n), dtype=torch.int32, device=dev) for _ in range(2)]
+        t_term = torch.zeros((k, n), dtype=torch.uint8, device=dev)
+        t_act = torch.zeros((k, 2, n), dtype=torch.int32, device=dev)
+
     def run(lib, steps):
+        if rollout:
+            for j in range(max(1, steps // rollout)):
+                rc = lib.pz_rollout_random(state.data_ptr(), n, n, C.byref(cfg), 7, j * rollout, rollout,
+                                           t_act.data_ptr(), t_obs[0].data_ptr(), t_obs[1].data_ptr(),
+                                           t_rew[0].data_ptr(), t_rew[1].data_ptr(), t_term.data_ptr(), None, None,
+                                           stream)
+                assert rc == 0, rc
+            return max(1, steps // rollout) * rollout
         for t in range(steps):
             a = acts[t % 64]
             lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
                         obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), None, stream)
+        return steps
 
     run(base, 700)
     snapshot = state.clone()
@@ -88,7 +108,8 @@ def main():
         state.copy_(snapshot)
         run(lib, 128)
         torch.cuda.synchronize()
-        finals[nm] = (state.clone(), obs[0].clone(), obs[1].clone(), rew[0].clone(), term.clone())
+        finals[nm] = ((state.clone(), t_obs[0].clone(), t_obs[1].clone(), t_rew[0].clone(), t_term.clone()) if rollout
+                      else (state.clone(), obs[0].clone(), obs[1].clone(), rew[0].clone(), term.clone()))
     for nm in names:
         same = all(torch.equal(a, b) for a, b in zip(finals[nm], finals["base"]))
         print(f"  {nm}: trajectory identical to base: {same}")
@@ -100,11 +121,12 @@ def main():
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            run(lib, K)
+            frames = run(lib, K)
             e1.record()
             torch.cuda.synchronize()
-            times[nm].append(e0.elapsed_time(e1) * 1e3 / K)
-    print(f"n={n} p2_computer={ai} wrappers={wrappers}: us per launch, median / min over {rounds} interleaved rounds of {K}")
+            times[nm].append(e0.elapsed_time(e1) * 1e3 / frames)
+    print(f"n={n} p2_computer={ai} wrappers={wrappers} rollout={rollout}: us per "
+          f"{'frame' if rollout else 'launch'}, median / min over {rounds} interleaved rounds of {K}")
     for nm in names:
         print(f"  {nm:28s} {statistics.median(times[nm]):7.3f} {min(times[nm]):7.3f}")
 
