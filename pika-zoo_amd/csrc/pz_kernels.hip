@@ -513,26 +513,58 @@ __device__ __forceinline__ void scout_landing_after_hits(const StepArgs& a, cons
         io.st(PZ_B_EXPECTED_LANDING_POINT_X, predict_landing_x<true>(slot[1], slot[2], slot[3], slot[4]));
 }
 
-// SCOUT (single-frame launches with a computer player, below the sparse write-back threshold): the
-// workgroup has a second wave for the flight predictions that can run beside the frame
-// (scout_candidates, scout_landing_after_hits).
-template <bool AI1, bool AI2, int MODE, bool SPARSE, bool SCOUT = false>
-__global__ __launch_bounds__(SCOUT ? 2 * kLanes : kLanes) void step_kernel(const StepArgs a)
+// The scout of the k-frame modes: one round per frame on what the main wave posted after its world step.
+__device__ __forceinline__ void scout_candidates_posted(const int32_t* __restrict__ posts, int32_t* __restrict__ cand,
+                                                        int32_t* __restrict__ scratch, int lane)
 {
-    static_assert(!SCOUT || (MODE == kActions && (AI1 || AI2)), "the scout wave serves single-frame AI launches");
+    const int32_t* post = posts + lane * kPostPitch;
+    const bool need = post[0] != 0;
+    Ball b{};
+    if (need) {
+        b.x = post[1];
+        b.y = post[2];
+        b.yv = post[3];
+    }
+    int ex[6] = {0, 0, 0, 0, 0, 0};
+    wave_power_hit_candidates<false>(need, b, ex, scratch, lane);
+    if (need) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) cand[lane * kCandPitch + c] = ex[c];
+    }
+}
+
+// SCOUT (launches with a computer player, below the sparse write-back threshold): the workgroup has a
+// second wave for the flight predictions that can run beside the frame -- kScoutLoads for the single
+// frame of pz_step (scout_candidates, scout_landing_after_hits), kScoutPosted for the k-frame modes
+// (scout_candidates_posted).  The scout executes exactly the workgroup barriers of the main wave.
+template <bool AI1, bool AI2, int MODE, bool SPARSE, int SCOUT = kNoScout>
+__global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_kernel(const StepArgs a)
+{
+    static_assert(SCOUT == kNoScout || ((AI1 || AI2) && !SPARSE && (MODE == kActions) == (SCOUT == kScoutLoads)),
+                  "kScoutLoads serves the single-frame AI launch, kScoutPosted the k-frame ones");
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     __shared__ int32_t tape_lds[MODE == kTape ? kTapeChunk * 2 * kLanes : 1];  // parked action tape (kTape only)
-    __shared__ int32_t cand[SCOUT ? kLanes * kCandPitch : 1];
-    __shared__ int32_t hits[SCOUT ? kLanes * kHitPitch : 1];
-    __shared__ int32_t scout_scratch[SCOUT ? 576 : 1];
+    __shared__ int32_t cand[SCOUT != kNoScout ? kLanes * kCandPitch : 1];
+    __shared__ int32_t hits[SCOUT == kScoutLoads ? kLanes * kHitPitch : 1];
+    __shared__ int32_t posts[SCOUT == kScoutPosted ? kLanes * kPostPitch : 1];
+    __shared__ int32_t scout_scratch[SCOUT != kNoScout ? 576 : 1];
 
     const int lane = threadIdx.x & (kLanes - 1);
-    if (SCOUT && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) {
-        scout_candidates<AI1, AI2>(a, cand, scout_scratch, lane);
-        __syncthreads();  // step_games: candidates handed over
-        __syncthreads();  // step_games: collided balls posted
-        scout_landing_after_hits(a, hits, lane);
-        __syncthreads();  // emit_outputs: observation rows staged (this wave has none)
+    if (SCOUT != kNoScout && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) {
+        if (SCOUT == kScoutLoads) {
+            scout_candidates<AI1, AI2>(a, cand, scout_scratch, lane);
+            __syncthreads();  // step_games: candidates handed over
+            __syncthreads();  // step_games: collided balls posted
+            scout_landing_after_hits(a, hits, lane);
+        } else {
+            for (int32_t s = 0; s < a.k; ++s) {
+                __syncthreads();  // step_games: this frame's ball posted
+                scout_candidates_posted(posts, cand, scout_scratch, lane);
+                __syncthreads();  // step_games: candidates handed over
+                if (MODE == kRollout || MODE == kTape) __syncthreads();  // emit_outputs of the frame
+            }
+        }
+        if (MODE != kRollout && MODE != kTape) __syncthreads();  // emit_outputs (this wave stages no rows)
         return;
     }
     const int64_t base = (int64_t)blockIdx.x * kLanes;
@@ -596,7 +628,7 @@ __global__ __launch_bounds__(SCOUT ? 2 * kLanes : kLanes) void step_kernel(const
                         tape_lds[(f * 2 + 1) * kLanes + lane] =
                             (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, n32 * 4u, 0);
                     }
-                    __syncthreads();
+                    wave_lds_handover<SCOUT == kNoScout>();  // every lane reads back its own words only
                 }
                 a1 = tape_lds[(slot * 2 + 0) * kLanes + lane];
                 a2 = tape_lds[(slot * 2 + 1) * kLanes + lane];
@@ -609,8 +641,8 @@ __global__ __launch_bounds__(SCOUT ? 2 * kLanes : kLanes) void step_kernel(const
 #else
             const bool last_frame = s == a.k - 1;
 #endif
-            reward = step_games<AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane, ScoutLink{nullptr, nullptr},
-                                          nullptr, last_frame);
+            reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane,
+                                                 ScoutLink{cand, hits, posts}, nullptr, last_frame);
             finished += (unsigned int)(live && g.e.game_ended && !frozen);
             rw = shape_rewards(a.cfg, g, reward, frozen);
             if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
@@ -626,7 +658,7 @@ __global__ __launch_bounds__(SCOUT ? 2 * kLanes : kLanes) void step_kernel(const
     } else if (!PZ_SKIP_FRAME) {
         const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
         reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane,
-                                             ScoutLink{cand, hits}, &ex_pending);
+                                             ScoutLink{cand, hits, posts}, &ex_pending);
         finished = (unsigned int)(live && g.e.game_ended && !frozen);
         rw = shape_rewards(a.cfg, g, reward, frozen);
         if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
@@ -908,15 +940,16 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
     }
 #endif
 #if !defined(PZ_NO_SCOUT_WAVE) && !defined(PZ_ABLATE) && !defined(PZ_STAMPS)
-    if (MODE == kActions && a.n < kSparseWritebackMinLanes) {  // a computer player is present (else: pair kernel)
+    if (a.n < kSparseWritebackMinLanes) {  // a computer player is present (else: pair kernel or plain kernel below)
+        constexpr int kScout = MODE == kActions ? kScoutLoads : kScoutPosted;
         const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
         const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
         if (ai1 && ai2)
-            hipLaunchKernelGGL((step_kernel<true, true, kActions, false, true>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((step_kernel<true, true, MODE, false, kScout>), grid, block, 0, stream, a);
         else if (ai1)
-            hipLaunchKernelGGL((step_kernel<true, false, kActions, false, true>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((step_kernel<true, false, MODE, false, kScout>), grid, block, 0, stream, a);
         else if (ai2)
-            hipLaunchKernelGGL((step_kernel<false, true, kActions, false, true>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((step_kernel<false, true, MODE, false, kScout>), grid, block, 0, stream, a);
         if (ai1 || ai2) return (int)hipGetLastError();
     }
 #endif

@@ -722,23 +722,29 @@ __device__ __forceinline__ void ball_player_collision(Ball& b, bool hit, int pla
 // `frozen` (auto_reset off and the game already over) leaves the game untouched.
 // ---------------------------------------------------------------------------------------
 // SCOUT: a second wave of the workgroup takes the flight predictions that can run beside this one
-// (pz_kernels.hip: scout_candidates, scout_landing_after_hits):
-//   * the power-hit candidates, evaluated while this wave loads, starts rounds and predicts the landing
-//     point; picked up from link.cand behind one workgroup barrier;
-//   * the landing point after a ball-player collision (:331-332), which nothing in the frame reads any
-//     more: the collided ball is posted in link.hits behind a second barrier at the end of the frame,
-//     the scout predicts and stores the state column itself, and `ex_pending` tells the caller not to.
+// (pz_kernels.hip: scout_candidates, scout_candidates_posted, scout_landing_after_hits):
+//   * the power-hit candidates, evaluated while this wave predicts the landing point (kScoutLoads: and
+//     while it loads and starts rounds -- the scout fetches its inputs itself; kScoutPosted, the
+//     k-frame modes: this wave posts ball and `need` in link.posts behind a barrier after the world
+//     step); picked up from link.cand behind one workgroup barrier;
+//   * kScoutLoads only: the landing point after a ball-player collision (:331-332), which nothing in the
+//     frame reads any more: the collided ball is posted in link.hits behind a barrier at the end of the
+//     frame, the scout predicts and stores the state column itself, and `ex_pending` tells the caller
+//     not to.
 constexpr int kCandPitch = 7;  // six landing points per game, odd pitch
 constexpr int kHitPitch = 5;   // flag, x, y, x velocity, y velocity
+constexpr int kPostPitch = 5;  // need, x, y, |y velocity| (+1: odd pitch)
+enum ScoutMode { kNoScout = 0, kScoutLoads = 1, kScoutPosted = 2 };
 struct ScoutLink {
     const int32_t* cand;  // LDS [64][kCandPitch]
-    int32_t* hits;        // LDS [64][kHitPitch]
+    int32_t* hits;        // LDS [64][kHitPitch]   (kScoutLoads)
+    int32_t* posts;       // LDS [64][kPostPitch]  (kScoutPosted)
 };
 
-template <bool AI1, bool AI2, bool SCOUT = false>
+template <bool AI1, bool AI2, int SCOUT = kNoScout>
 __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
                                           bool& frozen, int32_t* __restrict__ scratch, int lane,
-                                          const ScoutLink link = ScoutLink{nullptr, nullptr}, bool* ex_pending = nullptr,
+                                          const ScoutLink link = ScoutLink{nullptr, nullptr, nullptr}, bool* ex_pending = nullptr,
                                           const bool last_frame = true)
 {
     // The reference empties `agents` on termination (:237-238) and expects reset() before the
@@ -776,12 +782,22 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
         // physics_engine
         ground = ball_world_step(g.b);
         PZ_FRAME_STAMP(3);
-
-        if (AI1 || AI2) {
-            // :314-315 recomputes the landing point before each player; the ball does not move
-            // between the two calls, so one evaluation serves both.
-            g.b.ex = PZ_ABLATE_SKIP(32) ? g.b.x : predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
+    }
+    if (SCOUT == kScoutPosted) {
+        const bool need = active && ((AI1 && power_hit_scan_needed(g.p1, g.b)) || (AI2 && power_hit_scan_needed(g.p2, g.b)));
+        int32_t* post = link.posts + lane * kPostPitch;
+        post[0] = need;
+        if (need) {
+            post[1] = g.b.x;
+            post[2] = g.b.y;
+            post[3] = abs(g.b.yv);
         }
+        __syncthreads();  // the scout starts on this frame's candidates
+    }
+    if ((AI1 || AI2) && active) {
+        // :314-315 recomputes the landing point before each player; the ball does not move
+        // between the two calls, so one evaluation serves both.
+        g.b.ex = PZ_ABLATE_SKIP(32) ? g.b.x : predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
     }
 
     if (AI1) {
@@ -849,13 +865,13 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
         // launch (`last_frame` false) it only has to be evaluated for a game that freezes here.
         const bool ex_observable = last_frame | (g.e.game_ended != 0 && cfg.auto_reset == 0);
         if ((AI1 || AI2) && hit_processed && ex_observable) {
-            if (SCOUT)
+            if (SCOUT == kScoutLoads)
                 hit_for_scout = true;
             else
                 g.b.ex = PZ_ABLATE_SKIP(128) ? g.b.x : predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
         }
     }
-    if (SCOUT) {
+    if (SCOUT == kScoutLoads) {
         int32_t* slot = link.hits + lane * kHitPitch;
         slot[0] = hit_for_scout;
         if (hit_for_scout) {
