@@ -362,6 +362,30 @@ def test_masked_reset_and_frozen_lanes(oracle):
     assert torch.equal(raw.state[42] != 0, ~mask)
 
 
+@pytest.mark.parametrize("kw", [dict(is_player2_computer=True), dict(is_player1_computer=True, is_player2_computer=True)])
+def test_k_frame_launches_with_freezing_computer_games(kw, oracle):
+    """Between the frames of one launch the landing point after a ball-player collision is only evaluated
+    where it stays observable: on the last frame and for a game that freezes on that frame (auto_reset off).
+    Games end at different frames of the k-frame launches here; the whole state -- expected_landing_point_x
+    included -- must equal the oracle's frame-by-frame run after every launch."""
+    n, k = 4096, 37
+    env = make_env(num_envs=n, seed=12, env_id_base=40, winning_score=1, auto_reset=False, **kw)
+    ref = oracle.OracleEnv(n, oracle.make_config(winning_score=1, seed=12, env_id_base=40, auto_reset=False, **kw),
+                           nthreads=4)
+    env.reset(), ref.reset()
+    frozen_seen = 0
+    for r in range(12):
+        env.unwrapped.step_random(5, t0=r * k, k=k)
+        ref.rollout_random(5, r * k, k)
+        st = cpu(env.unwrapped.state)
+        assert np.array_equal(st, ref.state), r
+        frozen_seen = int((st[42] != 0).sum())  # game_ended
+    assert 0 < frozen_seen <= n
+    out = env.unwrapped.rollout_random(5, k, t0=12 * k)   # the trajectory kernel takes the same path
+    ref.rollout_random(5, 12 * k, k)
+    assert np.array_equal(cpu(env.unwrapped.state), ref.state)
+
+
 def test_checkpoint_roundtrip():
     env = make_env(num_envs=512, seed=8, is_player2_computer=True)
     env.reset()
