@@ -939,8 +939,13 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
         return (int)hipGetLastError();
     }
 #endif
+// With a computer player the two-wave kernel still wins at 262 144 games (36.5 vs 38.2 us per launch against the
+// single-wave kernel with the changed-only write-back) and loses at 524 288 (70.3 vs 66.4): switch in between.
+#ifndef PZ_SCOUT_MAX_LANES
+#define PZ_SCOUT_MAX_LANES (kSparseWritebackMinLanes + kSparseWritebackMinLanes / 2)
+#endif
 #if !defined(PZ_NO_SCOUT_WAVE) && !defined(PZ_ABLATE) && !defined(PZ_STAMPS)
-    if (a.n < kSparseWritebackMinLanes) {  // a computer player is present (else: pair kernel or plain kernel below)
+    if (a.n < PZ_SCOUT_MAX_LANES) {  // a computer player is present (else: pair kernel or plain kernel below)
         constexpr int kScout = MODE == kActions ? kScoutLoads : kScoutPosted;
         const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
         const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
