@@ -898,7 +898,14 @@ __global__ __launch_bounds__(256) void predictor_selftest_kernel(const int32_t* 
 // (4 GiB / 176 B of state per game); larger jobs are sharded by the caller (env_id_base).
 constexpr int64_t kMaxLanesPerLaunch = (int64_t)0xFFFFFFFFu / (PZ_STATE_WORDS * 4);
 // batches from this size on are HBM-bound and use the changed-only write-back
-constexpr int64_t kSparseWritebackMinLanes = 262144;
+// Kernel selection by batch size (interleaved A/B on MI355X, tools/ab.py; us per pz_step launch):
+//   human-vs-human   65 536: pair 7.90 | single-wave changed-only 8.05     81 920: 8.90 | 8.90
+//                    98 304: 9.92 | 9.64     131 072: 13.6 | 11.5     262 144: 25.8 | 23.7
+//   player 2 = computer   262 144: scout 36.5 | single-wave changed-only 38.2     524 288: 70.3 | 66.4
+#ifndef PZ_SPARSE_MIN_LANES
+#define PZ_SPARSE_MIN_LANES 81920
+#endif
+constexpr int64_t kSparseWritebackMinLanes = PZ_SPARSE_MIN_LANES;  // also: the pair kernel serves batches below it
 
 static int check_common(const void* state, int64_t n, int64_t stride, const pz_config* cfg)
 {
@@ -930,19 +937,21 @@ static int launch_step_ai(const StepArgs& a, hipStream_t stream)
     return (int)hipGetLastError();
 }
 
+#ifndef PZ_PAIR_MAX_LANES
+#define PZ_PAIR_MAX_LANES kSparseWritebackMinLanes
+#endif
+
 template <int MODE>
 static int launch_step(const StepArgs& a, hipStream_t stream)
 {
 #ifndef PZ_NO_PAIR_KERNEL
-    if (MODE == kActions && a.n < kSparseWritebackMinLanes && a.cfg.p1_computer == 0 && a.cfg.p2_computer == 0) {
+    if (MODE == kActions && a.n < PZ_PAIR_MAX_LANES && a.cfg.p1_computer == 0 && a.cfg.p2_computer == 0) {
         hipLaunchKernelGGL(step_pair_kernel, dim3(blocks_for(a.n, kLanes)), dim3(2 * kLanes), 0, stream, a);
         return (int)hipGetLastError();
     }
 #endif
-// With a computer player the two-wave kernel still wins at 262 144 games (36.5 vs 38.2 us per launch against the
-// single-wave kernel with the changed-only write-back) and loses at 524 288 (70.3 vs 66.4): switch in between.
 #ifndef PZ_SCOUT_MAX_LANES
-#define PZ_SCOUT_MAX_LANES (kSparseWritebackMinLanes + kSparseWritebackMinLanes / 2)
+#define PZ_SCOUT_MAX_LANES 393216  // with a computer player the two-wave kernel wins up to somewhere above 262 144
 #endif
 #if !defined(PZ_NO_SCOUT_WAVE) && !defined(PZ_ABLATE) && !defined(PZ_STAMPS)
     if (a.n < PZ_SCOUT_MAX_LANES) {  // a computer player is present (else: pair kernel or plain kernel below)
