@@ -360,8 +360,8 @@ def main():
                             f"auto-reset, p2_computer={args.p2_computer}, fused_wrappers={args.wrappers}",
                 "num_envs_per_gpu": args.num_envs, "num_envs_total": main_res["n_total"],
                 "launch": args.launch,
-                "kernel": ("pz::step_kernel<AI1,AI2,kActions,SPARSE> via pz_step" if args.num_envs >= (393216 if args.p2_computer else 81920)
-                           else "pz::step_kernel<false,true,kActions,false,kScoutLoads> via pz_step" if args.p2_computer
+                "kernel": ("pz::step_kernel<AI1,AI2,kActions,true> via pz_step" if args.num_envs >= 393216
+                           else "pz::step_kernel<false,true,kActions,true,kScoutLoads> via pz_step" if args.p2_computer
                            else "pz::step_pair_kernel via pz_step"),
             },
             "roofline": {

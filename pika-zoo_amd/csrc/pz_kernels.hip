@@ -186,7 +186,7 @@ __device__ __forceinline__ void store_player_changed(const Player& p, const Play
     if (p.standby != o.standby) io.st(c0 + PZ_P_COMPUTER_WHERE_TO_STAND_BY, p.standby);
 }
 
-__device__ __forceinline__ void store_game_changed(const Game& g, const Game& o, const StateIO& io)
+__device__ __forceinline__ void store_game_changed(const Game& g, const Game& o, const StateIO& io, bool skip_ex = false)
 {
     store_player_changed(g.p1, o.p1, io, 0);
     store_player_changed(g.p2, o.p2, io, PZ_P_WORDS);
@@ -200,7 +200,7 @@ __device__ __forceinline__ void store_game_changed(const Game& g, const Game& o,
     io.st(PZ_B_FINE_ROTATION, g.b.rot);
     if (g.b.xv != o.b.xv) io.st(PZ_B_X_VELOCITY, g.b.xv);
     if (g.b.power != o.b.power) io.st(PZ_B_IS_POWER_HIT, g.b.power);
-    if (g.b.ex != o.b.ex) io.st(PZ_B_EXPECTED_LANDING_POINT_X, g.b.ex);
+    if (g.b.ex != o.b.ex && !skip_ex) io.st(PZ_B_EXPECTED_LANDING_POINT_X, g.b.ex);
     if (g.b.punch != o.b.punch) io.st(PZ_B_PUNCH_EFFECT_X, g.b.punch);
     if (g.e.s1 != o.e.s1) io.st(PZ_E_SCORE_P1, g.e.s1);
     if (g.e.s2 != o.e.s2) io.st(PZ_E_SCORE_P2, g.e.s2);
@@ -540,7 +540,7 @@ __device__ __forceinline__ void scout_candidates_posted(const int32_t* __restric
 template <bool AI1, bool AI2, int MODE, bool SPARSE, int SCOUT = kNoScout>
 __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_kernel(const StepArgs a)
 {
-    static_assert(SCOUT == kNoScout || ((AI1 || AI2) && !SPARSE && (MODE == kActions) == (SCOUT == kScoutLoads)),
+    static_assert(SCOUT == kNoScout || ((AI1 || AI2) && (MODE == kActions) == (SCOUT == kScoutLoads)),
                   "kScoutLoads serves the single-frame AI launch, kScoutPosted the k-frame ones");
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     __shared__ int32_t tape_lds[MODE == kTape ? kTapeChunk * 2 * kLanes : 1];  // parked action tape (kTape only)
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
     PZ_STAMP(2);
     if (live) {
         if (SPARSE)
-            store_game_changed(g, loaded, io);
+            store_game_changed(g, loaded, io, ex_pending);
         else
             store_game(g, io, ex_pending);
         if (with_stats) {
@@ -740,27 +740,29 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, int32_t (*lds_obs)[
             st.len = sio.ld(2);
         }
     }
+    const Game loaded = g;  // what the columns held before the frame
     const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     bool frozen = false;
-    const int reward = step_games_pair<ROLE>(g, a.cfg, id, a1, a2, live, frozen, xchg, lane);
+    const int reward = step_games_pair<ROLE>(g, a.cfg, id, a1, a2, live, frozen, xchg, kLanes * PZ_OBS_DIM, lane);
     const Rewards rw = shape_rewards(a.cfg, g, reward, frozen);
     if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
 
     if (live) {
-        store_player(ROLE == 0 ? g.p1 : g.p2, io, kOwn);
+        // changed-only write-back of the rarely changing columns, as in store_game_changed
+        store_player_changed(ROLE == 0 ? g.p1 : g.p2, ROLE == 0 ? loaded.p1 : loaded.p2, io, kOwn);
         if (ROLE == 0) {
             io.st(PZ_B_X, g.b.x);
             io.st(PZ_B_Y, g.b.y);
-            io.st(PZ_B_X_VELOCITY, g.b.xv);
             io.st(PZ_B_Y_VELOCITY, g.b.yv);
-            io.st(PZ_B_IS_POWER_HIT, g.b.power);
-            io.st(PZ_B_PUNCH_EFFECT_X, g.b.punch);
-            io.st(PZ_E_SCORE_P1, g.e.s1);
-            io.st(PZ_E_SCORE_P2, g.e.s2);
-            io.st(PZ_E_IS_PLAYER2_SERVE, g.e.p2serve);
-            io.st(PZ_E_ROUND_ENDED, g.e.round_ended);
-            io.st(PZ_E_GAME_ENDED, g.e.game_ended);
-            io.st(PZ_E_RNG_DRAW_COUNTER, (int32_t)g.e.rng);
+            if (g.b.xv != loaded.b.xv) io.st(PZ_B_X_VELOCITY, g.b.xv);
+            if (g.b.power != loaded.b.power) io.st(PZ_B_IS_POWER_HIT, g.b.power);
+            if (g.b.punch != loaded.b.punch) io.st(PZ_B_PUNCH_EFFECT_X, g.b.punch);
+            if (g.e.s1 != loaded.e.s1) io.st(PZ_E_SCORE_P1, g.e.s1);
+            if (g.e.s2 != loaded.e.s2) io.st(PZ_E_SCORE_P2, g.e.s2);
+            if (g.e.p2serve != loaded.e.p2serve) io.st(PZ_E_IS_PLAYER2_SERVE, g.e.p2serve);
+            if (g.e.round_ended != loaded.e.round_ended) io.st(PZ_E_ROUND_ENDED, g.e.round_ended);
+            if (g.e.game_ended != loaded.e.game_ended) io.st(PZ_E_GAME_ENDED, g.e.game_ended);
+            if (g.e.rng != loaded.e.rng) io.st(PZ_E_RNG_DRAW_COUNTER, (int32_t)g.e.rng);
             if (with_stats) {
                 sio.st(0, (int)st.r1);
                 sio.st(1, (int)st.r2);
@@ -774,7 +776,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, int32_t (*lds_obs)[
             io.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
             io.st(PZ_B_PREVIOUS_PREVIOUS_Y, g.b.ppy);
             io.st(PZ_B_FINE_ROTATION, g.b.rot);
-            io.st(PZ_B_EXPECTED_LANDING_POINT_X, g.b.ex);
+            // expected_landing_point_x never changes without a computer player
         }
         const Rsrc rew = make_rsrc(ROLE == 0 ? a.rew_p1 : a.rew_p2, n32 * 4u);
         const unsigned int bits = as_float ? __float_as_uint(ROLE == 0 ? rw.f1 : rw.f2)
@@ -794,7 +796,9 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, int32_t (*lds_obs)[
 __global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(const StepArgs a)
 {
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
-    __shared__ int32_t xchg[2 * kLanes * 9];
+    // the player exchange of step_games_pair lives in the staging rows (each wave's incoming data in its own
+    // rows, overwritten by nobody else): 17.5 KB of LDS per workgroup, 8 workgroups per CU
+    int32_t* xchg = &lds_obs[0][0];
     // the wave index is uniform by construction; readfirstlane makes that visible to the compiler
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (kLanes - 1);
@@ -899,13 +903,16 @@ __global__ __launch_bounds__(256) void predictor_selftest_kernel(const int32_t* 
 constexpr int64_t kMaxLanesPerLaunch = (int64_t)0xFFFFFFFFu / (PZ_STATE_WORDS * 4);
 // batches from this size on are HBM-bound and use the changed-only write-back
 // Kernel selection by batch size (interleaved A/B on MI355X, tools/ab.py; us per pz_step launch):
-//   human-vs-human   65 536: pair 7.90 | single-wave changed-only 8.05     81 920: 8.90 | 8.90
-//                    98 304: 9.92 | 9.64     131 072: 13.6 | 11.5     262 144: 25.8 | 23.7
-//   player 2 = computer   262 144: scout 36.5 | single-wave changed-only 38.2     524 288: 70.3 | 66.4
-#ifndef PZ_SPARSE_MIN_LANES
-#define PZ_SPARSE_MIN_LANES 81920
+//   human-vs-human, pair kernel | single-wave kernel, both with the changed-only write-back:
+//       65 536: 7.58 | 8.01    131 072: 11.1 | 11.5    262 144: 22.4 | 23.8    294 912: 25.3 | 26.5
+//      524 288: 47.2 | 46.5    1 048 576: 93.9 | 90.6      (single-wave without changed-only at 65 536: 8.52)
+//   player 2 = computer, scout kernel | single-wave changed-only:   262 144: 36.5 | 38.2    524 288: 70.3 | 66.4
+#ifndef PZ_TWO_WAVE_MAX_LANES
+#define PZ_TWO_WAVE_MAX_LANES 393216  // below: two waves per workgroup (pair kernel / scout)
 #endif
-constexpr int64_t kSparseWritebackMinLanes = PZ_SPARSE_MIN_LANES;  // also: the pair kernel serves batches below it
+//   the changed-only write-back also pays in the scout kernel (65 536: 14.3 | 14.65 without, 262 144: 35.6 | 36.6)
+//   and is used by every launch that writes the state back after ONE frame; a trajectory launch writes it once
+//   per k frames, where the plain write-back is always right.
 
 static int check_common(const void* state, int64_t n, int64_t stride, const pz_config* cfg)
 {
@@ -937,39 +944,31 @@ static int launch_step_ai(const StepArgs& a, hipStream_t stream)
     return (int)hipGetLastError();
 }
 
-#ifndef PZ_PAIR_MAX_LANES
-#define PZ_PAIR_MAX_LANES kSparseWritebackMinLanes
-#endif
-
 template <int MODE>
 static int launch_step(const StepArgs& a, hipStream_t stream)
 {
 #ifndef PZ_NO_PAIR_KERNEL
-    if (MODE == kActions && a.n < PZ_PAIR_MAX_LANES && a.cfg.p1_computer == 0 && a.cfg.p2_computer == 0) {
+    if (MODE == kActions && a.n < PZ_TWO_WAVE_MAX_LANES && a.cfg.p1_computer == 0 && a.cfg.p2_computer == 0) {
         hipLaunchKernelGGL(step_pair_kernel, dim3(blocks_for(a.n, kLanes)), dim3(2 * kLanes), 0, stream, a);
         return (int)hipGetLastError();
     }
 #endif
-#ifndef PZ_SCOUT_MAX_LANES
-#define PZ_SCOUT_MAX_LANES 393216  // with a computer player the two-wave kernel wins up to somewhere above 262 144
-#endif
 #if !defined(PZ_NO_SCOUT_WAVE) && !defined(PZ_ABLATE) && !defined(PZ_STAMPS)
-    if (a.n < PZ_SCOUT_MAX_LANES) {  // a computer player is present (else: pair kernel or plain kernel below)
+    if (a.n < PZ_TWO_WAVE_MAX_LANES) {  // a computer player is present (else: pair kernel or plain kernel below)
         constexpr int kScout = MODE == kActions ? kScoutLoads : kScoutPosted;
         const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
         const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
+        constexpr bool kSparse = MODE == kActions || MODE == kRandom;
         if (ai1 && ai2)
-            hipLaunchKernelGGL((step_kernel<true, true, MODE, false, kScout>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((step_kernel<true, true, MODE, kSparse, kScout>), grid, block, 0, stream, a);
         else if (ai1)
-            hipLaunchKernelGGL((step_kernel<true, false, MODE, false, kScout>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((step_kernel<true, false, MODE, kSparse, kScout>), grid, block, 0, stream, a);
         else if (ai2)
-            hipLaunchKernelGGL((step_kernel<false, true, MODE, false, kScout>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((step_kernel<false, true, MODE, kSparse, kScout>), grid, block, 0, stream, a);
         if (ai1 || ai2) return (int)hipGetLastError();
     }
 #endif
-    // a rollout writes the state once per k frames: the plain write-back is always right there
-    if (MODE != kRollout && MODE != kTape && a.n >= kSparseWritebackMinLanes) return launch_step_ai<MODE, true>(a, stream);
-    return launch_step_ai<MODE, false>(a, stream);
+    return launch_step_ai<MODE, MODE == kActions || MODE == kRandom>(a, stream);
 }
 
 }  // namespace pz

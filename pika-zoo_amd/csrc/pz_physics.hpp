@@ -897,11 +897,15 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
 // which are deterministic, so the two copies stay identical.  One LDS exchange per frame hands
 // the moved player to the partner.  `g` holds: the own player complete, of the partner only
 // `coll` (and whatever the exchange fills in), ball and env complete.
-// xchg: 2 * 64 * 9 words of LDS.  Contains exactly one __syncthreads().
+// xchg: two regions of LDS, `xchg_region` words apart, 64 * 9 words used in each; a wave writes its
+// player into the PARTNER's region and reads the partner's from its own, so a wave may reuse its own
+// region afterwards without asking (the pair kernel aliases them with the observation staging rows).
+// Contains exactly one __syncthreads().
 // ---------------------------------------------------------------------------------------
 template <int ROLE>
 __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2,
-                                               bool live, bool& frozen, int32_t* __restrict__ xchg, int lane)
+                                               bool live, bool& frozen, int32_t* __restrict__ xchg, int xchg_region,
+                                               int lane)
 {
     Player& own = ROLE == 0 ? g.p1 : g.p2;
     Player& other = ROLE == 0 ? g.p2 : g.p1;
@@ -948,7 +952,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     // (frozen games exchange their unchanged players, so their observations stay complete)
     constexpr int kXchgWords = 9;  // odd pitch: conflict-free LDS rows
     if (live) {
-        int32_t* mine = xchg + (ROLE * 64 + lane) * kXchgWords;
+        int32_t* mine = xchg + (1 - ROLE) * xchg_region + lane * kXchgWords;  // into the partner's region
         mine[0] = own.x;
         mine[1] = own.y;
         mine[2] = own.yv;
@@ -961,7 +965,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     }
     __syncthreads();
     if (live) {
-        const int32_t* theirs = xchg + ((1 - ROLE) * 64 + lane) * kXchgWords;
+        const int32_t* theirs = xchg + ROLE * xchg_region + lane * kXchgWords;
         other.x = theirs[0];
         other.y = theirs[1];
         other.yv = theirs[2];

@@ -691,14 +691,14 @@ def test_randomized_config_sweep_vs_oracle(oracle):
 
 
 @pytest.mark.parametrize("kw,steps,switch", [
-    (dict(winning_score=1), 12, 81920),
+    (dict(winning_score=1), 12, 393216),
     (dict(winning_score=1, is_player2_computer=True), 60, 393216),
     (dict(winning_score=1, is_player1_computer=True, is_player2_computer=True, serve="random"), 60, 393216),
 ])
 def test_two_wave_and_single_wave_kernels_agree_across_the_size_switch(kw, steps, switch, oracle):
-    """Small batches run pz_step with two waves per 64 games (human-vs-human below 81 920 games: split by
-    player; with a computer player below 393 216: a scout wave for the flight predictions); from there on the
-    single-wave kernel with the changed-only write-back: both sides of the switch against the oracle."""
+    """Below 393 216 games pz_step runs two waves per 64 games (human-vs-human: split by player; with a
+    computer player: a scout wave for the flight predictions), from there on one: both sides of the switch
+    against the oracle."""
     for n in (switch - 64, switch):
         env = make_env(num_envs=n, seed=44, env_id_base=7, **kw)
         env.reset()
