@@ -533,7 +533,7 @@ __device__ __forceinline__ void scout_candidates_posted(const int32_t* __restric
     }
 }
 
-// SCOUT (launches with a computer player, below the sparse write-back threshold): the workgroup has a
+// SCOUT (launches with a computer player, below PZ_TWO_WAVE_MAX_LANES games): the workgroup has a
 // second wave for the flight predictions that can run beside the frame -- kScoutLoads for the single
 // frame of pz_step (scout_candidates, scout_landing_after_hits), kScoutPosted for the k-frame modes
 // (scout_candidates_posted).  The scout executes exactly the workgroup barriers of the main wave.
