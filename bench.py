@@ -55,6 +55,7 @@ def parse_args():
                     help="graph: the K launches captured once in a hipGraph and replayed; cabi: K direct "
                          "C-ABI calls; api: K env.step() calls")
     ap.add_argument("--p2-computer", action="store_true", help="config 3: rule-based AI on player 2")
+    ap.add_argument("--p1-computer", action="store_true", help="rule-based AI on player 1 (not a BASELINE config)")
     ap.add_argument("--wrappers", action="store_true", help="config 5: fused SimplifyAction+RewardByBallPosition")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on CPU baseline threads")
@@ -71,6 +72,7 @@ def make_env(args, shard, p2_computer, wrappers, device):
     from pikazoo_amd.wrappers import RewardByBallPosition, SimplifyAction
 
     env = pikazoo_v0.env(winning_score=15, serve="winner", is_player2_computer=p2_computer,
+                         is_player1_computer=args.p1_computer,
                          num_envs=shard.n_local, device=device, seed=0, env_id_base=shard.env_id_base,
                          auto_reset=True, validate_actions=False)
     if wrappers:
@@ -180,6 +182,7 @@ def cpu_baseline(args, raw_gpu, p2_computer, wrappers, total_steps):
 
     def cfg(base):
         return po.make_config(winning_score=15, serve="winner", is_player2_computer=p2_computer,
+                              is_player1_computer=args.p1_computer,
                               simplify_action=wrappers, additional_reward=table, seed=0, env_id_base=base)
 
     # timing sample: the same 65 536-game batch, as many 250-step chunks as fit the budget
@@ -357,11 +360,12 @@ def main():
             "config": {
                 "workload": f"{args.num_envs} games per GPU, both players uniform-random actions "
                             f"(Philox policy stream pre-generated in HBM), winning_score=15, serve=winner, "
-                            f"auto-reset, p2_computer={args.p2_computer}, fused_wrappers={args.wrappers}",
+                            f"auto-reset, p1_computer={args.p1_computer}, p2_computer={args.p2_computer}, "
+                            f"fused_wrappers={args.wrappers}",
                 "num_envs_per_gpu": args.num_envs, "num_envs_total": main_res["n_total"],
                 "launch": args.launch,
                 "kernel": ("pz::step_kernel<AI1,AI2,kActions,true> via pz_step" if args.num_envs >= 393216
-                           else "pz::step_kernel<false,true,kActions,true,kScoutLoads> via pz_step" if args.p2_computer
+                           else "pz::step_kernel<AI1,AI2,kActions,true,kScoutLoads> via pz_step" if args.p2_computer or args.p1_computer
                            else "pz::step_pair_kernel via pz_step"),
             },
             "roofline": {
