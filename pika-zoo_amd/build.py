@@ -22,6 +22,8 @@ LIB = LIB_DIR / "libpikazoo_hip.so"
 SOURCES = [CSRC / "pz_kernels.hip"]
 DEPS = SOURCES + [CSRC / "pz_physics.hpp", INCLUDE / "pikazoo_hip.h"]
 ARCH = "gfx950"
+# the step kernels' five leading arguments (10 dwords) are preloaded into SGPRs at wave launch (pz_kernels.hip: HotArgs)
+FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-mllvm", "-amdgpu-kernarg-preload-count=10"]
 
 
 def hipcc_path() -> str:
@@ -42,7 +44,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
     if not force and not needs_build():
         return LIB
     LIB_DIR.mkdir(parents=True, exist_ok=True)
-    cmd = [hipcc_path(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-shared", "-fPIC",
+    cmd = [hipcc_path(), *FLAGS, "-shared", "-fPIC",
            f"-I{INCLUDE}", f"-I{CSRC}", *extra_flags, "-o", str(LIB), *map(str, SOURCES)]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -59,6 +59,19 @@ struct StateIO {
     }
 };
 
+// What the first loads of a wave depend on.  The step kernels take these five as leading scalar kernel
+// arguments (and everything, again, in StepArgs): the build preloads the first 10 argument dwords into
+// SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=10), so the state loads do not have to wait
+// for a scalar load from the kernarg segment first (pair kernel: 7.51 -> 7.33 us per launch).
+struct HotArgs {
+    int32_t* state;
+    int64_t n, stride;
+    const int32_t* act_p1;
+    const int32_t* act_p2;
+};
+#define PZ_HOT_PARAMS int32_t *state, int64_t n, int64_t stride, const int32_t *act_p1, const int32_t *act_p2
+#define PZ_HOT_ARGS(a) (a).state, (a).n, (a).stride, (a).act_p1, (a).act_p2
+
 struct StepArgs {
     int32_t* state;
     int64_t n, stride;
@@ -462,7 +475,7 @@ __device__ __forceinline__ void emit_outputs(const StepArgs& a, const Game& g, c
 // 44 columns, starting rounds and predicting the landing point.  A game whose round (re)starts this
 // frame never scans (its players are put back on the ground), so the scout skips it.
 template <bool AI1, bool AI2>
-__device__ __forceinline__ void scout_candidates(const StepArgs& a, int32_t* __restrict__ cand,
+__device__ __forceinline__ void scout_candidates(const HotArgs a, int32_t* __restrict__ cand,
                                                  int32_t* __restrict__ scratch, int lane)
 {
     const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
@@ -538,8 +551,9 @@ __device__ __forceinline__ void scout_candidates_posted(const int32_t* __restric
 // frame of pz_step (scout_candidates, scout_landing_after_hits), kScoutPosted for the k-frame modes
 // (scout_candidates_posted).  The scout executes exactly the workgroup barriers of the main wave.
 template <bool AI1, bool AI2, int MODE, bool SPARSE, int SCOUT = kNoScout>
-__global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_kernel(const StepArgs a)
+__global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
 {
+    const HotArgs hot{state, n, stride, act_p1, act_p2};
     static_assert(SCOUT == kNoScout || ((AI1 || AI2) && (MODE == kActions) == (SCOUT == kScoutLoads)),
                   "kScoutLoads serves the single-frame AI launch, kScoutPosted the k-frame ones");
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
@@ -556,7 +570,7 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
             // let the scout issue first (config 3: 14.3 -> 13.5 us; no gain in the per-frame hand-shake of the
             // k-frame modes, so only here)
             __builtin_amdgcn_s_setprio(1);
-            scout_candidates<AI1, AI2>(a, cand, scout_scratch, lane);
+            scout_candidates<AI1, AI2>(hot, cand, scout_scratch, lane);
             __syncthreads();  // step_games: candidates handed over
             __syncthreads();  // step_games: collided balls posted
             scout_landing_after_hits(a, hits, lane);
@@ -573,11 +587,11 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
     }
     const int64_t base = (int64_t)blockIdx.x * kLanes;
     const int64_t i = base + lane;
-    const bool live = i < a.n;
-    const uint32_t n32 = (uint32_t)a.n;
+    const bool live = i < hot.n;
+    const uint32_t n32 = (uint32_t)hot.n;
 
     // descriptors are built from kernel arguments only, so they are provably wave-uniform
-    const StateIO io{make_rsrc(a.state, (uint32_t)(a.stride * (PZ_STATE_WORDS * 4))), (uint32_t)a.stride * 4u,
+    const StateIO io{make_rsrc(hot.state, (uint32_t)(hot.stride * (PZ_STATE_WORDS * 4))), (uint32_t)hot.stride * 4u,
                      (uint32_t)i * 4u};
     const bool as_float = a.cfg.ballpos_reward != 0 || a.cfg.normal_state_mode != 0;
     const bool with_stats = a.episode_stats != nullptr && a.cfg.episode_stats_mode != 0;  // uniform
@@ -596,8 +610,8 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
     PZ_STAMP(0);
     int a1 = 0, a2 = 0;
     if (MODE == kActions) {  // rows past n read as 0 through the range check
-        a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act_p1, n32 * 4u), io.voff, 0, 0);
-        a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act_p2, n32 * 4u), io.voff, 0, 0);
+        a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.voff, 0, 0);
+        a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.voff, 0, 0);
     }
     EpisodeStats st{0u, 0u, 0};
     if (live) {
@@ -698,13 +712,13 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
 // waves load all 12), player 1's wave also the 6 env columns, the episode statistics and `terminated`;
 // each wave writes its own agent's reward and observation tensor.
 template <int ROLE>
-__device__ __forceinline__ void pair_body(const StepArgs& a, int32_t (*lds_obs)[kLanes * PZ_OBS_DIM],
+__device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, int32_t (*lds_obs)[kLanes * PZ_OBS_DIM],
                                           int32_t* __restrict__ xchg, int lane)
 {
     const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
-    const bool live = i < a.n;
-    const uint32_t n32 = (uint32_t)a.n;
-    const StateIO io{make_rsrc(a.state, (uint32_t)(a.stride * (PZ_STATE_WORDS * 4))), (uint32_t)a.stride * 4u,
+    const bool live = i < hot.n;
+    const uint32_t n32 = (uint32_t)hot.n;
+    const StateIO io{make_rsrc(hot.state, (uint32_t)(hot.stride * (PZ_STATE_WORDS * 4))), (uint32_t)hot.stride * 4u,
                      (uint32_t)i * 4u};
     const bool as_float = a.cfg.ballpos_reward != 0 || a.cfg.normal_state_mode != 0;
     const bool with_stats = ROLE == 0 && a.episode_stats != nullptr && a.cfg.episode_stats_mode != 0;
@@ -714,8 +728,8 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, int32_t (*lds_obs)[
 
     Game g{};
     const RngId id = make_rng_id(a.cfg, live ? i : 0);
-    const int a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act_p1, n32 * 4u), io.voff, 0, 0);
-    const int a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act_p2, n32 * 4u), io.voff, 0, 0);
+    const int a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.voff, 0, 0);
+    const int a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.voff, 0, 0);
     EpisodeStats st{0u, 0u, 0};
     if (live) {
         g.e.round_ended = io.ld(PZ_E_ROUND_ENDED);
@@ -797,8 +811,9 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, int32_t (*lds_obs)[
     flush_rows(lds_obs[ROLE], ROLE == 0 ? a.obs_p1 : a.obs_p2, n32 * kRowBytes, lane);
 }
 
-__global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(const StepArgs a)
+__global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(PZ_HOT_PARAMS, const StepArgs a)
 {
+    const HotArgs hot{state, n, stride, act_p1, act_p2};
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     // the player exchange of step_games_pair lives in the staging rows (each wave's incoming data in its own
     // rows, overwritten by nobody else): 17.5 KB of LDS per workgroup, 8 workgroups per CU
@@ -807,9 +822,9 @@ __global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(const StepArgs a)
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (kLanes - 1);
     if (role == 0)
-        pair_body<0>(a, lds_obs, xchg, lane);
+        pair_body<0>(a, hot, lds_obs, xchg, lane);
     else
-        pair_body<1>(a, lds_obs, xchg, lane);
+        pair_body<1>(a, hot, lds_obs, xchg, lane);
 }
 
 // ---- constructor / reset / observe / policy kernels --------------------------------------------
@@ -938,13 +953,13 @@ static int launch_step_ai(const StepArgs& a, hipStream_t stream)
     const dim3 grid(blocks_for(a.n, kLanes)), block(kLanes);
     const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
     if (ai1 && ai2)
-        hipLaunchKernelGGL((step_kernel<true, true, MODE, SPARSE>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((step_kernel<true, true, MODE, SPARSE>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
     else if (ai1)
-        hipLaunchKernelGGL((step_kernel<true, false, MODE, SPARSE>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((step_kernel<true, false, MODE, SPARSE>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
     else if (ai2)
-        hipLaunchKernelGGL((step_kernel<false, true, MODE, SPARSE>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((step_kernel<false, true, MODE, SPARSE>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
     else
-        hipLaunchKernelGGL((step_kernel<false, false, MODE, SPARSE>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((step_kernel<false, false, MODE, SPARSE>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
     return (int)hipGetLastError();
 }
 
@@ -953,7 +968,7 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
 {
 #ifndef PZ_NO_PAIR_KERNEL
     if (MODE == kActions && a.n < PZ_TWO_WAVE_MAX_LANES && a.cfg.p1_computer == 0 && a.cfg.p2_computer == 0) {
-        hipLaunchKernelGGL(step_pair_kernel, dim3(blocks_for(a.n, kLanes)), dim3(2 * kLanes), 0, stream, a);
+        hipLaunchKernelGGL(step_pair_kernel, dim3(blocks_for(a.n, kLanes)), dim3(2 * kLanes), 0, stream, PZ_HOT_ARGS(a), a);
         return (int)hipGetLastError();
     }
 #endif
@@ -964,11 +979,11 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
         const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
         constexpr bool kSparse = MODE == kActions || MODE == kRandom;
         if (ai1 && ai2)
-            hipLaunchKernelGGL((step_kernel<true, true, MODE, kSparse, kScout>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((step_kernel<true, true, MODE, kSparse, kScout>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
         else if (ai1)
-            hipLaunchKernelGGL((step_kernel<true, false, MODE, kSparse, kScout>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((step_kernel<true, false, MODE, kSparse, kScout>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
         else if (ai2)
-            hipLaunchKernelGGL((step_kernel<false, true, MODE, kSparse, kScout>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((step_kernel<false, true, MODE, kSparse, kScout>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
         if (ai1 || ai2) return (int)hipGetLastError();
     }
 #endif

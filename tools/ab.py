@@ -17,12 +17,13 @@ from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO / "pika-zoo_amd"))
+from build import FLAGS as PRODUCT_FLAGS  # noqa: E402  (same compiler flags as the product library)
 LIBDIR = REPO / "pika-zoo_amd" / "lib"
 
 
 def build(name, flags):
     out = LIBDIR / f"ab_{name}.so"
-    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", *flags.split(),
+    cmd = ["hipcc", *PRODUCT_FLAGS, "-shared", "-fPIC", *flags.split(),
            f"-I{REPO / 'include'}", f"-I{REPO / 'pika-zoo_amd' / 'csrc'}", "-o", str(out),
            str(REPO / "pika-zoo_amd" / "csrc" / "pz_kernels.hip")]
     subprocess.check_call(cmd)

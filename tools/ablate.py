@@ -17,11 +17,12 @@ from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO / "pika-zoo_amd"))
+from build import FLAGS as PRODUCT_FLAGS  # noqa: E402  (same compiler flags as the product library)
 LIB = REPO / "pika-zoo_amd" / "lib" / "libpikazoo_hip_ablate.so"
 
 
 def build():
-    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-DPZ_ABLATE=1",
+    cmd = ["hipcc", *PRODUCT_FLAGS, "-shared", "-fPIC", "-DPZ_ABLATE=1",
            f"-I{REPO / 'include'}", f"-I{REPO / 'pika-zoo_amd' / 'csrc'}", "-o", str(LIB),
            str(REPO / "pika-zoo_amd" / "csrc" / "pz_kernels.hip")]
     subprocess.check_call(cmd)

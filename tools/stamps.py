@@ -17,13 +17,14 @@ import numpy as np
 
 REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO / "pika-zoo_amd"))
+from build import FLAGS as PRODUCT_FLAGS  # noqa: E402  (same compiler flags as the product library)
 LIB = REPO / "pika-zoo_amd" / "lib" / "stamps.so"
 
 
 def main():
     args = sys.argv[1:]
     if "--build" in args:
-        subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-DPZ_STAMPS=1",
+        subprocess.check_call(["hipcc", *PRODUCT_FLAGS, "-shared", "-fPIC", "-DPZ_STAMPS=1",
                                f"-I{REPO / 'include'}", f"-I{REPO / 'pika-zoo_amd' / 'csrc'}", "-o", str(LIB),
                                str(REPO / "pika-zoo_amd" / "csrc" / "pz_kernels.hip")])
         return
