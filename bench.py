@@ -106,7 +106,7 @@ def run_gpu(args, env, acts, warmup, steps, launch):
     def launch_range(t_lo, t_hi, stream):
         s = stream.cuda_stream
         for t in range(t_lo, t_hi):
-            rc = lib.pz_step(st, n, n, cfg, a_ptr + t * a_stride, a_ptr + t * a_stride + n * 4, o1, o2, r1, r2, tm,
+            rc = lib.pz_step(st, n, raw._stride, cfg, a_ptr + t * a_stride, a_ptr + t * a_stride + n * 4, o1, o2, r1, r2, tm,
                              None, s)
             if rc:
                 _native.check(rc, "pz_step")

@@ -112,7 +112,11 @@ class raw_env:
         self._cfg_ref = C.byref(cfg)
 
         n, dev = self.num_envs, self.device
-        self.state = torch.zeros((_native.STATE_WORDS, n), dtype=torch.int32, device=dev)
+        # columns are padded to a multiple of 64 games so that every workgroup's 256-byte segment of a column is
+        # aligned whatever num_envs is (a ragged pitch costs ~10 % per launch); `state` is the [44, n] view
+        self._stride = (n + 63) // 64 * 64
+        self._state_buf = torch.zeros((_native.STATE_WORDS, self._stride), dtype=torch.int32, device=dev)
+        self.state = self._state_buf[:, :n]
         self._obs = [torch.zeros((n, _native.OBS_DIM), dtype=torch.int32, device=dev) for _ in range(2)]
         # one 4-byte word per lane and agent; viewed as int32 or float32 (RewardByBallPosition)
         self._rew_raw = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
@@ -132,7 +136,8 @@ class raw_env:
         self.action_spaces = {a: Discrete(18) for a in self.possible_agents}
         self._spaces = {}
         with torch.cuda.device(self.device):
-            _native.check(self._lib.pz_init(self.state.data_ptr(), n, n, self._cfg_ref, self._stream()), "pz_init")
+            _native.check(self._lib.pz_init(self.state.data_ptr(), n, self._stride, self._cfg_ref, self._stream()),
+                          "pz_init")
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -205,7 +210,8 @@ class raw_env:
             raise RuntimeError("RecordEpisodeStatistics is already applied")
         wrapped = bool(self._cfg.ballpos_reward or self._cfg.normal_state_mode)
         self._cfg.episode_stats_mode = 2 if wrapped else 1
-        self._stats = torch.zeros((3, self.num_envs), dtype=torch.int32, device=self.device)
+        self._stats_buf = torch.zeros((3, self._stride), dtype=torch.int32, device=self.device)
+        self._stats = self._stats_buf[:, :self.num_envs]
 
     @property
     def episode_returns(self) -> Optional[torch.Tensor]:
@@ -313,7 +319,7 @@ class raw_env:
             if m.shape != (self.num_envs,):
                 raise ValueError(f"mask must have shape ({self.num_envs},)")
         with torch.cuda.device(self.device):
-            _native.check(self._lib.pz_reset(self.state.data_ptr(), self.num_envs, self.num_envs, self._cfg_ref,
+            _native.check(self._lib.pz_reset(self.state.data_ptr(), self.num_envs, self._stride, self._cfg_ref,
                                              _ptr(m), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
                                              self._stats_ptr(), self._stream()), "pz_reset")
         if self.scalar_api:
@@ -362,12 +368,12 @@ class raw_env:
                 raise IndexError(f"action out of range [0, {n_act})")
         p = self._ptrs
         if torch.cuda.current_device() == self.device.index:
-            rc = self._lib.pz_step(p[0], n, n, self._cfg_ref, a1.data_ptr(), a2.data_ptr(), p[1], p[2], p[3], p[4],
-                                   p[5], self._stats_ptr(), torch.cuda.current_stream().cuda_stream)
+            rc = self._lib.pz_step(p[0], n, self._stride, self._cfg_ref, a1.data_ptr(), a2.data_ptr(), p[1], p[2],
+                                   p[3], p[4], p[5], self._stats_ptr(), torch.cuda.current_stream().cuda_stream)
         else:
             with torch.cuda.device(self.device):
-                rc = self._lib.pz_step(p[0], n, n, self._cfg_ref, a1.data_ptr(), a2.data_ptr(), p[1], p[2], p[3],
-                                       p[4], p[5], self._stats_ptr(), self._stream())
+                rc = self._lib.pz_step(p[0], n, self._stride, self._cfg_ref, a1.data_ptr(), a2.data_ptr(), p[1], p[2],
+                                       p[3], p[4], p[5], self._stats_ptr(), self._stream())
         if rc:
             _native.check(rc, "pz_step")
         self.steps_done += 1
@@ -385,7 +391,7 @@ class raw_env:
         if t0 is None:
             t0 = self.steps_done
         with torch.cuda.device(self.device):
-            _native.check(self._lib.pz_step_random(self.state.data_ptr(), self.num_envs, self.num_envs,
+            _native.check(self._lib.pz_step_random(self.state.data_ptr(), self.num_envs, self._stride,
                                                    self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0),
                                                    int(k), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
                                                    self._rew_raw[0].data_ptr(), self._rew_raw[1].data_ptr(),
@@ -416,7 +422,7 @@ class raw_env:
                    "_term": torch.empty((k, n), dtype=torch.uint8, device=dev)}
         with torch.cuda.device(dev):
             _native.check(self._lib.pz_rollout_random(
-                self.state.data_ptr(), n, n, self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0), k,
+                self.state.data_ptr(), n, self._stride, self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0), k,
                 out["actions"].data_ptr(), out["_obs"][0].data_ptr(), out["_obs"][1].data_ptr(),
                 out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(), out["_term"].data_ptr(),
                 self._stats_ptr(), self._episodes.data_ptr(), self._stream()), "pz_rollout_random")
@@ -445,7 +451,7 @@ class raw_env:
         out["actions"] = actions
         with torch.cuda.device(dev):
             _native.check(self._lib.pz_step_many(
-                self.state.data_ptr(), n, n, self._cfg_ref, actions.data_ptr(), k, out["_obs"][0].data_ptr(),
+                self.state.data_ptr(), n, self._stride, self._cfg_ref, actions.data_ptr(), k, out["_obs"][0].data_ptr(),
                 out["_obs"][1].data_ptr(), out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(),
                 out["_term"].data_ptr(), self._stats_ptr(), self._episodes.data_ptr(), self._stream()),
                 "pz_step_many")
@@ -483,7 +489,7 @@ class raw_env:
         o1 = torch.empty_like(self._obs[0])
         o2 = torch.empty_like(self._obs[1])
         with torch.cuda.device(self.device):
-            _native.check(self._lib.pz_observe(self.state.data_ptr(), self.num_envs, self.num_envs,
+            _native.check(self._lib.pz_observe(self.state.data_ptr(), self.num_envs, self._stride,
                                                int(self._cfg.normalize_obs), o1.data_ptr(), o2.data_ptr(),
                                                self._stream()), "pz_observe")
         odt = self.obs_dtype
