@@ -284,12 +284,14 @@ def measure_rollout(args, shard, device, k, tape=False, p2_computer=False):
             "bytes_per_game_step": bytes_per_step, "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS}
 
 
-def load_traffic(workload_key):
-    """HBM bytes per launch from the committed PMC profile (profiles/traffic.json), or None."""
+def load_traffic(workload_key, num_envs):
+    """HBM bytes per launch from the committed PMC profile (profiles/traffic.json) of this workload at this batch
+    size, or None."""
     p = REPO / "profiles" / "traffic.json"
     if p.exists():
         try:
-            return json.loads(p.read_text()).get(workload_key, {}).get("hbm_bytes_per_launch")
+            entry = json.loads(p.read_text()).get(workload_key, {})
+            return entry.get("hbm_bytes_per_launch") if entry.get("num_envs") == num_envs else None
         except Exception:  # noqa: BLE001
             return None
     return None
@@ -370,7 +372,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(wl),
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(wl, args.num_envs),
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_us": main_res["launch_us"],
             },
         }
