@@ -11,22 +11,34 @@ columns and the two action vectors from HBM and writes state, both 35-dim observ
 rewards and the terminated flags.  The actions of all W+K steps are generated on device by the
 policy kernel BEFORE the timed region, so every input is resident in HBM when timing starts.
 
+Sequence of one measurement (every part replayed by the CPU oracle for the in-run parity check):
+  reset -> BURN-IN (untimed; --burn-in frames of the on-device policy, so that the timed frames are
+  steady-state play: rounds ending, auto-resets, collisions) -> W warm-up launches -> the K launches
+  captured in a hipGraph (repeated inside the graph until it holds >= 2 048 launches) -> one untimed
+  replay (graph upload + calibration) -> R timed replays, R chosen so that the timed region lasts at
+  least --min-time seconds whatever K is.  `steps` in the JSON line is K as given; `timed_steps` = the
+  launches actually timed; value = games * timed_steps / wall.
+
 Multi-GPU (torchrun, one rank per GPU): weak scaling, rank r owns global games
 [r*65536, (r+1)*65536); no collective on the step path, one SUM all-reduce of the counters after
 the timed region (RCCL).  Timing: barrier + synchronize on both sides, MAX over ranks.
 
 The single JSON line also carries
   roofline     -- algorithmic HBM bytes per launch (649 B/game-step) / average launch
-                  duration measured with HIP events on the launch stream, against 8 TB/s;
+                  duration measured with HIP events on the launch stream over the timed region, against
+                  8 TB/s (`frac`); the same from the wall clock `value` is computed from (`frac_wall`);
+                  and from the PMC-measured bytes of profiles/traffic.json (`frac_traffic`);
   cpu_baseline -- the CPU oracle (oracle/pz_oracle.c, a C port of the reference's Python step,
                   kind="port") timed on this host's cores on a bounded sample of the same workload,
-                  and used to check the GPU trajectories bit-for-bit on a lane subset.
+                  and used to check the GPU trajectories bit-for-bit on a lane subset;
+  configs      -- the other single-GPU BASELINE configs (2: 4 096 games, 3: player 2 = computer,
+                  5: fused wrappers), each timed the same way and oracle-checked.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -42,7 +54,11 @@ from pikazoo_amd import _native, dist, pikazoo_v0  # noqa: E402
 
 BYTES_PER_ENV_STEP = 8 * 44 + 297  # rd+wr state, 2 actions, 2x35 obs, 2 rewards, 1 flag
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
+INFINITY_CACHE_BYTES = 256 << 20
 ACTION_SEED = 1
+BURN_SEED = 2
+GRAPH_MIN_LAUNCHES = 2048          # a replay must dwarf its own host-side launch cost (10-16 us)
+WRAPPER_TABLE = (0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01)
 
 
 def parse_args():
@@ -54,30 +70,36 @@ def parse_args():
     ap.add_argument("--launch", choices=["graph", "cabi", "api"], default="graph",
                     help="graph: the K launches captured once in a hipGraph and replayed; cabi: K direct "
                          "C-ABI calls; api: K env.step() calls")
+    ap.add_argument("--min-time", type=float, default=0.25, help="minimum duration of the timed region (s)")
+    ap.add_argument("--burn-in", type=int, default=4096, help="untimed frames of random play before warm-up")
     ap.add_argument("--p2-computer", action="store_true", help="config 3: rule-based AI on player 2")
     ap.add_argument("--p1-computer", action="store_true", help="rule-based AI on player 1 (not a BASELINE config)")
     ap.add_argument("--wrappers", action="store_true", help="config 5: fused SimplifyAction+RewardByBallPosition")
+    ap.add_argument("--no-flight-tables", action="store_true",
+                    help="computer player: run the flight predictors in the kernel instead of the HBM look-up tables")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on CPU baseline threads")
     ap.add_argument("--check-lanes", type=int, default=2048, help="lanes replayed on the CPU oracle for parity")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and every oracle replay")
+    ap.add_argument("--no-configs", action="store_true", help="headline only (no configs 2/3/5 block)")
     ap.add_argument("--dist-backend", default=None,
                     help="torch.distributed backend (default nccl = RCCL). 'gloo' + PZ_BENCH_ONE_DEVICE=1 rehearses "
                          "the N>1 path with every rank on cuda:0 of a 1-GPU box")
-    ap.add_argument("--extra", action="store_true", help="also time configs 3 and 5 and report them under 'extra'")
+    ap.add_argument("--extra", action="store_true", help="also time rollouts, launch modes and a batch sweep")
+    ap.add_argument("--rollouts", action="store_true", help="only the k-frame kernels (for profiling runs)")
     return ap.parse_args()
 
 
-def make_env(args, shard, p2_computer, wrappers, device):
+def make_env(shard, device, *, num_envs, p1_computer=False, p2_computer=False, wrappers=False, flight_tables=True):
     from pikazoo_amd.wrappers import RewardByBallPosition, SimplifyAction
 
     env = pikazoo_v0.env(winning_score=15, serve="winner", is_player2_computer=p2_computer,
-                         is_player1_computer=args.p1_computer,
-                         num_envs=shard.n_local, device=device, seed=0, env_id_base=shard.env_id_base,
-                         auto_reset=True, validate_actions=False)
+                         is_player1_computer=p1_computer,
+                         num_envs=num_envs, device=device, seed=0, env_id_base=shard.env_id_base,
+                         auto_reset=True, validate_actions=False, flight_tables=flight_tables)
     if wrappers:
         env = SimplifyAction(env)
-        env = RewardByBallPosition(env, (0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01), 216, 176)
+        env = RewardByBallPosition(env, WRAPPER_TABLE, 216, 176)
     return env
 
 
@@ -92,14 +114,28 @@ def pregenerate_actions(raw, total_steps):
     return acts
 
 
-def run_gpu(args, env, acts, warmup, steps, launch):
-    """W untimed + K timed launches.  Returns (wall seconds of the K steps, event ms of the K steps)."""
+def burn_in(raw, frames):
+    """Untimed random play (k-frame launches of the on-device policy, stream BURN_SEED, t = 0..frames-1)."""
+    done = 0
+    while done < frames:
+        k = min(512, frames - done)
+        raw.step_random(BURN_SEED, t0=done, k=k)
+        done += k
+    raw.steps_done = 0
+
+
+def run_gpu(env, acts, warmup, steps, launch, min_time):
+    """W untimed launches, then the K launches repeated until the timed region lasts >= min_time.
+
+    Returns dict(wall, event_ms, timed_steps, passes): `passes` = how many times the K-step action
+    sequence ran in total (untimed calibration pass included) -- what the oracle has to replay."""
     raw = env.unwrapped
     lib = _native.load()
     n = raw.num_envs
     st, cfg = raw.state.data_ptr(), raw._cfg_ref
     o1, o2 = raw._obs[0].data_ptr(), raw._obs[1].data_ptr()
     r1, r2, tm = raw._rew_raw[0].data_ptr(), raw._rew_raw[1].data_ptr(), raw._term_u8.data_ptr()
+    tables = raw._tables_ref
     a_ptr = acts.data_ptr()
     a_stride = 2 * n * 4
 
@@ -107,40 +143,49 @@ def run_gpu(args, env, acts, warmup, steps, launch):
         s = stream.cuda_stream
         for t in range(t_lo, t_hi):
             rc = lib.pz_step(st, n, raw._stride, cfg, a_ptr + t * a_stride, a_ptr + t * a_stride + n * 4, o1, o2, r1, r2, tm,
-                             None, s)
+                             None, tables, s)
             if rc:
                 _native.check(rc, "pz_step")
 
     stream = torch.cuda.Stream(device=raw.device)
-    graph = None
+    inner = 1  # repetitions of the K-step sequence inside one timed unit
     with torch.cuda.stream(stream):
         if launch == "api":
             names = raw.possible_agents
             # the per-step action dicts a policy would hand over (views built outside the timed loop)
             feed = [{names[0]: acts[t, 0], names[1]: acts[t, 1]} for t in range(warmup + steps)]
 
-            def timed(t_lo, t_hi):
+            def unit():
                 step = env.step
-                for t in range(t_lo, t_hi):
+                for t in range(warmup, warmup + steps):
                     step(feed[t])
-            timed(0, warmup)
+            for t in range(warmup):
+                env.step(feed[t])
         else:
             launch_range(0, warmup, stream)
             if launch == "graph":
+                inner = max(1, math.ceil(GRAPH_MIN_LAUNCHES / steps))
                 stream.synchronize()
-                state_before = raw.state.clone()
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: the RCCL watchdog thread of a multi-rank run may poll events while we capture
                 with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
-                    launch_range(warmup, warmup + steps, torch.cuda.current_stream(raw.device))
-                graph.replay()                 # untimed first replay (graph upload), then rewind
-                raw.state.copy_(state_before)
+                    for _ in range(inner):
+                        launch_range(warmup, warmup + steps, torch.cuda.current_stream(raw.device))
+                # (capture records the launches without running them)
 
-                def timed(t_lo, t_hi):
+                def unit():
                     graph.replay()
             else:
-                def timed(t_lo, t_hi):
-                    launch_range(t_lo, t_hi, stream)
+                def unit():
+                    launch_range(warmup, warmup + steps, stream)
+        # untimed calibration pass (also the graph upload)
+        stream.synchronize()
+        t0 = time.perf_counter()
+        unit()
+        stream.synchronize()
+        est = time.perf_counter() - t0
+        reps = max(1, math.ceil(min_time / max(est, 1e-6)))
+        reps = int(dist.all_reduce_max(reps, device=dist.collective_device(raw.device)))  # same count on every rank
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         stream.synchronize()
@@ -148,14 +193,17 @@ def run_gpu(args, env, acts, warmup, steps, launch):
         torch.cuda.synchronize(raw.device)
         t0 = time.perf_counter()
         ev0.record(stream)
-        timed(warmup, warmup + steps)
+        for _ in range(reps):
+            unit()
         ev1.record(stream)
         torch.cuda.synchronize(raw.device)
         dist.barrier()
         wall = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
-    raw.steps_done = warmup + steps
-    return wall, ev_ms
+    passes = inner * (reps + 1)
+    raw.steps_done = warmup + steps * passes
+    return {"wall": wall, "event_ms": ev_ms, "timed_steps": steps * inner * reps, "passes": passes,
+            "replays": reps, "launches_per_replay": steps * inner}
 
 
 def usable_cores(requested: int) -> int:
@@ -171,19 +219,43 @@ def usable_cores(requested: int) -> int:
     return max(1, min(n, requested))
 
 
-def cpu_baseline(args, raw_gpu, p2_computer, wrappers, total_steps):
-    """Oracle timed on the host cores (bounded sample) + bit-exact check of a GPU lane subset."""
+def oracle_config(po, raw, p1_computer, p2_computer, wrappers, base):
+    return po.make_config(winning_score=15, serve="winner", is_player2_computer=p2_computer,
+                          is_player1_computer=p1_computer, simplify_action=wrappers,
+                          additional_reward=WRAPPER_TABLE if wrappers else None, seed=0, env_id_base=base)
+
+
+def oracle_parity(raw, seq, p1_computer, p2_computer, wrappers, lanes, cores):
+    """Replay burn-in + warm-up + every pass of the K-step sequence on the first `lanes` games with the
+    CPU oracle and compare the full state bit for bit."""
+    from oracle import pz_oracle as po
+
+    po.build()
+    k = min(lanes, raw.num_envs)
+    chk = po.OracleEnv(k, oracle_config(po, raw, p1_computer, p2_computer, wrappers, raw.env_id_base), nthreads=cores)
+    chk.reset()
+    if seq["burn_in"]:
+        chk.rollout_random(BURN_SEED, 0, seq["burn_in"])
+    if seq["warmup"]:
+        chk.rollout_random(ACTION_SEED, 0, seq["warmup"])
+    for _ in range(seq["passes"]):
+        chk.rollout_random(ACTION_SEED, seq["warmup"], seq["steps"])
+    gpu_state = raw.state[:, :k].cpu().numpy()
+    total = seq["burn_in"] + seq["warmup"] + seq["passes"] * seq["steps"]
+    return {"parity_lanes_checked": k, "parity_steps_checked": total,
+            "parity_bit_exact": bool((gpu_state == chk.state).all())}
+
+
+def cpu_baseline(args, raw_gpu, p2_computer, wrappers):
+    """Oracle timed on the host cores (bounded sample of the same workload)."""
     from oracle import pz_oracle as po
 
     po.build()
     cores = usable_cores(args.cpu_threads)
-    table = (0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01) if wrappers else None
     n = raw_gpu.num_envs
 
     def cfg(base):
-        return po.make_config(winning_score=15, serve="winner", is_player2_computer=p2_computer,
-                              is_player1_computer=args.p1_computer,
-                              simplify_action=wrappers, additional_reward=table, seed=0, env_id_base=base)
+        return oracle_config(po, raw_gpu, args.p1_computer, p2_computer, wrappers, base)
 
     # timing sample: the same 65 536-game batch, as many 250-step chunks as fit the budget
     env = po.OracleEnv(n, cfg(raw_gpu.env_id_base), nthreads=cores)
@@ -211,43 +283,50 @@ def cpu_baseline(args, raw_gpu, p2_computer, wrappers, total_steps):
         a1, a2 = po.random_actions(1, raw_gpu.env_id_base, ACTION_SEED, t, raw_gpu.n_actions)
         env0.step(a1, a2)
     one_env = 10000 / (time.perf_counter() - t0)
-    # parity: replay the first check-lanes games for every step the GPU ran
-    k = min(args.check_lanes, n)
-    chk = po.OracleEnv(k, cfg(raw_gpu.env_id_base), nthreads=cores)
-    chk.reset()
-    chk.rollout_random(ACTION_SEED, 0, total_steps)
-    gpu_state = raw_gpu.state[:, :k].cpu().numpy()
-    parity = bool((gpu_state == chk.state).all())
     return {
         "value": value, "unit": "env-steps/s", "cores": cores, "kind": "port",
         "sample": f"{n} games x {sample_steps} steps of the same workload, OpenMP static lane partition "
                   f"over {cores} threads ({t_spent:.1f} s)",
         "one_core_value": one_core,
         "config1_one_env_steps_per_s": one_env,  # 1 game stepped call by call from Python (ctypes overhead-bound)
-        "parity_lanes_checked": k, "parity_steps_checked": total_steps, "parity_bit_exact": parity,
     }
 
 
-def measure(args, shard, device, p2_computer, wrappers, launch, with_cpu):
-    env = make_env(args, shard, p2_computer, wrappers, device)
+def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=False, launch=None, steps=None,
+            warmup=None, burn=None, min_time=None, check_lanes=0, flight_tables=True):
+    num_envs = args.num_envs if num_envs is None else num_envs
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    burn = args.burn_in if burn is None else burn
+    min_time = args.min_time if min_time is None else min_time
+    launch = args.launch if launch is None else launch
+    env = make_env(shard, device, num_envs=num_envs, p1_computer=args.p1_computer, p2_computer=p2_computer,
+                   wrappers=wrappers, flight_tables=flight_tables)
     raw = env.unwrapped
     env.reset()
-    total = args.warmup + args.steps
-    acts = pregenerate_actions(raw, total)
+    burn_in(raw, burn)
+    acts = pregenerate_actions(raw, warmup + steps)
     torch.cuda.synchronize(device)
-    wall, ev_ms = run_gpu(args, env, acts, args.warmup, args.steps, launch)
+    run = run_gpu(env, acts, warmup, steps, launch, min_time)
     cdev = dist.collective_device(device)  # counters live on the GPU under nccl (RCCL), on the CPU under gloo
-    wall = dist.all_reduce_max(wall, device=cdev)
-    terminated_now = int(raw._term_u8.sum().item())
+    wall = dist.all_reduce_max(run["wall"], device=cdev)
     n_total, = dist.all_reduce_sum([raw.num_envs], device=cdev)
+    launch_us = run["event_ms"] * 1e3 / run["timed_steps"]
+    alg = BYTES_PER_ENV_STEP * num_envs
     res = {
-        "wall_s": wall, "event_ms": ev_ms, "n_total": n_total,
-        "value": n_total * args.steps / wall,
-        "launch_us": ev_ms * 1e3 / args.steps,
-        "terminated_in_last_frame": terminated_now,
+        "wall_s": wall, "event_ms": run["event_ms"], "n_total": n_total, "timed_steps": run["timed_steps"],
+        "replays": run["replays"], "launches_per_replay": run["launches_per_replay"],
+        "value": n_total * run["timed_steps"] / wall,
+        "launch_us": launch_us, "wall_us_per_step": wall * 1e6 / run["timed_steps"],
+        "achieved_GBps": alg / (launch_us * 1e-6) / 1e9,
+        "raw": raw,
     }
-    if with_cpu:
-        res["cpu"] = cpu_baseline(args, raw, p2_computer, wrappers, total)
+    res["frac"] = res["achieved_GBps"] / HBM_PEAK_GBPS
+    res["frac_wall"] = alg / (res["wall_us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
+    if check_lanes and not args.no_cpu and dist.get_rank() == 0:
+        seq = {"burn_in": burn, "warmup": warmup, "steps": steps, "passes": run["passes"]}
+        res.update(oracle_parity(raw, seq, args.p1_computer, p2_computer, wrappers, check_lanes,
+                                 usable_cores(args.cpu_threads)))
     del acts
     return res
 
@@ -257,10 +336,11 @@ def measure_rollout(args, shard, device, k, tape=False, p2_computer=False):
     launch, every frame's outputs written to trajectory tensors (state in registers, read/written once
     per launch).  Honest bytes per game-step of THESE kernels: 297 (8 of them action words written
     resp. read) + 352/k."""
-    env = make_env(args, shard, p2_computer, False, device)
+    env = make_env(shard, device, num_envs=args.num_envs, p1_computer=args.p1_computer, p2_computer=p2_computer)
     raw = env.unwrapped
     env.reset()
-    launches = max(1, args.steps // k)
+    burn_in(raw, min(args.burn_in, 1024))
+    launches = max(1, 2048 // k)
     tapes = None
     if tape:
         acts = pregenerate_actions(raw, (launches + 1) * k).view(launches + 1, k, 2, raw.num_envs)
@@ -298,14 +378,39 @@ def load_traffic(workload_key, num_envs):
 
 
 def ensure_built():
-    """Build libpikazoo_hip.so if the tree does not carry it (hipcc is on every box of this image)."""
-    if not _native.LIB_PATH.exists():
-        import importlib.util
+    """(Re)build libpikazoo_hip.so when it is missing or was not built from the sources in this tree
+    (build.py compares the source hash baked into the library; hipcc is on every box of this image)."""
+    import importlib.util
 
-        spec = importlib.util.spec_from_file_location("pz_build", REPO / "pika-zoo_amd" / "build.py")
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        mod.build()
+    spec = importlib.util.spec_from_file_location("pz_build", REPO / "pika-zoo_amd" / "build.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build()
+
+
+def kernel_name(num_envs, ai, tables):
+    if num_envs >= 393216:
+        return "pz::step_kernel<AI1,AI2,kActions,true> via pz_step"
+    if ai and not tables:
+        return "pz::step_kernel<AI1,AI2,kActions,true,kScoutLoads> via pz_step"
+    return "pz::step_pair_kernel<AI1,AI2> via pz_step"
+
+
+def regime(num_envs):
+    """Where the per-step working set (state + both observation tensors + rewards, re-touched every launch)
+    lives: the 256 MiB Infinity Cache or HBM proper."""
+    ws = num_envs * (44 * 4 + 2 * 35 * 4 + 8 + 1 + 8)
+    return "infinity-cache-resident" if ws < INFINITY_CACHE_BYTES // 2 else "hbm-streaming"
+
+
+def config_entry(r, workload, num_envs):
+    e = {"workload": workload, "num_envs": num_envs, "value": r["value"], "launch_us": r["launch_us"],
+         "wall_us_per_step": r["wall_us_per_step"], "frac": r["frac"], "frac_wall": r["frac_wall"],
+         "timed_steps": r["timed_steps"]}
+    for k in ("parity_bit_exact", "parity_lanes_checked", "parity_steps_checked"):
+        if k in r:
+            e[k] = r[k]
+    return e
 
 
 def main():
@@ -323,42 +428,82 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    dist.barrier()  # rank 0 may have rebuilt the library: nobody loads it earlier
     shard = dist.weak_shard(args.num_envs, rank, world)
+    tables = not args.no_flight_tables
+    single = rank == 0 and world == 1
 
-    main_res = measure(args, shard, device, args.p2_computer, args.wrappers, args.launch,
-                       with_cpu=(rank == 0 and world == 1 and not args.no_cpu))
+    if args.rollouts:
+        out = {"rollout_k32": measure_rollout(args, shard, device, k=32),
+               "step_many_k32": measure_rollout(args, shard, device, k=32, tape=True),
+               "rollout_k32_p2_computer": measure_rollout(args, shard, device, k=32, p2_computer=True)}
+        print(json.dumps(out), flush=True)
+        return
+
+    main_res = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers,
+                       check_lanes=args.check_lanes if single else 0, flight_tables=tables)
+    raw_main = main_res.pop("raw")
+    cpu = None
+    if single and not args.no_cpu:
+        cpu = cpu_baseline(args, raw_main, args.p2_computer, args.wrappers)
+        for k in ("parity_bit_exact", "parity_lanes_checked", "parity_steps_checked"):
+            cpu[k] = main_res.get(k)
+    del raw_main
+
+    configs = {}
+    if single and not args.no_configs:
+        # the other single-GPU BASELINE configs, each timed like the headline (shorter) and oracle-checked
+        sub = dict(steps=1000, warmup=100, burn=2048, min_time=0.1, check_lanes=1024, launch="graph")
+        specs = {
+            "cfg2": ("4 096 games, random/random, winning_score=15, serve=winner", dict(num_envs=4096)),
+            "cfg3": ("65 536 games, player 2 = rule-based computer (flight look-up tables in HBM)",
+                     dict(num_envs=65536, p2_computer=True)),
+            "cfg3_compute": ("65 536 games, player 2 = rule-based computer, flight predictors computed in the kernel",
+                             dict(num_envs=65536, p2_computer=True, flight_tables=False)),
+            "cfg5": ("65 536 games, fused SimplifyAction + RewardByBallPosition",
+                     dict(num_envs=65536, wrappers=True)),
+        }
+        for key, (wl, kw) in specs.items():
+            r = measure(args, dist.weak_shard(kw["num_envs"], rank, world), device, **{**sub, **kw})
+            r.pop("raw")
+            configs[key] = config_entry(r, wl, kw["num_envs"])
+
     extra = {}
     if args.extra and world == 1:
-        for key, (ai, wr) in {"cfg3_p2_computer": (True, False), "cfg5_fused_wrappers": (False, True)}.items():
-            r = measure(args, shard, device, ai, wr, args.launch, with_cpu=False)
-            extra[key] = {"value": r["value"], "launch_us": r["launch_us"]}
         extra["rollout_k32"] = measure_rollout(args, shard, device, k=32)
         extra["step_many_k32"] = measure_rollout(args, shard, device, k=32, tape=True)
         extra["rollout_k32_p2_computer"] = measure_rollout(args, shard, device, k=32, p2_computer=True)
         # the same kernel at larger batches (more waves per SIMD hide each other's latency)
         sweep = {}
         for n_big in (262144, 524288, 1048576):
-            a2 = argparse.Namespace(**{**vars(args), "num_envs": n_big, "steps": 300, "warmup": 50})
-            r = measure(a2, dist.weak_shard(n_big, rank, world), device, False, False, "cabi", with_cpu=False)
-            gbps = BYTES_PER_ENV_STEP * n_big / (r["launch_us"] * 1e-6) / 1e9
-            sweep[str(n_big)] = {"value": r["value"], "launch_us": r["launch_us"], "achieved_GBps": gbps,
-                                 "frac_of_8TBps": gbps / HBM_PEAK_GBPS}
+            r = measure(args, dist.weak_shard(n_big, rank, world), device, num_envs=n_big, steps=300, warmup=50,
+                        burn=512, min_time=0.1, launch="cabi")
+            r.pop("raw")
+            sweep[str(n_big)] = {"value": r["value"], "launch_us": r["launch_us"], "achieved_GBps": r["achieved_GBps"],
+                                 "frac_of_8TBps": r["frac"], "regime": regime(n_big)}
         extra["batch_sweep_random_random"] = sweep
         for mode in ("cabi", "api"):
-            r = measure(args, shard, device, args.p2_computer, args.wrappers, mode, with_cpu=False)
+            r = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers, launch=mode,
+                        burn=512, min_time=0.1)
+            r.pop("raw")
             extra[f"launch_{mode}"] = {"value": r["value"], "launch_us": r["launch_us"]}
 
     if rank == 0:
-        launch_s = main_res["launch_us"] * 1e-6
         alg_bytes = BYTES_PER_ENV_STEP * args.num_envs
-        achieved = alg_bytes / launch_s / 1e9
         wl = "cfg3" if args.p2_computer else ("cfg5" if args.wrappers else "random_random")
+        traffic = load_traffic(wl, args.num_envs)
+        launch_s = main_res["launch_us"] * 1e-6
         out = {
             "metric": "env-steps/sec (random policy, 65 536 envs per GPU)",
             "value": main_res["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": main_res["wall_s"] * 1e3 / args.steps,
+            "warmup": args.warmup, "ms_per_step": main_res["wall_us_per_step"] * 1e-3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic",
+            "timed_steps": main_res["timed_steps"], "replays": main_res["replays"],
+            "launches_per_replay": main_res["launches_per_replay"], "timed_seconds": main_res["wall_s"],
+            "burn_in_frames": args.burn_in,
+            "rccl_ranks": dist.world_size(), "dist_backend": dist.backend_name(),
+            "build_id": _native.build_id(),
             "config": {
                 "workload": f"{args.num_envs} games per GPU, both players uniform-random actions "
                             f"(Philox policy stream pre-generated in HBM), winning_score=15, serve=winner, "
@@ -366,18 +511,23 @@ def main():
                             f"fused_wrappers={args.wrappers}",
                 "num_envs_per_gpu": args.num_envs, "num_envs_total": main_res["n_total"],
                 "launch": args.launch,
-                "kernel": ("pz::step_kernel<AI1,AI2,kActions,true> via pz_step" if args.num_envs >= 393216
-                           else "pz::step_kernel<AI1,AI2,kActions,true,kScoutLoads> via pz_step" if args.p2_computer or args.p1_computer
-                           else "pz::step_pair_kernel via pz_step"),
+                "kernel": kernel_name(args.num_envs, args.p2_computer or args.p1_computer, tables),
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(wl, args.num_envs),
+                "bound": "hbm", "achieved": main_res["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": main_res["frac"], "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_us": main_res["launch_us"],
+                # the same fraction on the wall clock `value` is computed from (launch gaps included)
+                "frac_wall": main_res["frac_wall"],
+                # ... and with the PMC-measured bytes instead of the 649 B/game-step contract figure
+                "frac_traffic": (traffic / launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                "regime": regime(args.num_envs),
             },
         }
-        if "cpu" in main_res:
-            out["cpu_baseline"] = main_res["cpu"]
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if configs:
+            out["configs"] = configs
         if extra:
             out["extra"] = extra
         print(json.dumps(out), flush=True)

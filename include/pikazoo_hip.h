@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PZ_ABI_VERSION 2
+#define PZ_ABI_VERSION 3
 #define PZ_STATE_WORDS 44
 #define PZ_OBS_DIM 35
 
@@ -102,12 +102,38 @@ typedef struct pz_config {
     int64_t env_id_base;          /* global id of lane 0 (shards of one job use disjoint ranges) */
 } pz_config;
 
+/* ---- flight look-up tables of the computer player (optional; caller-owned device memory) -----
+ * The two flight predictors of the rule-based computer player are pure functions of a few small
+ * integers, so they can be tabulated once per device and looked up by the step kernels instead of
+ * being iterated every frame (the slowest flight of a launch otherwise sets the launch's duration):
+ *   landing    calculate_expected_landing_point_x_for (physics.py:643-686):
+ *              uint16 [2*PZ_FT_YV_MAX+1 y velocities][23 x velocities][253 y][413 x]
+ *              (x 20..432, y 0..252, x velocity -20, -10..10, 20 -- the only values play produces:
+ *              physics.py:606-613,626-629 -- |y velocity| <= PZ_FT_YV_MAX);
+ *   power_hit  expected_landing_point_x_when_power_hit (physics.py:820-884) for the six
+ *              (x_direction, y_direction) candidates of decide_whether_input_power_hit (:796-816):
+ *              uint16 [PZ_FT_HIT_YV_MAX+1 |y velocity|][192 y][413 x][8] (y 61..252; entries 6,7 unused).
+ * pz_build_flight_tables fills them with the frame-by-frame iteration of the reference (the form
+ * pz_selftest_predictor exposes as out_iter).  A ball state outside a table's domain is computed in
+ * the kernel as before, so results never depend on whether tables are passed. */
+#define PZ_FT_YV_MAX 96
+#define PZ_FT_HIT_YV_MAX 64
+typedef struct pz_flight_tables {
+    const uint16_t *landing;     /* pz_flight_table_bytes(0) bytes, or NULL */
+    const uint16_t *power_hit;   /* pz_flight_table_bytes(1) bytes, 16-byte aligned, or NULL */
+} pz_flight_tables;
+int64_t pz_flight_table_bytes(int32_t which);   /* 0: landing, 1: power_hit */
+int pz_build_flight_tables(uint16_t *landing, uint16_t *power_hit, void *stream);
+
 /* ---- introspection -------------------------------------------------------------------- */
 int pz_abi_version(void);
 int pz_state_words(void);           /* = PZ_STATE_WORDS */
 int pz_obs_dim(void);               /* = PZ_OBS_DIM */
 int pz_config_bytes(void);          /* = sizeof(pz_config), for binding self-checks */
 const char *pz_error_string(int code);
+/* hex digest of the sources this library was compiled from (pz_kernels.hip, pz_physics.hpp, this header),
+ * baked in by pika-zoo_amd/build.py; the Python binding refuses a library whose id differs from the tree's. */
+const char *pz_build_id(void);
 
 /* ---- raw_env.__init__ : pikazoo_env.py:79-141 -> PikaPhysics physics.py:107-123 ---------
  * Fresh state for n games; consumes env-RNG draws 0,1 (the two boldness draws). */
@@ -127,18 +153,20 @@ int pz_observe(const int32_t *state, int64_t n, int64_t stride, int32_t normaliz
 
 /* ---- raw_env.step : pikazoo_env.py:175-240 (one frame of every game, one launch) ---------
  * act_p1/act_p2: int32[n] in [0,18) (or [0,13) with simplify_action).
- * rew_p1/rew_p2: int32[n] (+1/-1/0), or float32[n] when cfg->ballpos_reward.
+ * rew_p1/rew_p2: int32[n] (+1/-1/0), or float32[n] when cfg->ballpos_reward or cfg->normal_state_mode.
  * terminated:    uint8[n] = game_ended after this frame (terminations of both agents);
  *                truncations are always False in the reference (:234) and are not written.
  * episode_stats: NULL, or 4-byte words [3][stride] = episode return of player 1, of player 2
  *                (typed like the rewards) and episode length -- what RecordEpisodeStatistics
  *                reports as infos[agent]["episode"] = {"r", "l"} on a terminal frame; zeroed by
  *                reset (pz_reset or the in-place auto reset). Used when cfg->episode_stats_mode != 0.
- * With cfg->normalize_obs the observation buffers receive float32 bit patterns. */
+ * With cfg->normalize_obs the observation buffers receive float32 bit patterns.
+ * tables: NULL, or the flight look-up tables above (used when a player is the computer). */
 int pz_step(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
             const int32_t *act_p1, const int32_t *act_p2,
             int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
-            uint8_t *terminated, int32_t *episode_stats, void *stream);
+            uint8_t *terminated, int32_t *episode_stats, const pz_flight_tables *tables,
+            void *stream);
 
 /* ---- the same frame with the uniform random policy drawn on device ----------------------
  * actions of game g at step t come from Philox4x32-10(key=action_seed,
@@ -151,7 +179,7 @@ int pz_step_random(int32_t *state, int64_t n, int64_t stride, const pz_config *c
                    uint64_t action_seed, uint64_t t0, int32_t k,
                    int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
                    uint8_t *terminated, int32_t *episode_stats, int64_t *episodes_done,
-                   void *stream);
+                   const pz_flight_tables *tables, void *stream);
 
 /* ---- a k-frame rollout of the random policy with EVERY frame's outputs kept ---------------
  * Same trajectories as k calls of pz_step_random(k=1), in ONE launch: the state is read once,
@@ -165,7 +193,7 @@ int pz_rollout_random(int32_t *state, int64_t n, int64_t stride, const pz_config
                       uint64_t action_seed, uint64_t t0, int32_t k, int32_t *actions,
                       int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
                       uint8_t *terminated, int32_t *episode_stats, int64_t *episodes_done,
-                      void *stream);
+                      const pz_flight_tables *tables, void *stream);
 
 /* ---- k frames of GIVEN actions in one launch, every frame's outputs kept -------------------
  * actions: int32[k][2][n] (frame, agent, game) -- e.g. a recorded action tape or an open-loop
@@ -175,7 +203,7 @@ int pz_step_many(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg
                  const int32_t *actions, int32_t k,
                  int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
                  uint8_t *terminated, int32_t *episode_stats, int64_t *episodes_done,
-                 void *stream);
+                 const pz_flight_tables *tables, void *stream);
 
 /* ---- the policy stream alone (for hosts that want the actions in HBM) -------------------- */
 int pz_random_actions(int32_t *act_p1, int32_t *act_p2, int64_t n, int64_t env_id_base,

@@ -7,6 +7,7 @@ HIP runtime, not against torch.  hipcc cross-compiles without a GPU present.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -33,22 +34,49 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def source_id() -> str:
+    """Digest of the sources and compiler flags the library is built from; baked into the library as
+    ``pz_build_id()`` so that a stale prebuilt .so (git-ignored, but shipped to the GPU box) is never run."""
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(d.name.encode() + b"\0" + d.read_bytes() + b"\0")
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+_ID_MARKER = b"pz_build_id:"
+
+
+def library_id(lib: Path = LIB):
+    """The build id baked into a built library, or None (missing file / pre-build-id library).  Read from
+    the file's bytes (the library stores it behind the marker ``pz_build_id:``), not through dlopen: a
+    stale library mapped into this process would shadow the rebuilt one of the same name."""
+    if not lib.exists():
+        return None
+    data = lib.read_bytes()
+    at = data.find(_ID_MARKER)
+    if at < 0:
+        return None
+    end = data.find(b"\0", at)
+    return data[at + len(_ID_MARKER):end].decode(errors="replace")
+
+
 def needs_build() -> bool:
-    if not LIB.exists():
-        return True
-    t = LIB.stat().st_mtime
-    return any(d.stat().st_mtime > t for d in DEPS)
+    return library_id() != source_id()
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
     if not force and not needs_build():
         return LIB
     LIB_DIR.mkdir(parents=True, exist_ok=True)
-    cmd = [hipcc_path(), *FLAGS, "-shared", "-fPIC",
-           f"-I{INCLUDE}", f"-I{CSRC}", *extra_flags, "-o", str(LIB), *map(str, SOURCES)]
+    # compile to a temporary name and rename: other ranks / processes never see a half-written library
+    tmp = LIB.with_suffix(f".so.tmp{os.getpid()}")
+    cmd = [hipcc_path(), *FLAGS, "-shared", "-fPIC", f'-DPZ_BUILD_ID="{source_id()}"',
+           f"-I{INCLUDE}", f"-I{CSRC}", *extra_flags, "-o", str(tmp), *map(str, SOURCES)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
     return LIB
 
 

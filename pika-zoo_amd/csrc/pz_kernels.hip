@@ -87,8 +87,19 @@ struct StepArgs {
     uint8_t* terminated;
     int32_t* episode_stats;  // [3][stride] words: return p1, return p2, length (nullptr = off)
     unsigned long long* episodes_done;
+    pz_flight_tables tables;  // device pointers or NULL (pz_flight_tables in the header)
     pz_config cfg;
 };
+
+__device__ __forceinline__ FlightLut make_lut(const pz_flight_tables& t)
+{
+    FlightLut lut;
+    lut.has_landing = t.landing != nullptr;
+    lut.has_power_hit = t.power_hit != nullptr;
+    lut.landing = make_rsrc(t.landing, lut.has_landing ? (uint32_t)(kFtLandingEntries * 2) : 0u);
+    lut.power_hit = make_rsrc(t.power_hit, lut.has_power_hit ? (uint32_t)(kFtHitEntries * 16) : 0u);
+    return lut;
+}
 
 // ---- state columns <-> registers -----------------------------------------------------------
 __device__ __forceinline__ void load_player(Player& p, const StateIO& io, int c0)
@@ -175,13 +186,12 @@ __device__ __forceinline__ void store_game(const Game& g, const StateIO& io, boo
     io.st(PZ_E_RNG_DRAW_COUNTER, (int32_t)g.e.rng);
 }
 
-// Write-back for HBM-bound batches (state + observations no longer fit the 256 MB Infinity
-// Cache).  Columns that change on nearly every frame are stored unconditionally; the 24 columns
-// that change rarely (scores, flags, boldness, diving/lying state, collision debounce, ball x
-// velocity ...: on average 80 % of their 32-byte sectors are untouched by a frame of random
-// play) are stored only by the lanes whose value changed, and not at all when no lane of the
-// wave changed.  Measured: -10 % per launch at 524 288 games, +3 % at 65 536 (where the launch
-// is latency- not traffic-bound), hence selected by batch size on the host.
+// Changed-only write-back, used by every launch that writes the state back after ONE frame.  Columns
+// that change on nearly every frame are stored unconditionally; the 24 columns that change rarely
+// (scores, flags, boldness, diving/lying state, collision debounce, ball x velocity ...: on average
+// 80 % of their 32-byte sectors are untouched by a frame of random play) are stored only by the lanes
+// whose value changed, and not at all when no lane of the wave changed.  Measured: -10 % per launch at
+// 524 288 games, -5 % at 65 536 in the pair kernel (7.91 -> 7.48 us).
 __device__ __forceinline__ void store_player_changed(const Player& p, const Player& o, const StateIO& io, int c0)
 {
     io.st(c0 + PZ_P_X, p.x);
@@ -600,6 +610,7 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
 
     Game g{};
     const RngId id = make_rng_id(a.cfg, live ? i : 0);
+    const FlightLut lut = make_lut(a.tables);
     int reward = 0;
     bool frozen = false;
     bool ex_pending = false;  // SCOUT: the scout wave stores this lane's expected_landing_point_x
@@ -659,7 +670,7 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
 #else
             const bool last_frame = s == a.k - 1;
 #endif
-            reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane,
+            reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane, lut,
                                                  ScoutLink{cand, hits, posts}, nullptr, last_frame);
             finished += (unsigned int)(live && g.e.game_ended && !frozen);
             rw = shape_rewards(a.cfg, g, reward, frozen);
@@ -675,7 +686,7 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
         }
     } else if (!PZ_SKIP_FRAME) {
         const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
-        reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane,
+        reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane, lut,
                                              ScoutLink{cand, hits, posts}, &ex_pending);
         finished = (unsigned int)(live && g.e.game_ended && !frozen);
         rw = shape_rewards(a.cfg, g, reward, frozen);
@@ -707,14 +718,17 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
 }
 
 // ---- the pair kernel: two waves per 64 games, split by player (see step_games_pair) ---------------
-// Used for single-frame human-vs-human launches below the sparse write-back threshold -- the bench
-// headline.  Wave ROLE loads/stores its own player's 13 columns, its half of the ball columns (both
-// waves load all 12), player 1's wave also the 6 env columns, the episode statistics and `terminated`;
-// each wave writes its own agent's reward and observation tensor.
-template <int ROLE>
+// Used for single-frame launches below PZ_TWO_WAVE_MAX_LANES games: human-vs-human (the bench headline)
+// and, when flight tables are passed, every computer-player configuration.  Wave ROLE loads/stores its own
+// player's 13 columns, its half of the ball columns (both waves load all 12), player 1's wave also the 6
+// env columns, the episode statistics and `terminated`; each wave writes its own agent's reward and
+// observation tensor; the wave of the (last) computer player keeps ball.expected_landing_point_x.
+template <int ROLE, bool AI1, bool AI2>
 __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, int32_t (*lds_obs)[kLanes * PZ_OBS_DIM],
                                           int32_t* __restrict__ xchg, int lane)
 {
+    constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
+    constexpr bool kKeepsEx = (AI1 || AI2) && (ROLE == 1 ? AI2 : !AI2);
     const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
     const bool live = i < hot.n;
     const uint32_t n32 = (uint32_t)hot.n;
@@ -728,6 +742,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
 
     Game g{};
     const RngId id = make_rng_id(a.cfg, live ? i : 0);
+    const FlightLut lut = make_lut(a.tables);
     const int a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.voff, 0, 0);
     const int a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.voff, 0, 0);
     EpisodeStats st{0u, 0u, 0};
@@ -748,10 +763,17 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         g.b.ppx = io.ld(PZ_B_PREVIOUS_PREVIOUS_X);
         g.b.ppy = io.ld(PZ_B_PREVIOUS_PREVIOUS_Y);
         g.b.rot = io.ld(PZ_B_FINE_ROTATION);
-        g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);
+        if (kKeepsEx) g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);
         g.b.punch = io.ld(PZ_B_PUNCH_EFFECT_X);
         load_player(ROLE == 0 ? g.p1 : g.p2, io, kOwn);
-        (ROLE == 0 ? g.p2 : g.p1).coll = io.ld(kOther + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED);
+        Player& other = ROLE == 0 ? g.p2 : g.p1;
+        other.coll = io.ld(kOther + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED);
+        if (kOwnAI && ROLE == 0) other.x = io.ld(kOther + PZ_P_X);  // the decision reads the other player's x
+        if (kOwnAI && ROLE == 1 && !AI1) {  // ... player 2's after player 1's move: recomputed from these
+            other.x = io.ld(kOther + PZ_P_X);
+            other.state = io.ld(kOther + PZ_P_STATE);
+            other.dive = io.ld(kOther + PZ_P_DIVING_DIRECTION);
+        }
         if (with_stats) {
             st.r1 = (uint32_t)sio.ld(0);
             st.r2 = (uint32_t)sio.ld(1);
@@ -761,13 +783,15 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     const Game loaded = g;  // what the columns held before the frame
     const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     bool frozen = false;
-    const int reward = step_games_pair<ROLE>(g, a.cfg, id, a1, a2, live, frozen, xchg, kLanes * PZ_OBS_DIM, lane);
+    const int reward = step_games_pair<ROLE, AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, xchg, kLanes * PZ_OBS_DIM,
+                                                        lane, lut);
     const Rewards rw = shape_rewards(a.cfg, g, reward, frozen);
     if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
 
     if (live) {
         // changed-only write-back of the rarely changing columns, as in store_game_changed
         store_player_changed(ROLE == 0 ? g.p1 : g.p2, ROLE == 0 ? loaded.p1 : loaded.p2, io, kOwn);
+        if (kKeepsEx && g.b.ex != loaded.b.ex) io.st(PZ_B_EXPECTED_LANDING_POINT_X, g.b.ex);
         if (ROLE == 0) {
             io.st(PZ_B_X, g.b.x);
             io.st(PZ_B_Y, g.b.y);
@@ -794,7 +818,6 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
             io.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
             io.st(PZ_B_PREVIOUS_PREVIOUS_Y, g.b.ppy);
             io.st(PZ_B_FINE_ROTATION, g.b.rot);
-            // expected_landing_point_x never changes without a computer player
         }
         const Rsrc rew = make_rsrc(ROLE == 0 ? a.rew_p1 : a.rew_p2, n32 * 4u);
         const unsigned int bits = as_float ? __float_as_uint(ROLE == 0 ? rw.f1 : rw.f2)
@@ -811,6 +834,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     flush_rows(lds_obs[ROLE], ROLE == 0 ? a.obs_p1 : a.obs_p2, n32 * kRowBytes, lane);
 }
 
+template <bool AI1, bool AI2>
 __global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(PZ_HOT_PARAMS, const StepArgs a)
 {
     const HotArgs hot{state, n, stride, act_p1, act_p2};
@@ -822,9 +846,9 @@ __global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(PZ_HOT_PARAMS, co
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (kLanes - 1);
     if (role == 0)
-        pair_body<0>(a, hot, lds_obs, xchg, lane);
+        pair_body<0, AI1, AI2>(a, hot, lds_obs, xchg, lane);
     else
-        pair_body<1>(a, hot, lds_obs, xchg, lane);
+        pair_body<1, AI1, AI2>(a, hot, lds_obs, xchg, lane);
 }
 
 // ---- constructor / reset / observe / policy kernels --------------------------------------------
@@ -900,6 +924,41 @@ __global__ __launch_bounds__(256) void random_actions_kernel(int32_t* act_p1, in
     act_p2[i] = a2;
 }
 
+// ---- flight tables (pz_build_flight_tables) -----------------------------------------------------
+// One thread per entry, filled with the frame-by-frame iteration of the reference.
+__global__ __launch_bounds__(256) void build_landing_table_kernel(uint16_t* table)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= kFtLandingEntries) return;
+    const int x = (int)(e % kFtXCount) + kBallRadius;
+    int64_t r = e / kFtXCount;
+    const int y = (int)(r % kFtYCount);
+    r /= kFtYCount;
+    const int xv = ft_xv_value((int)(r % kFtXvCount));
+    const int yv = (int)(r / kFtXvCount) - PZ_FT_YV_MAX;
+    table[e] = (uint16_t)predict_landing_x_iterative<true>(x, y, xv, yv);
+}
+
+__global__ __launch_bounds__(256) void build_power_hit_table_kernel(uint16_t* table)
+{
+    // one thread per (entry, candidate): 8 slots per entry, slots 6 and 7 are padding
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= kFtHitEntries * 8) return;
+    const int c = (int)(t & 7);
+    const int64_t e = t >> 3;
+    const int x = (int)(e % kFtXCount) + kBallRadius;
+    const int64_t r = e / kFtXCount;
+    const int y = (int)(r % kFtHitYCount) + kFtHitYMin;
+    const int ayv = (int)(r / kFtHitYCount);
+    uint16_t v = 0;
+    if (c < 6) {
+        const int xdir = candidate_xdir(c), ydir = candidate_ydir(c);
+        const int sxv = (x < kGroundHalfWidth) ? (xdir + 1) * 10 : -(xdir + 1) * 10;  // physics.py:841-844
+        v = (uint16_t)predict_landing_x_iterative<false>(x, y, sxv, ayv * ydir * 2);  // :845
+    }
+    table[t] = v;
+}
+
 // Self-test hook: both forms of the flight predictor on caller-supplied ball states.
 __global__ __launch_bounds__(256) void predictor_selftest_kernel(const int32_t* x, const int32_t* y, const int32_t* xv,
                                                                  const int32_t* yv, int64_t n, int full_net,
@@ -963,20 +1022,32 @@ static int launch_step_ai(const StepArgs& a, hipStream_t stream)
     return (int)hipGetLastError();
 }
 
+template <bool AI1, bool AI2>
+static int launch_pair(const StepArgs& a, hipStream_t stream)
+{
+    hipLaunchKernelGGL((step_pair_kernel<AI1, AI2>), dim3(blocks_for(a.n, kLanes)), dim3(2 * kLanes), 0, stream,
+                       PZ_HOT_ARGS(a), a);
+    return (int)hipGetLastError();
+}
+
 template <int MODE>
 static int launch_step(const StepArgs& a, hipStream_t stream)
 {
+    const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
+    // with both tables every flight is one gather: no scout wave is needed, and the single frame splits by player
+    const bool tables = a.tables.landing != nullptr && a.tables.power_hit != nullptr;
 #ifndef PZ_NO_PAIR_KERNEL
-    if (MODE == kActions && a.n < PZ_TWO_WAVE_MAX_LANES && a.cfg.p1_computer == 0 && a.cfg.p2_computer == 0) {
-        hipLaunchKernelGGL(step_pair_kernel, dim3(blocks_for(a.n, kLanes)), dim3(2 * kLanes), 0, stream, PZ_HOT_ARGS(a), a);
-        return (int)hipGetLastError();
+    if (MODE == kActions && a.n < PZ_TWO_WAVE_MAX_LANES && (tables || !(ai1 || ai2))) {
+        if (ai1 && ai2) return launch_pair<true, true>(a, stream);
+        if (ai1) return launch_pair<true, false>(a, stream);
+        if (ai2) return launch_pair<false, true>(a, stream);
+        return launch_pair<false, false>(a, stream);
     }
 #endif
 #if !defined(PZ_NO_SCOUT_WAVE) && !defined(PZ_ABLATE) && !defined(PZ_STAMPS)
-    if (a.n < PZ_TWO_WAVE_MAX_LANES) {  // a computer player is present (else: pair kernel or plain kernel below)
+    if (a.n < PZ_TWO_WAVE_MAX_LANES && !tables) {  // a computer player is present (else: pair kernel above)
         constexpr int kScout = MODE == kActions ? kScoutLoads : kScoutPosted;
         const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
-        const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
         constexpr bool kSparse = MODE == kActions || MODE == kRandom;
         if (ai1 && ai2)
             hipLaunchKernelGGL((step_kernel<true, true, MODE, kSparse, kScout>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
@@ -990,6 +1061,11 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
     return launch_step_ai<MODE, MODE == kActions || MODE == kRandom>(a, stream);
 }
 
+static pz_flight_tables tables_of(const pz_flight_tables* t)
+{
+    return t != nullptr ? *t : pz_flight_tables{nullptr, nullptr};
+}
+
 }  // namespace pz
 
 using namespace pz;
@@ -1000,6 +1076,31 @@ int pz_abi_version(void) { return PZ_ABI_VERSION; }
 int pz_state_words(void) { return PZ_STATE_WORDS; }
 int pz_obs_dim(void) { return PZ_OBS_DIM; }
 int pz_config_bytes(void) { return (int)sizeof(pz_config); }
+
+#ifndef PZ_BUILD_ID
+#define PZ_BUILD_ID "unstamped"
+#endif
+// stored behind a marker so that build.py can read the id from the file without mapping the library
+static const char kBuildIdRecord[] = "pz_build_id:" PZ_BUILD_ID;
+const char* pz_build_id(void) { return kBuildIdRecord + 12; }
+
+int64_t pz_flight_table_bytes(int32_t which)
+{
+    return which == 0 ? kFtLandingEntries * 2 : (which == 1 ? kFtHitEntries * 16 : 0);
+}
+
+int pz_build_flight_tables(uint16_t* landing, uint16_t* power_hit, void* stream)
+{
+    if (landing == nullptr && power_hit == nullptr) return PZ_E_NULL;
+    if (misaligned16(power_hit)) return PZ_E_ALIGN;
+    if (landing != nullptr)
+        hipLaunchKernelGGL(build_landing_table_kernel, dim3(blocks_for(kFtLandingEntries, 256)), dim3(256), 0,
+                           (hipStream_t)stream, landing);
+    if (power_hit != nullptr)
+        hipLaunchKernelGGL(build_power_hit_table_kernel, dim3(blocks_for(kFtHitEntries * 8, 256)), dim3(256), 0,
+                           (hipStream_t)stream, power_hit);
+    return (int)hipGetLastError();
+}
 
 const char* pz_error_string(int code)
 {
@@ -1047,20 +1148,21 @@ int pz_observe(const int32_t* state, int64_t n, int64_t stride, int32_t normaliz
 
 int pz_step(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, const int32_t* act_p1,
             const int32_t* act_p2, int32_t* obs_p1, int32_t* obs_p2, void* rew_p1, void* rew_p2, uint8_t* terminated,
-            int32_t* episode_stats, void* stream)
+            int32_t* episode_stats, const pz_flight_tables* tables, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (!act_p1 || !act_p2 || !obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
     if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
+    if (tables != nullptr && misaligned16(tables->power_hit)) return PZ_E_ALIGN;
     StepArgs a{state,  n,          stride,        act_p1,  act_p2, 0, 0, 1, nullptr, obs_p1, obs_p2, rew_p1,
-               rew_p2, terminated, episode_stats, nullptr, *cfg};
+               rew_p2, terminated, episode_stats, nullptr, tables_of(tables), *cfg};
     return launch_step<kActions>(a, (hipStream_t)stream);
 }
 
 int pz_step_random(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, uint64_t action_seed, uint64_t t0,
                    int32_t k, int32_t* obs_p1, int32_t* obs_p2, void* rew_p1, void* rew_p2, uint8_t* terminated,
-                   int32_t* episode_stats, int64_t* episodes_done, void* stream)
+                   int32_t* episode_stats, int64_t* episodes_done, const pz_flight_tables* tables, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (!obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
@@ -1068,14 +1170,15 @@ int pz_step_random(int32_t* state, int64_t n, int64_t stride, const pz_config* c
     if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
     StepArgs a{state,  n,          stride,        nullptr, nullptr, action_seed, t0, k, nullptr, obs_p1, obs_p2, rew_p1,
-               rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), *cfg};
+               rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), tables_of(tables),
+               *cfg};
     return launch_step<kRandom>(a, (hipStream_t)stream);
 }
 
 int pz_rollout_random(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, uint64_t action_seed,
                       uint64_t t0, int32_t k, int32_t* actions, int32_t* obs_p1, int32_t* obs_p2, void* rew_p1,
                       void* rew_p2, uint8_t* terminated, int32_t* episode_stats, int64_t* episodes_done,
-                      void* stream)
+                      const pz_flight_tables* tables, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (!obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
@@ -1084,13 +1187,14 @@ int pz_rollout_random(int32_t* state, int64_t n, int64_t stride, const pz_config
     if (misaligned16(obs_p1) || misaligned16(obs_p2) || (k > 1 && (n & 3) != 0)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
     StepArgs a{state,  n,          stride,        nullptr, nullptr, action_seed, t0, k, actions, obs_p1, obs_p2, rew_p1,
-               rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), *cfg};
+               rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), tables_of(tables),
+               *cfg};
     return launch_step<kRollout>(a, (hipStream_t)stream);
 }
 
 int pz_step_many(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, const int32_t* actions, int32_t k,
                  int32_t* obs_p1, int32_t* obs_p2, void* rew_p1, void* rew_p2, uint8_t* terminated,
-                 int32_t* episode_stats, int64_t* episodes_done, void* stream)
+                 int32_t* episode_stats, int64_t* episodes_done, const pz_flight_tables* tables, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (!actions || !obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
@@ -1098,7 +1202,8 @@ int pz_step_many(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg
     if (misaligned16(obs_p1) || misaligned16(obs_p2) || (k > 1 && (n & 3) != 0)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
     StepArgs a{state,  n,          stride,        actions, nullptr, 0, 0, k, nullptr, obs_p1, obs_p2, rew_p1,
-               rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), *cfg};
+               rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), tables_of(tables),
+               *cfg};
     return launch_step<kTape>(a, (hipStream_t)stream);
 }
 

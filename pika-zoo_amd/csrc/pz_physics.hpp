@@ -448,6 +448,78 @@ __device__ __forceinline__ int predict_landing_x(int x, int y, int xv, int yv)
 }
 
 // ---------------------------------------------------------------------------------------
+// Flight look-up tables (pz_flight_tables in the header): both predictors are pure functions of a few
+// small integers, tabulated once per device by pz_build_flight_tables with the iterative forms above.
+// A launch lasts as long as its slowest lane, and with the predictors iterated in the kernel that lane
+// is the one 20-event flight among the launch's ~80 000; a table turns every flight into one gather.
+// States outside a table's domain (or a NULL table) take the computed path, so results are identical
+// with and without tables by construction.
+// ---------------------------------------------------------------------------------------
+using TableRsrc = __amdgpu_buffer_rsrc_t;
+typedef unsigned int lut_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kFtXCount = kGroundWidth - kBallRadius + 1;  // x 20..432
+constexpr int kFtYCount = kBallGroundY + 1;                // y 0..252
+constexpr int kFtXvCount = 23;                             // -20, -10..10, 20
+constexpr int kFtYvCount = 2 * PZ_FT_YV_MAX + 1;
+constexpr int kFtHitYMin = 61;                             // the scan needs |ball.y - player.y| < 48, player.y >= 108
+constexpr int kFtHitYCount = kBallGroundY - kFtHitYMin + 1;
+constexpr int64_t kFtLandingEntries = (int64_t)kFtYvCount * kFtXvCount * kFtYCount * kFtXCount;
+constexpr int64_t kFtHitEntries = (int64_t)(PZ_FT_HIT_YV_MAX + 1) * kFtHitYCount * kFtXCount;  // of 8 x uint16
+
+// x velocity -> table row, or -1
+__device__ __forceinline__ int ft_xv_index(int xv)
+{
+    const int a = abs(xv);
+    return a <= 10 ? xv + 11 : (a == 20 ? (xv > 0 ? 22 : 0) : -1);
+}
+__device__ __forceinline__ int ft_xv_value(int index) { return index == 0 ? -20 : (index == 22 ? 20 : index - 11); }
+
+struct FlightLut {
+    TableRsrc landing, power_hit;
+    bool has_landing, has_power_hit;  // wave-uniform (kernel arguments)
+
+    // calculate_expected_landing_point_x_for (physics.py:643-686)
+    __device__ __forceinline__ int landing_x(int x, int y, int xv, int yv) const
+    {
+        const int xi = ft_xv_index(xv);
+        const bool in = has_landing & (xi >= 0) & ((unsigned)(x - kBallRadius) < (unsigned)kFtXCount) &
+                        ((unsigned)y < (unsigned)kFtYCount) & (abs(yv) <= PZ_FT_YV_MAX);
+        if (in) {
+            const uint32_t e = (uint32_t)((((yv + PZ_FT_YV_MAX) * kFtXvCount + xi) * kFtYCount + y) * kFtXCount + (x - kBallRadius));
+            return (int)__builtin_amdgcn_raw_buffer_load_b16(landing, e * 2u, 0, 0);
+        }
+        return predict_landing_x<true>(x, y, xv, yv);
+    }
+
+    // the six candidates of decide_whether_input_power_hit (physics.py:796-816) for the ball (x, y, |yv|)
+    __device__ __forceinline__ void power_hit_candidates(int x, int y, int ayv, int (&ex)[6]) const
+    {
+        const bool in = has_power_hit & ((unsigned)(x - kBallRadius) < (unsigned)kFtXCount) &
+                        ((unsigned)(y - kFtHitYMin) < (unsigned)kFtHitYCount) & ((unsigned)ayv <= (unsigned)PZ_FT_HIT_YV_MAX);
+        if (in) {
+            const uint32_t e = (uint32_t)((ayv * kFtHitYCount + (y - kFtHitYMin)) * kFtXCount + (x - kBallRadius));
+            const lut_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(power_hit, e * 16u, 0, 0);
+            ex[0] = (int)(w.x & 0xFFFFu);
+            ex[1] = (int)(w.x >> 16);
+            ex[2] = (int)(w.y & 0xFFFFu);
+            ex[3] = (int)(w.y >> 16);
+            ex[4] = (int)(w.z & 0xFFFFu);
+            ex[5] = (int)(w.z >> 16);
+        } else {
+#pragma unroll 1
+            for (int c = 0; c < 6; ++c) {
+                const int xdir = c < 3 ? 1 : 0, ydir = (c < 3 ? c : c - 3) - 1;
+                const int sxv = (x < kGroundHalfWidth) ? (xdir + 1) * 10 : -(xdir + 1) * 10;  // :841-844
+                const int e = predict_landing_x<false>(x, y, sxv, ayv * ydir * 2);          // :845
+#pragma unroll
+                for (int k = 0; k < 6; ++k) ex[k] = (k == c) ? e : ex[k];  // (no dynamic register indexing)
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------
 // Rule-based computer player: let_computer_decide_user_input (physics.py:689-771) with
 // decide_whether_input_power_hit (:774-817).  IS_P2 selects the court side.
 //
@@ -744,8 +816,8 @@ struct ScoutLink {
 template <bool AI1, bool AI2, int SCOUT = kNoScout>
 __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
                                           bool& frozen, int32_t* __restrict__ scratch, int lane,
-                                          const ScoutLink link = ScoutLink{nullptr, nullptr, nullptr}, bool* ex_pending = nullptr,
-                                          const bool last_frame = true)
+                                          const FlightLut& lut, const ScoutLink link = ScoutLink{nullptr, nullptr, nullptr},
+                                          bool* ex_pending = nullptr, const bool last_frame = true)
 {
     // The reference empties `agents` on termination (:237-238) and expects reset() before the
     // next step; auto_reset applies reset() (:149-164) in place.  Both that and the new-round
@@ -797,7 +869,7 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
     if ((AI1 || AI2) && active) {
         // :314-315 recomputes the landing point before each player; the ball does not move
         // between the two calls, so one evaluation serves both.
-        g.b.ex = PZ_ABLATE_SKIP(32) ? g.b.x : predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
+        g.b.ex = PZ_ABLATE_SKIP(32) ? g.b.x : lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
     }
 
     if (AI1) {
@@ -810,6 +882,8 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
 #pragma unroll
                 for (int c = 0; c < 6; ++c) ex[c] = link.cand[lane * kCandPitch + c];
             }
+        } else if (lut.has_power_hit) {  // wave-uniform
+            if (hs.need) lut.power_hit_candidates(g.b.x, g.b.y, abs(g.b.yv), ex);
         } else {
             wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
         }
@@ -827,6 +901,8 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
 #pragma unroll
                 for (int c = 0; c < 6; ++c) ex[c] = link.cand[lane * kCandPitch + c];
             }
+        } else if (lut.has_power_hit) {
+            if (hs.need) lut.power_hit_candidates(g.b.x, g.b.y, abs(g.b.yv), ex);
         } else {
             wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
         }
@@ -868,7 +944,7 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
             if (SCOUT == kScoutLoads)
                 hit_for_scout = true;
             else
-                g.b.ex = PZ_ABLATE_SKIP(128) ? g.b.x : predict_landing_x<true>(g.b.x, g.b.y, g.b.xv, g.b.yv);
+                g.b.ex = PZ_ABLATE_SKIP(128) ? g.b.x : lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
         }
     }
     if (SCOUT == kScoutLoads) {
@@ -888,25 +964,47 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
 }
 
 // ---------------------------------------------------------------------------------------
-// The same frame for a PAIR of waves per 64 games (human-vs-human, single frame).
+// The same frame for a PAIR of waves per 64 games (single frame, every player configuration).
 // A lone wave per SIMD only fills every second issue slot, and its ~1 250 instructions run one
-// after the other.  Here the work of a workgroup's 64 games is split between two waves that
-// sit on different SIMDs: wave ROLE owns player ROLE+1 -- its new-round draw, its movement, its
-// state columns, its agent's reward and observation tensor -- and both redo the cheap shared
+// after the other.  Here the work of a workgroup's 64 games is split between two waves:
+// wave ROLE owns player ROLE+1 -- its new-round draw, its computer player's decision, its movement,
+// its state columns, its agent's reward and observation tensor -- and both redo the cheap shared
 // parts (round bookkeeping, action decode, ball-world step, ball-player collisions, scoring),
 // which are deterministic, so the two copies stay identical.  One LDS exchange per frame hands
-// the moved player to the partner.  `g` holds: the own player complete, of the partner only
-// `coll` (and whatever the exchange fills in), ball and env complete.
-// xchg: two regions of LDS, `xchg_region` words apart, 64 * 9 words used in each; a wave writes its
-// player into the PARTNER's region and reads the partner's from its own, so a wave may reuse its own
-// region afterwards without asking (the pair kernel aliases them with the observation staging rows).
-// Contains exactly one __syncthreads().
+// the moved player to the partner.  `g` holds: the own player complete, of the partner `coll` plus
+// what the caller loaded for the own computer player's decision (see pair_body) and whatever the
+// exchange fills in, ball and env complete.
+//
+// Computer players (AI1 / AI2).  The reference decides and moves player 1, then player 2
+// (physics.py:304-316); a decision reads the other player's x only (:801,:768 via
+// decide_whether_input_power_hit), player 1's sees player 2 before its move, player 2's sees player 1
+// after.  So
+//   * player 1's wave needs player 2's old x (loaded by the caller);
+//   * player 2's wave needs player 1's NEW x: with a human player 1 it recomputes that from the decoded
+//     action (x, state and diving direction loaded by the caller: the first lines of player_move); with a
+//     computer player 1 it waits for wave 0's early post {new x, draws made} behind one extra barrier;
+//   * the env stream's draws stay in the reference's order (p1 decision, p2 decision, p1 collision, p2
+//     collision): each wave counts its own decision's draws and posts the count with its player, both
+//     then continue from base + d1 + d2;
+//   * the decided (x_direction, y_direction) travel with the player too: the ball-player collision takes
+//     the power hit's direction from them (physics.py:329 passes the mutated user_input).
+// The flight predictions come from `lut` (tables or, outside their domain, the computed form); the wave
+// that owns the (last) computer player keeps ball.expected_landing_point_x (`keeps_ex`).
+// xchg: two regions of LDS, `xchg_region` words apart; a wave writes into the PARTNER's region and reads
+// from its own, so a wave may reuse its own region afterwards without asking (the pair kernel aliases them
+// with the observation staging rows).  One __syncthreads(), two when both players are computers.
 // ---------------------------------------------------------------------------------------
-template <int ROLE>
+constexpr int kXchgWords = 11;    // 9 player words + decision word + pad: odd pitch, conflict-free LDS rows
+constexpr int kEarlyPostAt = 1024;  // word offset of the early post {x, draws} inside a region (2 x 64 words)
+
+template <int ROLE, bool AI1, bool AI2>
 __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2,
                                                bool live, bool& frozen, int32_t* __restrict__ xchg, int xchg_region,
-                                               int lane)
+                                               int lane, const FlightLut& lut)
 {
+    constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
+    constexpr bool kOtherAI = ROLE == 0 ? AI2 : AI1;
+    constexpr bool kKeepsEx = (AI1 || AI2) && (ROLE == 1 ? AI2 : !AI2);
     Player& own = ROLE == 0 ? g.p1 : g.p2;
     Player& other = ROLE == 0 ? g.p2 : g.p1;
     frozen = live && g.e.game_ended && !cfg.auto_reset;
@@ -946,11 +1044,49 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
         }
 
         ground = ball_world_step(g.b);
-        player_move<ROLE == 1>(own, ROLE == 0 ? in1 : in2);
+    }
+    const uint32_t rng_base = g.e.rng;  // the env stream before this frame's decisions
+    uint32_t draws_own = 0, draws_other = 0;
+    Input& in_own = ROLE == 0 ? in1 : in2;
+    Input& in_other = ROLE == 0 ? in2 : in1;
+
+    if (ROLE == 1 && AI1 && AI2) {
+        __syncthreads();  // player 1's early post is in place
+        if (active) {
+            const int32_t* early = xchg + ROLE * xchg_region + kEarlyPostAt + lane * 2;
+            other.x = early[0];
+            draws_other = (uint32_t)early[1];
+        }
+    }
+    if (kOwnAI) {
+        if (active) {
+            // :314-315 recomputes the landing point before each player; the ball does not move in between
+            g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
+            if (ROLE == 1 && !AI1) {
+                // player 1 (human) has moved when player 2 decides: its new x as player_move computes it
+                const int vx = (other.state < 3) ? in1.xd * 6 : other.dive * 8;
+                const int nx = min(max(other.x + vx, kPlayerHalfLength), kGroundHalfWidth - kPlayerHalfLength);
+                other.x = (other.state == 4) ? other.x : nx;
+            }
+            uint32_t rng = rng_base + draws_other;
+            const HitScan hs = computer_decide_begin<ROLE == 1>(own, g.b, in_own, id, rng);
+            draws_own = rng - (rng_base + draws_other);
+            int ex[6] = {0, 0, 0, 0, 0, 0};
+            if (hs.need) lut.power_hit_candidates(g.b.x, g.b.y, abs(g.b.yv), ex);
+            computer_decide_finish<ROLE == 1>(hs, ex, own, other, in_own);
+        }
+    }
+    if (active) player_move<ROLE == 1>(own, in_own);
+    if (ROLE == 0 && AI1 && AI2) {
+        if (active) {
+            int32_t* early = xchg + (1 - ROLE) * xchg_region + kEarlyPostAt + lane * 2;
+            early[0] = own.x;
+            early[1] = (int32_t)draws_own;
+        }
+        __syncthreads();
     }
     // hand the own player to the partner wave: everything the collisions and the observations read
     // (frozen games exchange their unchanged players, so their observations stay complete)
-    constexpr int kXchgWords = 9;  // odd pitch: conflict-free LDS rows
     if (live) {
         int32_t* mine = xchg + (1 - ROLE) * xchg_region + lane * kXchgWords;  // into the partner's region
         mine[0] = own.x;
@@ -962,6 +1098,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
         mine[6] = own.dive;
         mine[7] = own.lying;
         mine[8] = own.hitprev;
+        if (kOwnAI) mine[9] = (in_own.xd + 1) | ((in_own.yd + 1) << 2) | (int32_t)(draws_own << 4);
     }
     __syncthreads();
     if (live) {
@@ -975,9 +1112,18 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
         other.dive = theirs[6];
         other.lying = theirs[7];
         other.hitprev = theirs[8];
+        if (kOtherAI) {
+            const int32_t w = theirs[9];
+            if (active) {
+                in_other.xd = (w & 3) - 1;
+                in_other.yd = ((w >> 2) & 3) - 1;
+                draws_other = (uint32_t)w >> 4;
+            }
+        }
     }
     int reward = 0;
     if (active) {
+        g.e.rng = rng_base + draws_own + draws_other;
 
         // physics.py:319-335: player 1 first, then player 2 against the possibly changed velocities
         const bool touch1 = ball_touches_player(g.b, g.p1), hit1 = touch1 & (g.p1.coll == 0);
@@ -995,6 +1141,10 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
         g.e.game_ended = ground & ((p2_scores ? g.e.s2 : g.e.s1) >= cfg.winning_score);
         g.e.round_ended = ground;
         reward = ground ? (p2_scores ? -1 : 1) : 0;
+
+        // :331-332 -- predicted again after a processed collision (one evaluation after both collisions
+        // leaves what the second of two would)
+        if (kKeepsEx && (hit1 | hit2)) g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
     }
     return reward;
 }

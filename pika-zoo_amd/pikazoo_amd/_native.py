@@ -11,7 +11,7 @@ from pathlib import Path
 PKG_ROOT = Path(__file__).resolve().parent.parent  # .../pika-zoo_amd
 LIB_PATH = PKG_ROOT / "lib" / "libpikazoo_hip.so"
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 STATE_WORDS = 44
 OBS_DIM = 35
 SERVE_MODES = {"winner": 0, "alternate": 1, "random": 2}
@@ -42,6 +42,12 @@ class PzConfig(C.Structure):
     ]
 
 
+class PzFlightTables(C.Structure):
+    """`pz_flight_tables` (include/pikazoo_hip.h): device pointers of the computer player's flight tables."""
+
+    _fields_ = [("landing", C.c_void_p), ("power_hit", C.c_void_p)]
+
+
 class PikazooNativeError(RuntimeError):
     pass
 
@@ -54,16 +60,20 @@ _SIGNATURES = {
     "pz_obs_dim": (C.c_int, []),
     "pz_config_bytes": (C.c_int, []),
     "pz_error_string": (C.c_char_p, [C.c_int]),
+    "pz_build_id": (C.c_char_p, []),
+    "pz_flight_table_bytes": (C.c_int64, [C.c_int32]),
+    "pz_build_flight_tables": (C.c_int, [_P, _P, _P]),
     "pz_init": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P]),
     "pz_reset": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, _P, _P, _P, _P]),
     "pz_observe": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, _P, _P, _P]),
-    "pz_step": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    # (the argument before the stream is `const pz_flight_tables*`: a byref(PzFlightTables) or None)
+    "pz_step": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pz_step_random": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), C.c_uint64, C.c_uint64,
-                                 C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                 C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pz_rollout_random": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), C.c_uint64, C.c_uint64,
-                                    C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                    C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pz_step_many": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, C.c_int32, _P, _P, _P, _P, _P, _P,
-                               _P, _P]),
+                               _P, _P, _P]),
     "pz_random_actions": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _P]),
     "pz_selftest_predictor": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
 }
@@ -71,8 +81,20 @@ _SIGNATURES = {
 _lib = None
 
 
+def _pz_build():
+    """pika-zoo_amd/build.py as a module (it lives beside the package, not inside it)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("pz_build", PKG_ROOT / "build.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def load():
-    """Load the shared library (once).  Raises if it has not been built."""
+    """Load the shared library (once).  Raises if it has not been built, or if it was built from other
+    sources than the ones in this tree (the library is git-ignored but travels with the working tree,
+    so a stale one would otherwise be run silently)."""
     global _lib
     if _lib is not None:
         return _lib
@@ -80,6 +102,13 @@ def load():
         raise PikazooNativeError(
             f"{LIB_PATH} is missing: build it with `python pika-zoo_amd/build.py` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    if (PKG_ROOT / "csrc" / "pz_kernels.hip").exists():  # a source tree: the library must match it
+        b = _pz_build()
+        have, want = b.library_id(LIB_PATH), b.source_id()
+        if have != want:
+            raise PikazooNativeError(
+                f"{LIB_PATH} is stale: built from sources {have}, the tree holds {want}; rebuild it with "
+                "`python pika-zoo_amd/build.py`")
     lib = C.CDLL(str(LIB_PATH))
     for name, (restype, argtypes) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing
@@ -92,6 +121,11 @@ def load():
         raise PikazooNativeError("pz_config / state layout of the library does not match this binding")
     _lib = lib
     return lib
+
+
+def build_id() -> str:
+    """Source digest the loaded library was compiled from (``pz_build_id``)."""
+    return load().pz_build_id().decode()
 
 
 def exported_names():

@@ -77,6 +77,20 @@ def all_reduce_max(value: float, device=None) -> float:
     return float(t.item())
 
 
+def get_rank() -> int:
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def world_size() -> int:
+    """Ranks in the process group as the backend sees them (1 without a group)."""
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def backend_name() -> str:
+    """"nccl" (= RCCL on ROCm), "gloo", or "none" for a single process without a group."""
+    return str(dist.get_backend()) if dist.is_initialized() else "none"
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

@@ -53,6 +53,29 @@ def _raw_stream(device_index: int) -> int:
     return torch.cuda.current_stream(device_index).cuda_stream
 
 
+# The computer player's flight look-up tables (pz_flight_tables in include/pikazoo_hip.h): caller-owned
+# device memory as far as the C ABI is concerned; the Python host keeps ONE pair per device, built by the
+# first env with a computer player (about 1 GB of the 288 GB, a few milliseconds of kernel time).
+_FLIGHT_TABLES = {}
+
+
+def flight_tables(device: torch.device):
+    """``(PzFlightTables, landing, power_hit)`` of `device`, built on first use."""
+    key = device.index
+    hit = _FLIGHT_TABLES.get(key)
+    if hit is None:
+        lib = _native.load()
+        with torch.cuda.device(device):
+            landing = torch.empty(lib.pz_flight_table_bytes(0), dtype=torch.uint8, device=device)
+            power_hit = torch.empty(lib.pz_flight_table_bytes(1), dtype=torch.uint8, device=device)
+            _native.check(lib.pz_build_flight_tables(landing.data_ptr(), power_hit.data_ptr(), _raw_stream(key)),
+                          "pz_build_flight_tables")
+            torch.cuda.current_stream(device).synchronize()  # envs on other streams may use them right away
+        hit = _FLIGHT_TABLES[key] = (_native.PzFlightTables(landing.data_ptr(), power_hit.data_ptr()), landing,
+                                     power_hit)
+    return hit
+
+
 class raw_env:
     """``pikazoo_v0.raw_env`` for ``num_envs`` games at once.
 
@@ -67,7 +90,10 @@ class raw_env:
     next frame, exactly what ``if not env.agents: env.reset()`` does around the reference);
     ``validate_actions`` (range-check actions like the reference's table lookup does; costs a
     device sync per step); ``scalar_api`` (``num_envs == 1`` only: return numpy rows / Python
-    scalars and empty ``agents`` on termination, i.e. the reference's exact return types).
+    scalars and empty ``agents`` on termination, i.e. the reference's exact return types;
+    ``auto_reset`` then defaults to False, so that ``while env.agents:`` loops end like they do around
+    the reference); ``flight_tables`` (computer players only: look the flight predictions up in the
+    per-device HBM tables instead of iterating them in the kernel; results are identical).
 
     Returned tensors are views of env-owned buffers that the next ``step`` overwrites;
     ``clone()`` what must outlive it.
@@ -77,8 +103,8 @@ class raw_env:
 
     def __init__(self, winning_score: int = 15, serve: str = "winner", is_player1_computer: bool = False,
                  is_player2_computer: bool = False, render_mode=None, *, num_envs: int = 1,
-                 device="cuda", seed: int = 0, env_id_base: int = 0, auto_reset: bool = True,
-                 validate_actions: bool = True, scalar_api: bool = False):
+                 device="cuda", seed: int = 0, env_id_base: int = 0, auto_reset: Optional[bool] = None,
+                 validate_actions: bool = True, scalar_api: bool = False, flight_tables: bool = True):
         assert serve in ("winner", "alternate", "random")  # pikazoo_env.py:104
         if render_mode is not None:
             raise NotImplementedError("rendering is outside the step path; use render_mode=None")
@@ -97,6 +123,8 @@ class raw_env:
         self._dev_index = self.device.index
         if scalar_api and num_envs != 1:
             raise ValueError("scalar_api needs num_envs == 1")
+        if auto_reset is None:
+            auto_reset = not scalar_api
 
         self.possible_agents = AGENTS[:]
         self.agents = self.possible_agents[:]
@@ -123,6 +151,11 @@ class raw_env:
         cfg.env_id_base = self.env_id_base
         self._cfg = cfg
         self._cfg_ref = C.byref(cfg)
+        self._tables = None
+        self._tables_ref = None  # `const pz_flight_tables*` of every step call (None: compute in the kernel)
+        if flight_tables and (cfg.p1_computer or cfg.p2_computer):
+            self._tables = globals()["flight_tables"](self.device)
+            self._tables_ref = C.byref(self._tables[0])
 
         n, dev = self.num_envs, self.device
         # columns are padded to a multiple of 64 games so that every workgroup's 256-byte segment of a column is
@@ -383,11 +416,12 @@ class raw_env:
         p = self._ptrs
         if torch.cuda.current_device() == self.device.index:
             rc = self._lib.pz_step(p[0], n, self._stride, self._cfg_ref, a1.data_ptr(), a2.data_ptr(), p[1], p[2],
-                                   p[3], p[4], p[5], self._stats_ptr(), _raw_stream(self._dev_index))
+                                   p[3], p[4], p[5], self._stats_ptr(), self._tables_ref,
+                                   _raw_stream(self._dev_index))
         else:
             with torch.cuda.device(self.device):
                 rc = self._lib.pz_step(p[0], n, self._stride, self._cfg_ref, a1.data_ptr(), a2.data_ptr(), p[1], p[2],
-                                       p[3], p[4], p[5], self._stats_ptr(), self._stream())
+                                       p[3], p[4], p[5], self._stats_ptr(), self._tables_ref, self._stream())
         if rc:
             _native.check(rc, "pz_step")
         self.steps_done += 1
@@ -410,7 +444,8 @@ class raw_env:
                                                    int(k), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
                                                    self._rew_raw[0].data_ptr(), self._rew_raw[1].data_ptr(),
                                                    self._term_u8.data_ptr(), self._stats_ptr(),
-                                                   self._episodes.data_ptr(), self._stream()), "pz_step_random")
+                                                   self._episodes.data_ptr(), self._tables_ref, self._stream()),
+                          "pz_step_random")
         self.steps_done += int(k)
         return self._pack_step()
 
@@ -439,7 +474,7 @@ class raw_env:
                 self.state.data_ptr(), n, self._stride, self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0), k,
                 out["actions"].data_ptr(), out["_obs"][0].data_ptr(), out["_obs"][1].data_ptr(),
                 out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(), out["_term"].data_ptr(),
-                self._stats_ptr(), self._episodes.data_ptr(), self._stream()), "pz_rollout_random")
+                self._stats_ptr(), self._episodes.data_ptr(), self._tables_ref, self._stream()), "pz_rollout_random")
         self.steps_done += k
         return self._finish_trajectory(out)
 
@@ -467,8 +502,8 @@ class raw_env:
             _native.check(self._lib.pz_step_many(
                 self.state.data_ptr(), n, self._stride, self._cfg_ref, actions.data_ptr(), k, out["_obs"][0].data_ptr(),
                 out["_obs"][1].data_ptr(), out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(),
-                out["_term"].data_ptr(), self._stats_ptr(), self._episodes.data_ptr(), self._stream()),
-                "pz_step_many")
+                out["_term"].data_ptr(), self._stats_ptr(), self._episodes.data_ptr(), self._tables_ref,
+                self._stream()), "pz_step_many")
         self.steps_done += k
         return self._finish_trajectory(out)
 
@@ -509,16 +544,48 @@ class raw_env:
         odt = self.obs_dtype
         return {self.possible_agents[0]: o1.view(odt), self.possible_agents[1]: o2.view(odt)}
 
-    # ---- checkpoint = the state tensor --------------------------------------------------------------------
+    # ---- checkpoint: the state tensor + the fused-wrapper words + what the trajectory is keyed by -------------
+    _CFG_KEYS = ("winning_score", "serve_mode", "p1_computer", "p2_computer", "simplify_action", "ballpos_reward",
+                 "x_line", "y_line", "auto_reset", "normal_state_mode", "normal_state_reward", "normalize_obs",
+                 "episode_stats_mode", "seed", "env_id_base")
+
+    def _cfg_dict(self):
+        d = {k: getattr(self._cfg, k) for k in self._CFG_KEYS}
+        d["additional_reward"] = [float(v) for v in self._cfg.additional_reward]
+        return d
+
     def state_dict(self):
+        """Everything a bit-exact continuation needs: the state tensor, the RecordEpisodeStatistics words, the
+        counters, and the configuration (Philox key, game ids, fused wrappers) the trajectory depends on."""
         return {"state": self.state.clone(), "steps_done": self.steps_done, "seed": self.seed,
-                "env_id_base": self.env_id_base}
+                "env_id_base": self.env_id_base, "config": self._cfg_dict(),
+                "episode_stats": None if self._stats is None else self._stats.clone(),
+                "episodes_done": self._episodes.clone()}
 
     def load_state_dict(self, sd):
+        """Restore a :meth:`state_dict`.  Raises when it was taken from an env whose Philox key, game ids or
+        (fused-wrapper) configuration differ from this one: the continuation would silently be another
+        trajectory."""
         if sd["state"].shape != self.state.shape:
             raise ValueError("state shape mismatch")
+        cfg = sd.get("config")
+        if cfg is not None:
+            mine = self._cfg_dict()
+            diff = {k: (cfg.get(k), mine[k]) for k in mine if cfg.get(k) != mine[k]}
+            if diff:
+                raise ValueError(f"checkpoint was taken with another configuration (saved, this env): {diff}")
+        elif int(sd.get("seed", self.seed)) != self.seed or int(sd.get("env_id_base", self.env_id_base)) != self.env_id_base:
+            raise ValueError("checkpoint was taken with another seed / env_id_base")
+        stats = sd.get("episode_stats")
+        if (stats is None) != (self._stats is None):
+            raise ValueError("checkpoint and env disagree on RecordEpisodeStatistics")
         self.state.copy_(sd["state"])
+        if stats is not None:
+            self._stats.copy_(stats)
+        if sd.get("episodes_done") is not None:
+            self._episodes.copy_(sd["episodes_done"])
         self.steps_done = int(sd["steps_done"])
+        self.agents = self.possible_agents[:]
 
     def render(self):
         raise NotImplementedError("rendering is outside the step path (render_mode=None only)")

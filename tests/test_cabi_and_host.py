@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 
     lib = C.CDLL(str(built_lib))
     names = header_functions()
-    assert len(names) >= 13
+    assert len(names) >= 16
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pikazoo_hip.h but not exported"
     assert sorted(_native.exported_names()) == names, "binding and header disagree"
@@ -43,9 +43,31 @@ def test_binding_matches_library_layout(built_lib):
     from pikazoo_amd import _native
 
     lib = _native.load()
-    assert lib.pz_abi_version() == 2 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
+    assert lib.pz_abi_version() == 3 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
     assert lib.pz_config_bytes() == C.sizeof(_native.PzConfig) == 104
     assert lib.pz_error_string(0) == b"ok" and b"NULL" in lib.pz_error_string(-1)
+    assert C.sizeof(_native.PzFlightTables) == 16
+
+
+def test_library_carries_the_digest_of_the_sources_it_was_built_from(built_lib, tmp_path):
+    """The .so is git-ignored but travels to the GPU box with the working tree: the binding must refuse one
+    that was built from other sources (build.py bakes a digest of csrc + header + flags into it)."""
+    import build as pz_build
+    from pikazoo_amd import _native
+
+    assert pz_build.library_id(built_lib) == pz_build.source_id() == _native.build_id()
+    assert re.fullmatch(r"[0-9a-f]{16}", _native.build_id())
+    # a library stamped with another digest is reported as stale (checked on a copy: nothing is loaded)
+    stale = tmp_path / "libpikazoo_hip.so"
+    stale.write_bytes(built_lib.read_bytes().replace(b"pz_build_id:" + pz_build.source_id().encode(),
+                                                     b"pz_build_id:" + b"0" * 16))
+    assert pz_build.library_id(stale) == "0" * 16 != pz_build.source_id()
+    saved, _native._lib, _native.LIB_PATH = (_native._lib, _native.LIB_PATH), None, stale
+    try:
+        with pytest.raises(_native.PikazooNativeError, match="stale"):
+            _native.load()
+    finally:
+        _native._lib, _native.LIB_PATH = saved
 
 
 def test_header_layout_matches_oracle_layout(oracle):
@@ -160,10 +182,16 @@ def test_argument_validation_without_a_gpu(built_lib):
     cfg.serve_mode, cfg.winning_score = 0, 0
     assert lib.pz_init(fake, 0, 0, C.byref(cfg), None) == -3
     cfg.winning_score = 1
-    assert lib.pz_step(fake, 0, 0, C.byref(cfg), None, fake, fake, fake, fake, fake, fake, None, None) == -1
-    assert lib.pz_step_random(fake, 0, 0, C.byref(cfg), 1, 0, 0, fake, fake, fake, fake, fake, None, None, None) == -2
+    assert lib.pz_step(fake, 0, 0, C.byref(cfg), None, fake, fake, fake, fake, fake, fake, None, None, None) == -1
+    assert lib.pz_step_random(fake, 0, 0, C.byref(cfg), 1, 0, 0, fake, fake, fake, fake, fake, None, None, None,
+                              None) == -2
     assert lib.pz_observe(fake, 0, 0, 0, C.c_void_p(4100), fake, None) == -4   # PZ_E_ALIGN
-    assert lib.pz_step(fake, 0, 0, C.byref(cfg), fake, fake, fake, fake, fake, fake, fake, None, None) == 0
+    assert lib.pz_step(fake, 0, 0, C.byref(cfg), fake, fake, fake, fake, fake, fake, fake, None, None, None) == 0
+    bad = _native.PzFlightTables(None, 4104)  # power-hit table not 16-byte aligned
+    assert lib.pz_step(fake, 8, 8, C.byref(cfg), fake, fake, fake, fake, fake, fake, fake, None, C.byref(bad),
+                       None) == -4
+    assert lib.pz_build_flight_tables(None, None, None) == -1
+    assert lib.pz_flight_table_bytes(0) == 2 * 193 * 23 * 253 * 413 and lib.pz_flight_table_bytes(1) == 16 * 65 * 192 * 413
 
 
 def test_no_vmem_store_data_hazard_in_device_code(built_lib, tmp_path):

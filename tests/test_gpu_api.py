@@ -286,3 +286,61 @@ def test_graph_replay_equals_eager_launches():
     assert torch.equal(env.state, want_state)
     assert torch.equal(obs["player_1"], want_obs) and torch.equal(rew["player_1"], want_rew)
     assert torch.equal(term["player_1"], want_term)
+
+
+def test_scalar_api_default_loop_terminates_like_the_reference():
+    """`while env.agents:` around a scalar_api env must end at the game's end without any extra kwarg
+    (auto_reset defaults to False there; the reference empties `agents`, pikazoo_env.py:237-238)."""
+    from pikazoo_amd import pikazoo_v0
+
+    env = pikazoo_v0.env(num_envs=1, scalar_api=True, winning_score=1, seed=3)
+    assert env.auto_reset is False
+    env.reset()
+    rng = np.random.default_rng(0)
+    frames = 0
+    while env.agents:
+        obs, rew, term, trunc, infos = env.step({a: int(rng.integers(0, 18)) for a in env.agents})
+        frames += 1
+        assert frames < 5000
+    assert term == {"player_1": True, "player_2": True} and sorted(rew.values()) == [-1, 1]
+    with pytest.raises(RuntimeError):
+        env.step({"player_1": 0, "player_2": 0})
+    env.reset()
+    assert env.agents == ["player_1", "player_2"]
+    # the batched default stays auto-reset
+    assert pikazoo_v0.env(num_envs=4).auto_reset is True
+
+
+def test_checkpoint_round_trip_with_fused_statistics():
+    """state_dict() carries the RecordEpisodeStatistics words, the counters and the configuration: a restore in
+    the middle of episodes continues bit for bit (incl. infos["episode"]), and a checkpoint of another seed /
+    wrapper stack is refused."""
+    from pikazoo_amd import pikazoo_v0
+    from pikazoo_amd.wrappers import RecordEpisodeStatistics, RewardInNormalState
+
+    def make(seed=5, reward=0.25):
+        e = pikazoo_v0.env(num_envs=512, seed=seed, env_id_base=40, winning_score=1, is_player2_computer=True,
+                           validate_actions=False)
+        return RecordEpisodeStatistics(RewardInNormalState(e, reward))
+
+    a = make()
+    a.reset()
+    a.unwrapped.step_random(3, k=130)
+    sd = a.unwrapped.state_dict()
+    assert sd["episode_stats"] is not None and int(sd["episode_stats"][2].max()) > 0
+    a.unwrapped.step_random(3, k=170)
+    b = make()
+    b.reset()
+    b.unwrapped.load_state_dict(sd)
+    assert b.unwrapped.steps_done == 130
+    b.unwrapped.step_random(3, k=170)
+    assert torch.equal(a.unwrapped.state, b.unwrapped.state)
+    assert torch.equal(a.unwrapped._stats, b.unwrapped._stats)
+    assert a.unwrapped.episodes_done == b.unwrapped.episodes_done > 0
+    with pytest.raises(ValueError, match="configuration"):
+        make(seed=6).unwrapped.load_state_dict(sd)
+    with pytest.raises(ValueError, match="configuration"):
+        make(reward=0.5).unwrapped.load_state_dict(sd)
+    plain = pikazoo_v0.env(num_envs=512, seed=5, env_id_base=40, winning_score=1, is_player2_computer=True)
+    with pytest.raises(ValueError):
+        plain.load_state_dict(sd)

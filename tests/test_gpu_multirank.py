@@ -1,0 +1,115 @@
+"""Two ranks through the HIP path (run with ``-m gpu`` on the one-GPU box).
+
+SURVEY 8(e): the batch shards by contiguous lane ranges, global game ids feed the Philox counters, and the
+only collective is a SUM all-reduce of the counters.  Here two fresh child processes (``torch.distributed.run``,
+backend gloo, both on ``cuda:0``, launched before anything in them touches the GPU) each step their shard through
+``pikazoo_amd``; the concatenated shards must equal the single-process batch bit for bit, and the all-reduced
+counters must equal its totals.  The same launcher then runs ``bench.py --gpus 2`` the way the driver does (with
+gloo standing in for RCCL on a one-GPU box) and checks the line it prints.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REPO = Path(__file__).resolve().parent.parent
+
+_WORKER = r'''
+import os, sys
+repo, out_dir, n_global, steps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+sys.path.insert(0, os.path.join(repo, "pika-zoo_amd")); sys.path.insert(0, repo)
+import torch
+from pikazoo_amd import dist, pikazoo_v0
+
+rank, world, _ = dist.init_from_env("gloo")          # before any GPU call in this process
+assert world == 2 and dist.world_size() == 2 and dist.backend_name() == "gloo"
+shard = dist.shard_for_rank(n_global, rank, world)
+results = {}
+for name, kw in (("human", {}), ("cfg3", dict(is_player2_computer=True)), ("both", dict(is_player1_computer=True, is_player2_computer=True))):
+    env = pikazoo_v0.env(num_envs=shard.n_local, device="cuda:0", seed=21, env_id_base=shard.env_id_base,
+                         winning_score=1, validate_actions=False, **kw)
+    env.reset()
+    terms = 0
+    for t in range(steps):                            # one pz_step launch per frame (pair kernel)
+        obs, rew, term, _, _ = env.step(env.random_actions(8, t))
+        terms += int(term["player_1"].sum().item())
+    env.step_random(8, t0=steps, k=64)                # and one k-frame launch
+    torch.cuda.synchronize()
+    total_terms, total_envs, total_eps = dist.all_reduce_sum([terms, shard.n_local, env.episodes_done])
+    results[name] = {"state": env.state.cpu(), "obs1": obs["player_1"].cpu(), "terms": terms,
+                     "total_terms": total_terms, "total_envs": total_envs, "total_eps": total_eps,
+                     "base": shard.env_id_base}
+torch.save(results, os.path.join(out_dir, f"rank{rank}.pt"))
+dist.barrier()
+torch.distributed.destroy_process_group()
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(args, timeout=420):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port())] + args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=str(REPO))
+
+
+def test_two_ranks_through_the_hip_path_equal_the_single_batch(tmp_path):
+    from pikazoo_amd import pikazoo_v0
+
+    n_global, steps = 8192 + 200, 150  # ragged: the second shard starts inside a 64-game workgroup span
+    worker = tmp_path / "worker.py"
+    worker.write_text(_WORKER)
+    r = _launch([str(worker), str(REPO), str(tmp_path), str(n_global), str(steps)])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    shards = [torch.load(tmp_path / f"rank{k}.pt") for k in range(2)]
+    for name, kw in (("human", {}), ("cfg3", dict(is_player2_computer=True)),
+                     ("both", dict(is_player1_computer=True, is_player2_computer=True))):
+        env = pikazoo_v0.env(num_envs=n_global, device="cuda:0", seed=21, env_id_base=0, winning_score=1,
+                             validate_actions=False, **kw)
+        env.reset()
+        terms = 0
+        for t in range(steps):
+            obs, rew, term, _, _ = env.step(env.random_actions(8, t))
+            terms += int(term["player_1"].sum().item())
+        env.step_random(8, t0=steps, k=64)
+        a, b = shards[0][name], shards[1][name]
+        assert a["base"] == 0 and b["base"] == a["state"].shape[1]
+        assert torch.equal(torch.cat([a["state"], b["state"]], dim=1), env.state.cpu()), name
+        assert torch.equal(torch.cat([a["obs1"], b["obs1"]], dim=0), obs["player_1"].cpu()), name
+        # the one collective: counters summed over ranks == the single batch's totals, on both ranks
+        for sh in (a, b):
+            assert sh["total_envs"] == n_global and sh["total_terms"] == terms == a["terms"] + b["terms"], name
+            assert sh["total_eps"] == env.episodes_done, name
+        assert terms > 0
+
+
+def test_bench_with_two_ranks_prints_the_aggregate_line():
+    """`bench.py --gpus 2` under torch.distributed.run as the driver launches it; both ranks share cuda:0
+    (PZ_BENCH_ONE_DEVICE) and gloo stands in for RCCL.  value must be the whole-job aggregate."""
+    env = dict(os.environ, PZ_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(REPO / "bench.py"), "--gpus", "2", "--steps", "64",
+           "--warmup", "8", "--burn-in", "128", "--min-time", "0.05", "--dist-backend", "gloo", "--no-cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=str(REPO))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["dist_backend"] == "gloo"
+    assert out["config"]["num_envs_total"] == 2 * 65536 and out["scaling"] == "weak"
+    assert out["timed_steps"] >= 64 and out["timed_seconds"] >= 0.05
+    per_step_s = out["ms_per_step"] * 1e-3
+    assert np.isclose(out["value"], 2 * 65536 / per_step_s, rtol=1e-6)
+    assert "configs" not in out and "cpu_baseline" not in out  # single-GPU extras stay off for N > 1

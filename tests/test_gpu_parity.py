@@ -43,11 +43,16 @@ def cpu(t):
 # ------------------------------------------------------------------------------------------------
 # 1. golden trajectories of the reference
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", FULL_FIXTURES)
-def test_hip_matches_reference_trajectory(name):
+AI_FIXTURES = ["cfg3_p2_computer", "p1_computer", "both_computer", "full_wrapper_stack"]
+
+
+@pytest.mark.parametrize("name,tables", [(n, True) for n in FULL_FIXTURES] + [(n, False) for n in AI_FIXTURES])
+def test_hip_matches_reference_trajectory(name, tables):
+    """`tables`: the computer player's flight predictions come from the HBM look-up tables (default) or are
+    iterated in the kernel (the scout-wave launch); fixtures without a computer player never use them."""
     d = load_golden(name)
     meta = d["meta"]
-    env = make_env(meta)
+    env = make_env(meta, flight_tables=tables)
     raw = env.unwrapped
     T, L = meta["steps"], meta["lanes"]
     assert np.array_equal(cpu(raw.state), d["state_ctor"])
@@ -149,12 +154,18 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("case", list(CASES))
-def test_hip_matches_oracle_random_batches(case, oracle):
+def _has_computer(kw):
+    return bool(kw.get("is_player1_computer") or kw.get("is_player2_computer"))
+
+
+@pytest.mark.parametrize("case,tables", [(c, True) for c in CASES] +
+                         [(c, False) for c in CASES if _has_computer(CASES[c]["kw"])])
+def test_hip_matches_oracle_random_batches(case, tables, oracle):
     c = CASES[case]
     n, steps, kw, wr = c["n"], c["steps"], dict(c["kw"]), c.get("wr", {})
     seed, base, aseed = 99, 12345, 4242
-    env = make_env(num_envs=n, seed=seed, env_id_base=base, wrappers=wr, **kw)
+    env = make_env(num_envs=n, seed=seed, env_id_base=base, wrappers=wr, flight_tables=tables, **kw)
+    assert (env.unwrapped._tables_ref is not None) == (tables and _has_computer(kw))
     raw = env.unwrapped
     from oracle.ref_capture import fused_options
     ocfg = oracle.make_config(
@@ -279,10 +290,11 @@ def test_full_size_properties(n, kw, oracle):
 # ------------------------------------------------------------------------------------------------
 # 4. C ABI edge cases
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tables", [True, False])
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 129])
-def test_small_and_ragged_sizes(n, oracle):
+def test_small_and_ragged_sizes(n, tables, oracle):
     env = make_env(num_envs=n, seed=1, env_id_base=5, is_player1_computer=True, is_player2_computer=True,
-                   winning_score=1)
+                   winning_score=1, flight_tables=tables)
     env.reset()
     ref = oracle.OracleEnv(n, oracle.make_config(winning_score=1, is_player1_computer=True, is_player2_computer=True,
                                                  seed=1, env_id_base=5))
@@ -316,7 +328,7 @@ def test_stride_larger_than_n_and_error_codes(oracle):
     for t in range(100):
         assert lib.pz_step_random(state.data_ptr(), n, stride, C.byref(cfg), 11, t, 1, obs1.data_ptr(),
                                   obs2.data_ptr(), rew1.data_ptr(), rew2.data_ptr(), term.data_ptr(), None, None,
-                                  s) == 0
+                                  None, s) == 0
     torch.cuda.synchronize()
     assert bool((state[:, n:] == -7).all()), "columns beyond n must not be touched"
     ref = oracle.OracleEnv(n, oracle.make_config(winning_score=2, is_player2_computer=True, seed=77, env_id_base=9))
@@ -331,7 +343,7 @@ def test_stride_larger_than_n_and_error_codes(oracle):
     assert lib.pz_init(state.data_ptr(), n, stride, C.byref(cfg), s) == -3
     cfg.winning_score = 2
     assert lib.pz_step_random(state.data_ptr(), n, stride, C.byref(cfg), 11, 0, 0, obs1.data_ptr(), obs2.data_ptr(),
-                              rew1.data_ptr(), rew2.data_ptr(), term.data_ptr(), None, None, s) == -2
+                              rew1.data_ptr(), rew2.data_ptr(), term.data_ptr(), None, None, None, s) == -2
     assert lib.pz_observe(state.data_ptr(), n, stride, 0, obs1.data_ptr() + 4, obs2.data_ptr(), s) == -4
     cfg.normal_state_mode = 3
     assert lib.pz_init(state.data_ptr(), n, stride, C.byref(cfg), s) == -3
@@ -416,21 +428,20 @@ def _selftest(x, y, xv, yv, full_net):
 
 @pytest.mark.parametrize("full_net", [True, False])
 def test_predictor_fast_forward_equals_iteration_exhaustive(full_net, oracle):
-    """Every ball state of the reachable domain: x in [20,432], y in [0,252], x velocity in [-20,20]
-    (physics.py:607-626 bounds it), y velocity in [-300,300] in steps that include every value the power
-    hit can produce (2*|yv|); about 6e8 states per predictor form."""
+    """Every ball state of the reachable domain and far beyond it: x in [20,432], y in [0,252], x velocity in
+    [-20,20] (physics.py:607-626 bounds it), EVERY integer y velocity in [-300,300] (play reaches +-145);
+    2.6e9 states per predictor form."""
     dev = torch.device("cuda:0")
     xs = torch.arange(20, 433, dtype=torch.int32, device=dev)
     ys = torch.arange(0, 253, dtype=torch.int32, device=dev)
     xvs = torch.arange(-20, 21, dtype=torch.int32, device=dev)
     gx, gy, gxv = (t.contiguous().reshape(-1) for t in torch.meshgrid(xs, ys, xvs, indexing="ij"))
-    yv_values = list(range(-130, 131)) + list(range(-300, -130, 2)) + list(range(132, 301, 2))
-    bad = 0
-    for yv in yv_values:
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for yv in range(-300, 301):
         gyv = torch.full_like(gx, yv)
         fast, it = _selftest(gx, gy, gxv, gyv, full_net)
-        bad += int((fast != it).sum().item())
-    assert bad == 0
+        bad += (fast != it).sum()
+    assert int(bad.item()) == 0
     # spot-check the device iteration itself against the CPU oracle
     g = torch.Generator(device="cpu").manual_seed(5)
     m = 3000
@@ -623,11 +634,15 @@ def test_randomized_config_sweep_vs_oracle(oracle):
 
     from pikazoo_amd import _native
 
+    from pikazoo_amd.env import flight_tables
+
     lib = _native.load()
     rnd = random.Random(20241008)
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
+    tables_ref = C.byref(flight_tables(dev)[0])
     for trial in range(40):
+        tb = tables_ref if rnd.random() < 0.5 else None  # flight look-up tables or computed predictors
         n = rnd.choice([1, 2, 3, 31, 63, 64, 65, 100, 127, 128, 129, 255, 300, 511, 640, 700])
         stride = n + rnd.choice([0, 0, 1, 7, 64, 130])
         k = dict(winning_score=rnd.choice([1, 1, 2, 3]), serve=rnd.choice(["winner", "alternate", "random"]),
@@ -665,7 +680,7 @@ def test_randomized_config_sweep_vs_oracle(oracle):
                     d1, d2 = torch.as_tensor(a1, device=dev), torch.as_tensor(a2, device=dev)
                     assert lib.pz_step(state.data_ptr(), n, stride, C.byref(cfg), d1.data_ptr(), d2.data_ptr(),
                                        obs[0].data_ptr(), obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(),
-                                       term.data_ptr(), sp, stream) == 0
+                                       term.data_ptr(), sp, tb, stream) == 0
                     ref.step(a1, a2)
                     t += 1
             else:
@@ -674,11 +689,11 @@ def test_randomized_config_sweep_vs_oracle(oracle):
                 for _ in range(reps):
                     assert lib.pz_step_random(state.data_ptr(), n, stride, C.byref(cfg), aseed, t, kk,
                                               obs[0].data_ptr(), obs[1].data_ptr(), rew[0].data_ptr(),
-                                              rew[1].data_ptr(), term.data_ptr(), sp, None, stream) == 0
+                                              rew[1].data_ptr(), term.data_ptr(), sp, None, tb, stream) == 0
                     ref.rollout_random(aseed, t, kk)
                     t += kk
             torch.cuda.synchronize()
-            ctx = (trial, phase, mode, n, stride, k)
+            ctx = (trial, phase, mode, n, stride, tb is not None, k)
             assert np.array_equal(cpu(state[:, :n]), ref.state), ctx
             assert bool((state[:, n:] == -99).all()), ctx
             assert np.array_equal(cpu(obs[0]), ref.obs[0].view(np.int32)) and np.array_equal(cpu(obs[1]),
@@ -695,12 +710,15 @@ def test_randomized_config_sweep_vs_oracle(oracle):
     (dict(winning_score=1, is_player2_computer=True), 60, 393216),
     (dict(winning_score=1, is_player1_computer=True, is_player2_computer=True, serve="random"), 60, 393216),
 ])
-def test_two_wave_and_single_wave_kernels_agree_across_the_size_switch(kw, steps, switch, oracle):
-    """Below 393 216 games pz_step runs two waves per 64 games (human-vs-human: split by player; with a
-    computer player: a scout wave for the flight predictions), from there on one: both sides of the switch
-    against the oracle."""
+@pytest.mark.parametrize("tables", [True, False])
+def test_two_wave_and_single_wave_kernels_agree_across_the_size_switch(kw, steps, switch, tables, oracle):
+    """Below 393 216 games pz_step runs two waves per 64 games (split by player; with a computer player and no
+    flight tables: frame wave + scout wave for the flight predictions), from there on one: both sides of the
+    switch against the oracle."""
+    if not tables and not _has_computer(kw):
+        pytest.skip("no computer player: the tables are never consulted")
     for n in (switch - 64, switch):
-        env = make_env(num_envs=n, seed=44, env_id_base=7, **kw)
+        env = make_env(num_envs=n, seed=44, env_id_base=7, flight_tables=tables, **kw)
         env.reset()
         for t in range(steps):
             obs, rew, term, _, _ = env.step(env.unwrapped.random_actions(21, t))
@@ -714,3 +732,126 @@ def test_two_wave_and_single_wave_kernels_agree_across_the_size_switch(kw, steps
             assert np.array_equal(cpu(obs["player_2"][lo:lo + 1024]), robs[1]), (n, lo)
             assert np.array_equal(cpu(rew["player_1"][lo:lo + 1024]), rrew[0]), (n, lo)
             assert np.array_equal(cpu(term["player_1"][lo:lo + 1024]).astype(np.uint8), rterm), (n, lo)
+
+
+# ------------------------------------------------------------------------------------------------
+# 9. the headline size against the oracle on EVERY lane (BASELINE configs 3, 4-shard and 5 at 65 536 games)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw,wr", [
+    ("random_random_pair_kernel", dict(), {}),
+    ("cfg3_p2_computer_tables", dict(is_player2_computer=True), {}),
+    ("cfg3_p2_computer_scout", dict(is_player2_computer=True, flight_tables=False), {}),
+    ("cfg5_fused_wrappers", dict(), dict(simplify_action=True,
+                                         additional_reward=(0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01))),
+])
+def test_headline_size_every_lane_vs_oracle(name, kw, wr, oracle):
+    """65 536 games x 320 frames through pz_step (one launch per frame, actions from HBM), all lanes compared
+    with the oracle: full state every 40 frames, observations / rewards / terminations on the last frame."""
+    from oracle.ref_capture import fused_options
+
+    n, steps, seed, base, aseed = 65536, 320, 11, 1 << 33, 99
+    okw = {k: v for k, v in kw.items() if k != "flight_tables"}
+    env = make_env(num_envs=n, seed=seed, env_id_base=base, winning_score=2, wrappers=wr, **kw)
+    raw = env.unwrapped
+    ref = oracle.OracleEnv(n, oracle.make_config(winning_score=2, seed=seed, env_id_base=base, **okw,
+                                                 **fused_options(wr)), nthreads=16)
+    env.reset(), ref.reset()
+    for t in range(steps):
+        acts = raw.random_actions(aseed, t)
+        obs, rew, term, _, _ = env.step(acts)
+        if (t + 1) % 40 == 0:
+            ref.rollout_random(aseed, t + 1 - 40, 40)
+            hs = cpu(raw.state)
+            if not np.array_equal(hs, ref.state):
+                f, l = np.argwhere(hs != ref.state)[0]
+                pytest.fail(f"{name}: frame {t} lane {l} word {oracle.FIELD_NAMES[f]}: hip {hs[f, l]} != "
+                            f"oracle {ref.state[f, l]}")
+    assert np.array_equal(cpu(obs["player_1"]), ref.obs[0]) and np.array_equal(cpu(obs["player_2"]), ref.obs[1])
+    assert np.array_equal(cpu(rew["player_1"]), ref.rew[0]) and np.array_equal(cpu(rew["player_2"]), ref.rew[1])
+    assert np.array_equal(cpu(term["player_1"]).astype(np.uint8), ref.term)
+    assert int(ref.state[42].sum()) >= 0 and ref.state[43].min() >= 4
+
+
+# ------------------------------------------------------------------------------------------------
+# 10. the flight look-up tables themselves
+# ------------------------------------------------------------------------------------------------
+def test_flight_tables_hold_the_iterative_predictors(oracle):
+    """Every entry of both tables == the frame-by-frame iteration (pz_selftest_predictor's out_iter) on the ball
+    state the entry stands for, and a sample of them == the CPU oracle.  Index arithmetic is restated here."""
+    from pikazoo_amd import _native
+    from pikazoo_amd.env import flight_tables
+
+    dev = torch.device("cuda:0")
+    _, landing, power_hit = flight_tables(dev)
+    lib = _native.load()
+    YV, HYV = 96, 64
+    assert landing.numel() == lib.pz_flight_table_bytes(0) == 2 * (2 * YV + 1) * 23 * 253 * 413
+    assert power_hit.numel() == lib.pz_flight_table_bytes(1) == 16 * (HYV + 1) * 192 * 413
+    land = landing.view(torch.int16).view(2 * YV + 1, 23, 253, 413)
+    xs = torch.arange(20, 433, dtype=torch.int32, device=dev)
+    ys = torch.arange(0, 253, dtype=torch.int32, device=dev)
+    xv_values = [-20] + list(range(-10, 11)) + [20]
+    gy, gx = (t.contiguous().reshape(-1) for t in torch.meshgrid(ys, xs, indexing="ij"))
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for yi in range(2 * YV + 1):
+        for xi, xv in enumerate(xv_values):
+            _, it = _selftest(gx, gy, torch.full_like(gx, xv), torch.full_like(gx, yi - YV), True)
+            bad += (land[yi, xi].reshape(-1).to(torch.int32) != it).sum()
+    assert int(bad.item()) == 0
+    hit = power_hit.view(torch.int16).view(HYV + 1, 192, 413, 8)
+    hy = torch.arange(61, 253, dtype=torch.int32, device=dev)
+    gy, gx = (t.contiguous().reshape(-1) for t in torch.meshgrid(hy, xs, indexing="ij"))
+    for ayv in range(HYV + 1):
+        for c in range(6):
+            xdir, ydir = (1 if c < 3 else 0), (c % 3) - 1
+            sxv = torch.where(gx < 216, (xdir + 1) * 10, -(xdir + 1) * 10).to(torch.int32)
+            _, it = _selftest(gx, gy, sxv, torch.full_like(gx, ayv * ydir * 2), False)
+            bad += (hit[ayv, :, :, c].reshape(-1).to(torch.int32) != it).sum()
+    assert int(bad.item()) == 0
+    # a sample straight against the oracle's scalar predictors
+    g = torch.Generator(device="cpu").manual_seed(9)
+    m = 2000
+    X = torch.randint(20, 433, (m,), generator=g)
+    Y = torch.randint(0, 253, (m,), generator=g)
+    XI = torch.randint(0, 23, (m,), generator=g)
+    YVs = torch.randint(-YV, YV + 1, (m,), generator=g)
+    got = land.cpu()[YVs + YV, XI, Y, X - 20]
+    for j in range(m):
+        assert int(got[j]) == oracle.expected_landing_x(int(X[j]), int(Y[j]), xv_values[int(XI[j])], int(YVs[j]))
+    Yh = torch.randint(61, 253, (m,), generator=g)
+    A = torch.randint(0, HYV + 1, (m,), generator=g)
+    Cc = torch.randint(0, 6, (m,), generator=g)
+    goth = hit.cpu()[A, Yh - 61, X - 20, Cc]
+    for j in range(m):
+        c = int(Cc[j])
+        # the oracle substitutes the velocities itself (physics.py:841-845): pass the ball's |y velocity|
+        assert int(goth[j]) == oracle.expected_landing_x_power_hit(1 if c < 3 else 0, (c % 3) - 1, int(X[j]),
+                                                                   int(Yh[j]), 0, int(A[j]))
+
+
+def test_ball_states_outside_the_tables_take_the_computed_path(oracle):
+    """A ball faster than the tables' domain (|y velocity| > 96 resp. 64) or with an x velocity they do not list is
+    predicted in the kernel: plant such states and compare the next frames with the oracle."""
+    n = 4096
+    kw = dict(is_player1_computer=True, is_player2_computer=True, winning_score=3)
+    env = make_env(num_envs=n, seed=3, env_id_base=50, **kw)
+    raw = env.unwrapped
+    ref = oracle.OracleEnv(n, oracle.make_config(seed=3, env_id_base=50, **kw), nthreads=8)
+    env.reset(), ref.reset()
+    env.step_random(5, t0=0, k=40), ref.rollout_random(5, 0, 40)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    st = raw.state.cpu()
+    st[29] = torch.randint(-200, 201, (n,), generator=g, dtype=torch.int32)          # ball y velocity
+    st[28] = torch.randint(-20, 21, (n,), generator=g, dtype=torch.int32)            # x velocities 11..19 included
+    # balls next to a jumping computer player, so that the power-hit scan runs on fast balls too
+    st[3, ::2] = 1
+    st[1, ::2] = 200
+    st[26, ::2] = st[0, ::2] + 10
+    st[27, ::2] = 190
+    raw.state.copy_(st.to(raw.device))
+    ref.state[:] = st.numpy()
+    for t in range(40, 70):
+        acts = raw.random_actions(5, t)
+        env.step(acts)
+        ref.step(cpu(acts["player_1"]), cpu(acts["player_2"]))
+        assert np.array_equal(cpu(raw.state), ref.state), t

@@ -5,6 +5,8 @@ rounds in ONE process, median and min reported).
     python tools/ab.py --build name1=-DFLAG1 name2="-DFLAG2 -DFLAG3" ...   # here: cross-compile variants
     python tools/ab.py [--ai] [--n 65536] [--rollout K] name1 name2 ...    # on the GPU box: time them
                                                                            # (--rollout: pz_rollout_random, K frames/launch)
+    a name with the suffix "+t" runs that library WITH the flight look-up tables (pz_flight_tables), e.g.
+    `python tools/ab.py --ai base base+t`
 
 A variant named "base" is always built with no extra flags.  Libraries go to
 pika-zoo_amd/lib/ab_<name>.so (git-ignored, shipped by gpurun).
@@ -54,13 +56,21 @@ def main():
     dev = torch.device("cuda:0")
     P = C.c_void_p
     libs = {}
+    loaded = {}
     for nm in names:
-        lib = C.CDLL(str(LIBDIR / f"ab_{nm}.so"))
+        file = nm[:-2] if nm.endswith("+t") else nm
+        if file in loaded:
+            libs[nm] = loaded[file]
+            continue
+        lib = loaded[file] = C.CDLL(str(LIBDIR / f"ab_{file}.so"))
         lib.pz_init.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P]
         lib.pz_reset.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P]
-        lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P, P]
+        lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P, P, P]
         lib.pz_rollout_random.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), C.c_uint64, C.c_uint64,
-                                          C.c_int32, P, P, P, P, P, P, P, P, P]
+                                          C.c_int32, P, P, P, P, P, P, P, P, P, P]
+        lib.pz_flight_table_bytes.restype = C.c_int64
+        lib.pz_flight_table_bytes.argtypes = [C.c_int32]
+        lib.pz_build_flight_tables.argtypes = [P, P, P]
         libs[nm] = lib
     cfg = _native.PzConfig()
     cfg.winning_score, cfg.auto_reset, cfg.seed, cfg.p2_computer = 15, 1, 0, int(ai)
@@ -75,6 +85,12 @@ def main():
     acts = torch.randint(0, 13 if wrappers else 18, (64, 2, n), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     base = libs["base"]
+    tables = None
+    if any(nm.endswith("+t") for nm in names):
+        t_land = torch.empty(base.pz_flight_table_bytes(0), dtype=torch.uint8, device=dev)
+        t_hit = torch.empty(base.pz_flight_table_bytes(1), dtype=torch.uint8, device=dev)
+        assert base.pz_build_flight_tables(t_land.data_ptr(), t_hit.data_ptr(), stream) == 0
+        tables = _native.PzFlightTables(t_land.data_ptr(), t_hit.data_ptr())
     assert base.pz_init(state.data_ptr(), n, n, C.byref(cfg), stream) == 0
     assert base.pz_reset(state.data_ptr(), n, n, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(), None, stream) == 0
 
@@ -85,29 +101,31 @@ def main():
         t_term = torch.zeros((k, n), dtype=torch.uint8, device=dev)
         t_act = torch.zeros((k, 2, n), dtype=torch.int32, device=dev)
 
-    def run(lib, steps):
+    def run(nm, steps):
+        lib = libs[nm]
+        tb = C.byref(tables) if nm.endswith("+t") else None
         if rollout:
             for j in range(max(1, steps // rollout)):
                 rc = lib.pz_rollout_random(state.data_ptr(), n, n, C.byref(cfg), 7, j * rollout, rollout,
                                            t_act.data_ptr(), t_obs[0].data_ptr(), t_obs[1].data_ptr(),
                                            t_rew[0].data_ptr(), t_rew[1].data_ptr(), t_term.data_ptr(), None, None,
-                                           stream)
+                                           tb, stream)
                 assert rc == 0, rc
             return max(1, steps // rollout) * rollout
         for t in range(steps):
             a = acts[t % 64]
             lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
-                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), None, stream)
+                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), None, tb, stream)
         return steps
 
-    run(base, 700)
+    run("base", 700)
     snapshot = state.clone()
     torch.cuda.synchronize()
     # every variant must produce the same trajectory as base
     finals = {}
-    for nm, lib in libs.items():
+    for nm in names:
         state.copy_(snapshot)
-        run(lib, 128)
+        run(nm, 128)
         torch.cuda.synchronize()
         finals[nm] = ((state.clone(), t_obs[0].clone(), t_obs[1].clone(), t_rew[0].clone(), t_term.clone()) if rollout
                       else (state.clone(), obs[0].clone(), obs[1].clone(), rew[0].clone(), term.clone()))
@@ -117,12 +135,12 @@ def main():
     K, rounds = 400, 9
     times = {nm: [] for nm in names}
     for _ in range(rounds):
-        for nm, lib in libs.items():
+        for nm in names:
             state.copy_(snapshot)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            frames = run(lib, K)
+            frames = run(nm, K)
             e1.record()
             torch.cuda.synchronize()
             times[nm].append(e0.elapsed_time(e1) * 1e3 / frames)

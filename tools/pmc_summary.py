@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Condense the raw rocprofv3 output of tools/profile.sh into the files committed under profiles/.
+
+    python tools/pmc_summary.py TAG        # reads gpurun_out/prof_TAG/, writes profiles/TAG_*.{csv,json}
+
+* kernel stats  (``*_kernel_stats.csv`` of the --kernel-trace --stats runs) are copied as they are;
+* counter runs  (``*_counter_collection.csv``): per kernel and counter the mean over the step-kernel dispatches of
+  the timed part (burn-in / reset / policy kernels are listed separately), plus the derived figures
+  DESIGN.md quotes: VALU issue utilisation, active-lane utilisation, wave occupancy, LDS bank-conflict share,
+  HBM-side bytes (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note, WRITE_SIZE exact);
+* ``traffic.json`` gets / keeps one entry per workload with measured bytes per launch (read by bench.py).
+"""
+import csv
+import json
+import shutil
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+STEP_KERNELS = ("pz::step_pair_kernel", "pz::step_kernel")
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def counter_means(csv_path, trace_path=None):
+    """{kernel: {counter: mean value per dispatch}} and {kernel: dispatches} of one counter_collection.csv."""
+    sums, counts = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
+    meta = {}
+    with open(csv_path) as f:
+        for row in csv.DictReader(f):
+            k = short(row["Kernel_Name"])
+            c = row["Counter_Name"]
+            sums[k][c] += float(row["Counter_Value"])
+            counts[k][c] += 1
+            meta[k] = {"grid": int(row["Grid_Size"]), "workgroup": int(row["Workgroup_Size"]),
+                       "vgpr": int(row["VGPR_Count"]), "sgpr": int(row["SGPR_Count"]),
+                       "lds": int(row["LDS_Block_Size"])}
+    means = {k: {c: sums[k][c] / counts[k][c] for c in sums[k]} for k in sums}
+    disp = {k: max(counts[k].values()) for k in counts}
+    return means, disp, meta
+
+
+def kernel_avg_ns(trace_csv):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    with open(trace_csv) as f:
+        for row in csv.DictReader(f):
+            k = short(row["Kernel_Name"])
+            tot[k] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+            cnt[k] += 1
+    return {k: tot[k] / cnt[k] for k in tot}, dict(cnt)
+
+
+def find(run_dir, suffix):
+    hits = sorted(Path(run_dir).rglob(f"*{suffix}"))
+    return hits[0] if hits else None
+
+
+def main():
+    tag = sys.argv[1]
+    src = REPO / "gpurun_out" / f"prof_{tag}"
+    dst = REPO / "profiles"
+    dst.mkdir(exist_ok=True)
+    summary = {}
+    for run in sorted(p for p in src.iterdir() if p.is_dir()):
+        name = run.name
+        stats = find(run, "_kernel_stats.csv")
+        if stats is not None:
+            shutil.copy(stats, dst / f"{tag}_{name}_kernel_stats.csv")
+        cc = find(run, "_counter_collection.csv")
+        if cc is None:
+            continue
+        means, disp, meta = counter_means(cc)
+        trace = find(run, "_kernel_trace.csv")
+        avg_ns, _ = kernel_avg_ns(trace) if trace else ({}, {})
+        entry = {}
+        for k in means:
+            if not k.startswith(STEP_KERNELS):
+                continue
+            entry[k] = {"dispatches": disp[k], "avg_ns_under_pmc": avg_ns.get(k), **meta[k], "counters": means[k]}
+        summary[name] = entry
+    # derived figures per workload prefix (hh / cfg3 / big)
+    derived = {}
+    for prefix in sorted({n.rsplit("_", 1)[0] for n in summary}):
+        d = {}
+        fetch = summary.get(f"{prefix}_fetch", {})
+        write = summary.get(f"{prefix}_write", {})
+        for k, e in fetch.items():
+            d.setdefault(k, {})["fetch_size_kb_raw"] = e["counters"].get("FETCH_SIZE")
+        for k, e in write.items():
+            d.setdefault(k, {})["write_size_kb"] = e["counters"].get("WRITE_SIZE")
+        for k, v in d.items():
+            if v.get("fetch_size_kb_raw") is not None and v.get("write_size_kb") is not None:
+                # gfx950: FETCH_SIZE reports 1/2 of coalesced read bytes (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact
+                v["hbm_bytes_per_launch"] = (2.0 * v["fetch_size_kb_raw"] + v["write_size_kb"]) * 1024.0
+        sqa = summary.get(f"{prefix}_sqa", {})
+        sqb = summary.get(f"{prefix}_sqb", {})
+        for k, e in sqa.items():
+            c = e["counters"]
+            v = d.setdefault(k, {})
+            waves, wc = c.get("SQ_WAVES"), c.get("SQ_WAVE_CYCLES")
+            if waves and wc:
+                v["waves_per_launch"] = waves
+                v["wave_cycles_per_wave_x4"] = 4.0 * wc / waves           # SQ_WAVE_CYCLES counts quad-cycles
+            if c.get("SQ_BUSY_CYCLES") and wc:
+                v["avg_waves_resident_per_busy_SQ_cycle"] = wc / c["SQ_BUSY_CYCLES"]
+            if c.get("SQ_ACTIVE_INST_VALU") and wc:
+                v["valu_issue_share_of_wave_cycles"] = c["SQ_ACTIVE_INST_VALU"] / wc
+            if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
+                # thread-cycles / (instruction-cycles x 64 lanes): share of lanes active in issued VALU work
+                v["valu_active_lane_share"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+            if c.get("SQ_INSTS_VALU") and waves:
+                v["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / waves
+            for name in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+                if c.get(name) and wc:
+                    v[name.lower() + "_share"] = c[name] / wc
+        for k, e in sqb.items():
+            c = e["counters"]
+            v = d.setdefault(k, {})
+            if c.get("SQ_LDS_IDX_ACTIVE"):
+                v["lds_bank_conflict_share"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
+            for name in ("SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
+                if name in c:
+                    v[name.lower() + "_per_launch"] = c[name]
+        derived[prefix] = d
+    out = {"tag": tag, "derived": derived, "raw_means": summary}
+    (dst / f"{tag}_pmc_summary.json").write_text(json.dumps(out, indent=1))
+    print(json.dumps(derived, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,54 @@
+#!/bin/bash
+# tools/profile.sh TAG [SECTION ...] -- rocprofv3 evidence for profiles/ (run on the GPU box through gpurun).
+#
+#   kt        --kernel-trace --stats of the default bench line (all single-GPU BASELINE configs in one run)
+#   pmc_hh    FETCH_SIZE / WRITE_SIZE / SQ passes on the headline (random/random, 65 536 games)
+#   pmc_cfg3  the same passes on config 3 (player 2 = computer)
+#   pmc_big   FETCH_SIZE / WRITE_SIZE at 524 288 games (config 4's total size: past the Infinity Cache)
+#   kt_roll   --kernel-trace --stats of pz_rollout_random / pz_step_many (k = 32)
+#
+# Every PMC pass is its own rocprofv3 run with --kernel-trace only (MI355X_MICROARCH.md, rocprofv3 PMC slots:
+# FETCH_SIZE and WRITE_SIZE do not fit one pass; gpurun refuses --pmc together with the API trace domains).
+# Raw output lands in gpurun_out/prof_$TAG/; tools/pmc_summary.py condenses it into profiles/.
+set -u
+TAG=${1:?tag}
+shift
+SECTIONS=${*:-kt pmc_hh pmc_cfg3 pmc_big kt_roll}
+OUT=gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+PY=python3
+SQ_A="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+SQ_B="SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS"
+
+run() {  # name, rocprof args..., -- , program args
+    local name=$1
+    shift
+    echo "== $name" | tee -a "$OUT/log.txt"
+    rocprofv3 -d "$OUT/$name" -o run "$@" > "$OUT/$name.log" 2>&1 || { echo "rocprofv3 failed: $name (see $OUT/$name.log)" | tee -a "$OUT/log.txt"; tail -5 "$OUT/$name.log"; return 1; }
+}
+
+pmc_set() {  # prefix, bench args...
+    local p=$1
+    shift
+    run "${p}_fetch" --kernel-trace --pmc FETCH_SIZE -- $PY bench.py "$@" || return 1
+    run "${p}_write" --kernel-trace --pmc WRITE_SIZE -- $PY bench.py "$@" || return 1
+    run "${p}_sqa" --kernel-trace --pmc $SQ_A -- $PY bench.py "$@" || return 1
+    run "${p}_sqb" --kernel-trace --pmc $SQ_B -- $PY bench.py "$@" || return 1
+}
+
+for s in $SECTIONS; do
+    case $s in
+    kt) run kt --kernel-trace --stats -- $PY bench.py --no-cpu || exit 1 ;;
+    pmc_hh) pmc_set hh --no-cpu --no-configs --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1 ;;
+    pmc_cfg3) pmc_set cfg3 --no-cpu --no-configs --p2-computer --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1 ;;
+    pmc_big)
+        run big_fetch --kernel-trace --pmc FETCH_SIZE -- $PY bench.py --no-cpu --no-configs --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
+        run big_write --kernel-trace --pmc WRITE_SIZE -- $PY bench.py --no-cpu --no-configs --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
+        run big_kt --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --num-envs 524288 --steps 300 --warmup 50 --burn-in 256 --launch cabi || exit 1
+        ;;
+    kt_roll) run roll --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --rollouts || exit 1 ;;
+    *) echo "unknown section $s"; exit 2 ;;
+    esac
+done
+echo "done: $OUT" | tee -a "$OUT/log.txt"
