@@ -672,6 +672,87 @@ __device__ __forceinline__ void computer_decide_finish(const HitScan& hs, const 
     }
 }
 
+// The same decision for the pair kernel, in one straight-line piece: let_computer_decide_user_input
+// (physics.py:689-771) incl. decide_whether_input_power_hit (:774-817), with
+//   * the env stream's next three draws handed in (`pre`: Philox word 0 at counters rng, rng+1, rng+2, which the
+//     caller computes unconditionally while its table gathers are in flight): the decision makes at most three
+//     draws -- (0,20) :728, (0,2) :729, (0,2) :795 -- always from consecutive counters, so every draw becomes a
+//     select instead of a divergent 10-round Philox on the wave's critical path;
+//   * the six candidate landing points handed in (`ex`, meaningful where `scan`: gathered from the power-hit
+//     table as soon as the ball has moved -- `scan` = power_hit_scan_needed is a pure function of the player before
+//     its move and of the ball).
+// Returns the number of draws made (the caller advances the stream by it).
+struct PreDrawn {
+    uint32_t w0, w1, w2;
+};
+
+__device__ __forceinline__ PreDrawn predraw3(const RngId& id, uint32_t counter)
+{
+    PreDrawn pre;
+    uint32_t unused;
+    philox4x32_10(id.id_lo, id.id_hi, counter, 0u, id.k0, id.k1, pre.w0, unused);
+    philox4x32_10(id.id_lo, id.id_hi, counter + 1u, 0u, id.k0, id.k1, pre.w1, unused);
+    philox4x32_10(id.id_lo, id.id_hi, counter + 2u, 0u, id.k0, id.k1, pre.w2, unused);
+    return pre;
+}
+
+template <bool IS_P2>
+__device__ __forceinline__ uint32_t computer_decide_predrawn(Player& p, const Ball& b, int other_x, const PreDrawn& pre,
+                                                            bool scan, const int (&ex)[6], Input& in)
+{
+    constexpr int kLeft = IS_P2 ? kGroundHalfWidth : 0;                      // left boundary of own side
+    constexpr int kRight = kLeft + kGroundHalfWidth;                         // right boundary
+    constexpr int kOppHigh = (IS_P2 ? kGroundWidth : 0) + kGroundHalfWidth;  // :718,:801
+
+    const int dxb = abs(b.x - p.x);
+    const bool far_slow = (dxb > 100) & (abs(b.xv) < p.bold + 5);
+    const bool ex_outside = (b.ex <= kLeft) | (b.ex >= kOppHigh);
+    const int target = (far_slow & ex_outside & (p.standby == 0)) ? kLeft + kGroundHalfWidth / 2 : b.ex;  // :713-722
+
+    const bool moving = abs(target - p.x) > p.bold + 8;
+    int xd = moving ? ((p.x < target) ? 1 : -1) : 0;  // :724-728
+    int yd = 0, hit = 0;
+    // :728-729 -- integers(0, 20) == 0, then integers(0, 2); (u32 * n) >> 32 as in rng_integers
+    const bool redraw = !moving & (__umulhi(pre.w0, 20u) == 0u);
+    p.standby = redraw ? (int)__umulhi(pre.w1, 2u) : p.standby;
+    uint32_t draws = moving ? 0u : (redraw ? 2u : 1u);
+
+    const bool toward = p.x < b.x;
+    if (p.state == 0) {
+        const bool jump = (abs(b.xv) < p.bold + 3) & (dxb < kPlayerHalfLength) & (b.y > -36) & (b.y < 10 * p.bold + 84) &
+                          (b.yv > 0);
+        yd = jump ? -1 : 0;
+        const bool dive = (b.ex > kLeft) & (b.ex < kRight) & (dxb > p.bold * 5 + kPlayerLength) & (b.x > kLeft) &
+                          (b.x < kRight) & (b.y > 174);
+        hit = dive ? 1 : 0;
+        xd = dive ? (toward ? 1 : -1) : xd;
+    } else if (p.state == 1 || p.state == 2) {
+        xd = (dxb > 8) ? (toward ? 1 : -1) : xd;
+        if (scan) {  // == dxb < 48 && |b.y - p.y| < 48 in these states (:757)
+            const uint32_t w = draws == 0u ? pre.w0 : (draws == 1u ? pre.w1 : pre.w2);
+            const bool ascending = __umulhi(w, 2u) == 0u;  // :795
+            draws += 1u;
+            bool found = false;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                // scan order: x_direction 1 then 0; y_direction ascending (-1,0,1) or descending (1,0,-1)
+                const int c = ascending ? k : (k < 3 ? 2 - k : 8 - k);
+                const int e = ascending ? ex[k] : ex[k < 3 ? 2 - k : 8 - k];
+                const bool good = !found & ((e <= kLeft) | (e >= kOppHigh)) & (abs(e - other_x) > kPlayerLength);
+                xd = good ? candidate_xdir(c) : xd;
+                yd = good ? candidate_ydir(c) : yd;
+                found |= good;
+            }
+            hit = found ? 1 : hit;
+            yd = (found & (abs(other_x - p.x) < 80)) ? -1 : yd;  // :768-771
+        }
+    }
+    in.xd = xd;
+    in.yd = yd;
+    in.hit = hit;
+    return draws;
+}
+
 // ---------------------------------------------------------------------------------------
 // Player movement (physics.py:457-552; the game-end tail :554-564 is unreachable under the
 // env because termination is immediate, pikazoo_env.py:230-233).
@@ -1058,12 +1139,11 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             draws_other = (uint32_t)early[1];
         }
     }
+#ifdef PZ_NO_PREDRAWN  // tools/ab.py variant: the decision as the single-wave frame makes it (draws on demand)
     if (kOwnAI) {
         if (active) {
-            // :314-315 recomputes the landing point before each player; the ball does not move in between
             g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
             if (ROLE == 1 && !AI1) {
-                // player 1 (human) has moved when player 2 decides: its new x as player_move computes it
                 const int vx = (other.state < 3) ? in1.xd * 6 : other.dive * 8;
                 const int nx = min(max(other.x + vx, kPlayerHalfLength), kGroundHalfWidth - kPlayerHalfLength);
                 other.x = (other.state == 4) ? other.x : nx;
@@ -1076,6 +1156,26 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             computer_decide_finish<ROLE == 1>(hs, ex, own, other, in_own);
         }
     }
+#else
+    if (kOwnAI) {
+        if (active) {
+            // :314-315 recomputes the landing point before each player; the ball does not move in between.
+            // Both gathers go out first; the three Philox blocks of the decision's draws run under their latency.
+            const bool scan = power_hit_scan_needed(own, g.b);
+            int ex[6] = {0, 0, 0, 0, 0, 0};
+            g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
+            if (scan) lut.power_hit_candidates(g.b.x, g.b.y, abs(g.b.yv), ex);
+            const PreDrawn pre = predraw3(id, rng_base + draws_other);
+            if (ROLE == 1 && !AI1) {
+                // player 1 (human) has moved when player 2 decides: its new x as player_move computes it
+                const int vx = (other.state < 3) ? in1.xd * 6 : other.dive * 8;
+                const int nx = min(max(other.x + vx, kPlayerHalfLength), kGroundHalfWidth - kPlayerHalfLength);
+                other.x = (other.state == 4) ? other.x : nx;
+            }
+            draws_own = computer_decide_predrawn<ROLE == 1>(own, g.b, other.x, pre, scan, ex, in_own);
+        }
+    }
+#endif
     if (active) player_move<ROLE == 1>(own, in_own);
     if (ROLE == 0 && AI1 && AI2) {
         if (active) {

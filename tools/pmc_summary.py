@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Condense the raw rocprofv3 output of tools/profile.sh into the files committed under profiles/.
 
-    python tools/pmc_summary.py TAG        # reads gpurun_out/prof_TAG/, writes profiles/TAG_*.{csv,json}
+    python tools/pmc_summary.py TAG        # reads gpurun_out/prof_TAG/<run>/, writes gpurun_out/prof_TAG/out/TAG_*
+
+(tools/profile.sh runs it on the GPU box and then deletes the raw traces: gpurun brings back at most 64 MiB;
+copy gpurun_out/prof_TAG/out/* into profiles/ to commit them.)
 
 * kernel stats  (``*_kernel_stats.csv`` of the --kernel-trace --stats runs) are copied as they are;
 * counter runs  (``*_counter_collection.csv``): per kernel and counter the mean over the step-kernel dispatches of
@@ -53,6 +56,22 @@ def kernel_avg_ns(trace_csv):
     return {k: tot[k] / cnt[k] for k in tot}, dict(cnt)
 
 
+def sample_rows(csv_path, out_path, per_kernel=24):
+    """The first `per_kernel` rows of every step kernel of a counter_collection.csv, as evidence."""
+    seen = defaultdict(int)
+    with open(csv_path) as f, open(out_path, "w", newline="") as g:
+        r = csv.reader(f)
+        w = csv.writer(g)
+        header = next(r)
+        w.writerow(header)
+        ki = header.index("Kernel_Name")
+        for row in r:
+            k = short(row[ki])
+            if k.startswith(STEP_KERNELS) and seen[k] < per_kernel:
+                seen[k] += 1
+                w.writerow(row)
+
+
 def find(run_dir, suffix):
     hits = sorted(Path(run_dir).rglob(f"*{suffix}"))
     return hits[0] if hits else None
@@ -61,10 +80,10 @@ def find(run_dir, suffix):
 def main():
     tag = sys.argv[1]
     src = REPO / "gpurun_out" / f"prof_{tag}"
-    dst = REPO / "profiles"
+    dst = src / "out"
     dst.mkdir(exist_ok=True)
     summary = {}
-    for run in sorted(p for p in src.iterdir() if p.is_dir()):
+    for run in sorted(p for p in src.iterdir() if p.is_dir() and p.name != "out"):
         name = run.name
         stats = find(run, "_kernel_stats.csv")
         if stats is not None:
@@ -73,6 +92,7 @@ def main():
         if cc is None:
             continue
         means, disp, meta = counter_means(cc)
+        sample_rows(cc, dst / f"{tag}_{name}_counter_sample.csv")
         trace = find(run, "_kernel_trace.csv")
         avg_ns, _ = kernel_avg_ns(trace) if trace else ({}, {})
         entry = {}

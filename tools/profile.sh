@@ -3,7 +3,8 @@
 #
 #   kt        --kernel-trace --stats of the default bench line (all single-GPU BASELINE configs in one run)
 #   pmc_hh    FETCH_SIZE / WRITE_SIZE / SQ passes on the headline (random/random, 65 536 games)
-#   pmc_cfg3  the same passes on config 3 (player 2 = computer)
+#   pmc_cfg3  the same passes on config 3 (player 2 = computer, flight look-up tables)
+#   pmc_cfg3c the same passes on config 3 with the flight predictors computed in the kernel (scout-wave launch)
 #   pmc_big   FETCH_SIZE / WRITE_SIZE at 524 288 games (config 4's total size: past the Infinity Cache)
 #   kt_roll   --kernel-trace --stats of pz_rollout_random / pz_step_many (k = 32)
 #
@@ -13,7 +14,7 @@
 set -u
 TAG=${1:?tag}
 shift
-SECTIONS=${*:-kt pmc_hh pmc_cfg3 pmc_big kt_roll}
+SECTIONS=${*:-kt pmc_hh pmc_cfg3 pmc_cfg3c pmc_big kt_roll}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -42,6 +43,7 @@ for s in $SECTIONS; do
     kt) run kt --kernel-trace --stats -- $PY bench.py --no-cpu || exit 1 ;;
     pmc_hh) pmc_set hh --no-cpu --no-configs --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1 ;;
     pmc_cfg3) pmc_set cfg3 --no-cpu --no-configs --p2-computer --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1 ;;
+    pmc_cfg3c) pmc_set cfg3c --no-cpu --no-configs --p2-computer --no-flight-tables --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1 ;;
     pmc_big)
         run big_fetch --kernel-trace --pmc FETCH_SIZE -- $PY bench.py --no-cpu --no-configs --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
         run big_write --kernel-trace --pmc WRITE_SIZE -- $PY bench.py --no-cpu --no-configs --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
@@ -51,4 +53,7 @@ for s in $SECTIONS; do
     *) echo "unknown section $s"; exit 2 ;;
     esac
 done
+# condense on the box (gpurun brings back at most 64 MiB of gpurun_out/), then drop the raw traces
+$PY tools/pmc_summary.py "$TAG" > "$OUT/summary.log" 2>&1 || { echo "pmc_summary failed"; tail -5 "$OUT/summary.log"; exit 1; }
+find "$OUT" -mindepth 1 -maxdepth 1 -type d ! -name out -exec rm -rf {} +
 echo "done: $OUT" | tee -a "$OUT/log.txt"
