@@ -380,7 +380,8 @@ __device__ unsigned long long g_pz_stamps[8192 * 8];
 // timing-only build (tools/ablate.py): cfg.reserved bits skip parts of the kernel; results are
 // wrong by construction.  bit3: no game logic; bit4: no observation staging / flush;
 // bits 5,6,7: skip the landing predictor before the players / the power-hit candidates / the
-// landing predictor after a collision (pz_physics.hpp).
+// landing predictor after a collision (pz_physics.hpp); pair kernel also bit 8: no pre-drawn Philox
+// blocks, bit 9: no computer decision at all.
 #define PZ_SKIP_FRAME ((a.cfg.reserved & 8) != 0)
 #define PZ_SKIP_OBS ((a.cfg.reserved & 16) != 0)
 #else
@@ -783,15 +784,18 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     const Game loaded = g;  // what the columns held before the frame
     const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     bool frozen = false;
+#ifdef PZ_ABLATE
+    g_pz_ablate_bits = a.cfg.reserved;  // every lane stores the same value; read by the hooks in pz_physics.hpp
+#endif
+    LandingProbe after_hit{false, false, 0u};
     const int reward = step_games_pair<ROLE, AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, xchg, kLanes * PZ_OBS_DIM,
-                                                        lane, lut);
+                                                        lane, lut, after_hit);
     const Rewards rw = shape_rewards(a.cfg, g, reward, frozen);
     if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
 
     if (live) {
         // changed-only write-back of the rarely changing columns, as in store_game_changed
         store_player_changed(ROLE == 0 ? g.p1 : g.p2, ROLE == 0 ? loaded.p1 : loaded.p2, io, kOwn);
-        if (kKeepsEx && g.b.ex != loaded.b.ex) io.st(PZ_B_EXPECTED_LANDING_POINT_X, g.b.ex);
         if (ROLE == 0) {
             io.st(PZ_B_X, g.b.x);
             io.st(PZ_B_Y, g.b.y);
@@ -832,6 +836,11 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     }
     __syncthreads();
     flush_rows(lds_obs[ROLE], ROLE == 0 ? a.obs_p1 : a.obs_p2, n32 * kRowBytes, lane);
+    // last: after a ball-player collision the value comes from a table gather issued at the end of the frame
+    if (kKeepsEx) {
+        const int ex = lut.landing_finish(after_hit, g.b.x, g.b.y, g.b.xv, g.b.yv, g.b.ex);
+        if (live && ex != loaded.b.ex) io.st(PZ_B_EXPECTED_LANDING_POINT_X, ex);
+    }
 }
 
 template <bool AI1, bool AI2>

@@ -475,38 +475,67 @@ __device__ __forceinline__ int ft_xv_index(int xv)
 }
 __device__ __forceinline__ int ft_xv_value(int index) { return index == 0 ? -20 : (index == 22 ? 20 : index - 11); }
 
+// A look-up in two halves, so that a caller can put independent work between them: `*_issue` computes the entry and
+// issues the load unconditionally (a lane outside the table's domain -- or without a table -- reads entry 0; the
+// range check of an empty descriptor returns 0), `*_finish` takes the loaded value or, for the rare lane outside
+// the domain, runs the computed form.  (A load inside the `inside the domain` branch would be waited for before the
+// branch closes: the two gathers of a decision and the Philox blocks between them would run one after the other.)
+struct LandingProbe {
+    bool in, wanted;
+    uint32_t value;
+};
+struct CandidateProbe {
+    bool in, wanted;
+    lut_u32x4 value;
+};
+
 struct FlightLut {
     TableRsrc landing, power_hit;
     bool has_landing, has_power_hit;  // wave-uniform (kernel arguments)
 
     // calculate_expected_landing_point_x_for (physics.py:643-686)
-    __device__ __forceinline__ int landing_x(int x, int y, int xv, int yv) const
+    // (`wanted` false: the lane needs no prediction; finish returns `keep`)
+    __device__ __forceinline__ LandingProbe landing_issue(bool wanted, int x, int y, int xv, int yv) const
     {
         const int xi = ft_xv_index(xv);
-        const bool in = has_landing & (xi >= 0) & ((unsigned)(x - kBallRadius) < (unsigned)kFtXCount) &
+        const bool in = wanted & has_landing & (xi >= 0) & ((unsigned)(x - kBallRadius) < (unsigned)kFtXCount) &
                         ((unsigned)y < (unsigned)kFtYCount) & (abs(yv) <= PZ_FT_YV_MAX);
-        if (in) {
-            const uint32_t e = (uint32_t)((((yv + PZ_FT_YV_MAX) * kFtXvCount + xi) * kFtYCount + y) * kFtXCount + (x - kBallRadius));
-            return (int)__builtin_amdgcn_raw_buffer_load_b16(landing, e * 2u, 0, 0);
-        }
-        return predict_landing_x<true>(x, y, xv, yv);
+        // 24-bit multiplies (every factor is far below 2^24, the products below 2^32): three cheap instructions, so
+        // the entry is computed for every lane and selected -- not put behind a branch that the loads would wait at
+        uint32_t e = __umul24((uint32_t)(yv + PZ_FT_YV_MAX), (uint32_t)kFtXvCount) + (uint32_t)xi;
+        e = __umul24(e, (uint32_t)kFtYCount) + (uint32_t)y;
+        e = __umul24(e, (uint32_t)kFtXCount) + (uint32_t)(x - kBallRadius);
+        return LandingProbe{in, wanted, (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(landing, in ? e * 2u : 0u, 0, 0)};
+    }
+    __device__ __forceinline__ int landing_finish(const LandingProbe& p, int x, int y, int xv, int yv, int keep) const
+    {
+        if (p.wanted & !p.in) return predict_landing_x<true>(x, y, xv, yv);
+        return p.in ? (int)p.value : keep;
+    }
+    __device__ __forceinline__ int landing_x(int x, int y, int xv, int yv) const
+    {
+        return landing_finish(landing_issue(true, x, y, xv, yv), x, y, xv, yv, 0);
     }
 
-    // the six candidates of decide_whether_input_power_hit (physics.py:796-816) for the ball (x, y, |yv|)
-    __device__ __forceinline__ void power_hit_candidates(int x, int y, int ayv, int (&ex)[6]) const
+    // the six candidates of decide_whether_input_power_hit (physics.py:796-816) for the ball (x, y, |yv|);
+    // `wanted`: this lane's computer player scans this frame
+    __device__ __forceinline__ CandidateProbe candidates_issue(bool wanted, int x, int y, int ayv) const
     {
-        const bool in = has_power_hit & ((unsigned)(x - kBallRadius) < (unsigned)kFtXCount) &
+        const bool in = wanted & has_power_hit & ((unsigned)(x - kBallRadius) < (unsigned)kFtXCount) &
                         ((unsigned)(y - kFtHitYMin) < (unsigned)kFtHitYCount) & ((unsigned)ayv <= (unsigned)PZ_FT_HIT_YV_MAX);
-        if (in) {
-            const uint32_t e = (uint32_t)((ayv * kFtHitYCount + (y - kFtHitYMin)) * kFtXCount + (x - kBallRadius));
-            const lut_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(power_hit, e * 16u, 0, 0);
-            ex[0] = (int)(w.x & 0xFFFFu);
-            ex[1] = (int)(w.x >> 16);
-            ex[2] = (int)(w.y & 0xFFFFu);
-            ex[3] = (int)(w.y >> 16);
-            ex[4] = (int)(w.z & 0xFFFFu);
-            ex[5] = (int)(w.z >> 16);
-        } else {
+        uint32_t e = __umul24((uint32_t)ayv, (uint32_t)kFtHitYCount) + (uint32_t)(y - kFtHitYMin);
+        e = __umul24(e, (uint32_t)kFtXCount) + (uint32_t)(x - kBallRadius);
+        return CandidateProbe{in, wanted, __builtin_amdgcn_raw_buffer_load_b128(power_hit, in ? e * 16u : 0u, 0, 0)};
+    }
+    __device__ __forceinline__ void candidates_finish(const CandidateProbe& p, int x, int y, int ayv, int (&ex)[6]) const
+    {
+        ex[0] = (int)(p.value.x & 0xFFFFu);
+        ex[1] = (int)(p.value.x >> 16);
+        ex[2] = (int)(p.value.y & 0xFFFFu);
+        ex[3] = (int)(p.value.y >> 16);
+        ex[4] = (int)(p.value.z & 0xFFFFu);
+        ex[5] = (int)(p.value.z >> 16);
+        if (p.wanted & !p.in) {
 #pragma unroll 1
             for (int c = 0; c < 6; ++c) {
                 const int xdir = c < 3 ? 1 : 0, ydir = (c < 3 ? c : c - 3) - 1;
@@ -516,6 +545,10 @@ struct FlightLut {
                 for (int k = 0; k < 6; ++k) ex[k] = (k == c) ? e : ex[k];  // (no dynamic register indexing)
             }
         }
+    }
+    __device__ __forceinline__ void power_hit_candidates(int x, int y, int ayv, int (&ex)[6]) const
+    {
+        candidates_finish(candidates_issue(true, x, y, ayv), x, y, ayv, ex);
     }
 };
 
@@ -1070,7 +1103,8 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
 //   * the decided (x_direction, y_direction) travel with the player too: the ball-player collision takes
 //     the power hit's direction from them (physics.py:329 passes the mutated user_input).
 // The flight predictions come from `lut` (tables or, outside their domain, the computed form); the wave
-// that owns the (last) computer player keeps ball.expected_landing_point_x (`keeps_ex`).
+// that owns the (last) computer player keeps ball.expected_landing_point_x (kKeepsEx) and hands the look-up of its
+// value after a ball-player collision back to the caller (`after_hit`, finished behind the caller's stores).
 // xchg: two regions of LDS, `xchg_region` words apart; a wave writes into the PARTNER's region and reads
 // from its own, so a wave may reuse its own region afterwards without asking (the pair kernel aliases them
 // with the observation staging rows).  One __syncthreads(), two when both players are computers.
@@ -1081,7 +1115,7 @@ constexpr int kEarlyPostAt = 1024;  // word offset of the early post {x, draws} 
 template <int ROLE, bool AI1, bool AI2>
 __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2,
                                                bool live, bool& frozen, int32_t* __restrict__ xchg, int xchg_region,
-                                               int lane, const FlightLut& lut)
+                                               int lane, const FlightLut& lut, LandingProbe& after_hit)
 {
     constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
     constexpr bool kOtherAI = ROLE == 0 ? AI2 : AI1;
@@ -1162,17 +1196,27 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             // :314-315 recomputes the landing point before each player; the ball does not move in between.
             // Both gathers go out first; the three Philox blocks of the decision's draws run under their latency.
             const bool scan = power_hit_scan_needed(own, g.b);
+            const int ayv = abs(g.b.yv);
             int ex[6] = {0, 0, 0, 0, 0, 0};
-            g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
-            if (scan) lut.power_hit_candidates(g.b.x, g.b.y, abs(g.b.yv), ex);
-            const PreDrawn pre = predraw3(id, rng_base + draws_other);
+            LandingProbe lp = lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv);
+            CandidateProbe cp = lut.candidates_issue(scan && !PZ_ABLATE_SKIP(64), g.b.x, g.b.y, ayv);
+            PreDrawn pre = PZ_ABLATE_SKIP(256) ? PreDrawn{1u, 1u, 1u} : predraw3(id, rng_base + draws_other);
+            // Keep the Philox blocks where they are written -- under the two gathers.  Left alone the compiler sinks
+            // them below the (rare) out-of-domain branches of the look-ups and waits for the gathers first.  The empty
+            // statement reads the draws together with the gathered registers: the draws must be complete before it,
+            // and the first wait for the gathers lands immediately in front of it.
+            asm volatile("" : "+v"(pre.w0), "+v"(pre.w1), "+v"(pre.w2), "+v"(lp.value), "+v"(cp.value.x), "+v"(cp.value.y),
+                         "+v"(cp.value.z));
             if (ROLE == 1 && !AI1) {
                 // player 1 (human) has moved when player 2 decides: its new x as player_move computes it
                 const int vx = (other.state < 3) ? in1.xd * 6 : other.dive * 8;
                 const int nx = min(max(other.x + vx, kPlayerHalfLength), kGroundHalfWidth - kPlayerHalfLength);
                 other.x = (other.state == 4) ? other.x : nx;
             }
-            draws_own = computer_decide_predrawn<ROLE == 1>(own, g.b, other.x, pre, scan, ex, in_own);
+            g.b.ex = PZ_ABLATE_SKIP(32) ? g.b.x : lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, 0);
+            lut.candidates_finish(cp, g.b.x, g.b.y, ayv, ex);
+            if (!PZ_ABLATE_SKIP(512))
+                draws_own = computer_decide_predrawn<ROLE == 1>(own, g.b, other.x, pre, scan, ex, in_own);
         }
     }
 #endif
@@ -1222,6 +1266,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
         }
     }
     int reward = 0;
+    bool hit_processed = false;
     if (active) {
         g.e.rng = rng_base + draws_own + draws_other;
 
@@ -1242,10 +1287,12 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
         g.e.round_ended = ground;
         reward = ground ? (p2_scores ? -1 : 1) : 0;
 
-        // :331-332 -- predicted again after a processed collision (one evaluation after both collisions
-        // leaves what the second of two would)
-        if (kKeepsEx && (hit1 | hit2)) g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
+        hit_processed = (hit1 | hit2) && !PZ_ABLATE_SKIP(128);
     }
+    // :331-332 -- predicted again after a processed collision (one evaluation after both collisions leaves what
+    // the second of two would).  Nothing in the frame reads it any more: the gather is issued here and taken
+    // by the caller behind its other stores (`after_hit`).
+    if (kKeepsEx) after_hit = lut.landing_issue(hit_processed, g.b.x, g.b.y, g.b.xv, g.b.yv);
     return reward;
 }
 

@@ -7,7 +7,7 @@ frame skipped (cfg.reserved bits, see pz_kernels.hip).  Interleaved rounds in on
 (cdna_hip_programming.md rule 24); prints median / min microseconds per launch from HIP events.
 
     python tools/ablate.py --build      # here (cross-compile)
-    python tools/ablate.py              # on the GPU box
+    python tools/ablate.py [N] [--ai] [--tables]   # on the GPU box (--tables: computer player on the look-up tables)
 """
 import ctypes as C
 import statistics
@@ -51,6 +51,16 @@ def main():
     lib.pz_init.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P]
     lib.pz_reset.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P]
     lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P, P, P]
+    tb = None
+    if "--tables" in sys.argv:
+        lib.pz_flight_table_bytes.restype = C.c_int64
+        lib.pz_flight_table_bytes.argtypes = [C.c_int32]
+        lib.pz_build_flight_tables.argtypes = [P, P, P]
+        t_land = torch.empty(lib.pz_flight_table_bytes(0), dtype=torch.uint8, device=dev)
+        t_hit = torch.empty(lib.pz_flight_table_bytes(1), dtype=torch.uint8, device=dev)
+        assert lib.pz_build_flight_tables(t_land.data_ptr(), t_hit.data_ptr(), stream) == 0
+        tables = _native.PzFlightTables(t_land.data_ptr(), t_hit.data_ptr())
+        tb = C.byref(tables)
     assert lib.pz_init(state.data_ptr(), n, n, C.byref(cfg), stream) == 0
     assert lib.pz_reset(state.data_ptr(), n, n, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(), None, stream) == 0
 
@@ -59,7 +69,7 @@ def main():
         for t in range(steps):
             a = acts[t % 64]
             lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
-                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), None, None, stream)
+                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), None, tb, stream)
 
     run(0, 600)  # desynchronise the games so divergence is realistic
     snapshot = state.clone()
@@ -67,6 +77,9 @@ def main():
     if p2ai:
         variants = {"baseline": 0, "no_frame": 8, "no_landing_A": 32, "no_candidates": 64, "no_landing_B": 128,
                     "no_A_no_B": 160, "no_predictors": 224}
+        if tb is not None:
+            variants.update({"no_predraw": 256, "no_predictors_no_predraw": 224 + 256, "no_decision": 512,
+                             "no_decision_no_predictors_no_predraw": 512 + 256 + 224, "no_obs": 16})
     times = {k: [] for k in variants}
     K = 300
     for rnd in range(7):
