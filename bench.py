@@ -490,7 +490,10 @@ def main():
 
     if rank == 0:
         alg_bytes = BYTES_PER_ENV_STEP * args.num_envs
-        wl = "cfg3" if args.p2_computer else ("cfg5" if args.wrappers else "random_random")
+        wl = (("cfg3" if tables else "cfg3_compute") if args.p2_computer
+              else ("cfg5" if args.wrappers else "random_random"))
+        if args.num_envs != 65536 and wl == "random_random":
+            wl = f"random_random_{args.num_envs}"
         traffic = load_traffic(wl, args.num_envs)
         launch_s = main_res["launch_us"] * 1e-6
         out = {

@@ -72,6 +72,24 @@ def sample_rows(csv_path, out_path, per_kernel=24):
                 w.writerow(row)
 
 
+def stats_by_grid(trace_csv, out_path):
+    """Kernel durations of a --kernel-trace run grouped by (kernel, grid size): one bench run times several batch
+    sizes through the same kernel, which the tool's own --stats table lumps together."""
+    acc = defaultdict(list)
+    with open(trace_csv) as f:
+        for row in csv.DictReader(f):
+            k = short(row["Kernel_Name"])
+            if k.startswith(STEP_KERNELS):
+                acc[(k, int(row["Grid_Size_X"]), int(row["Workgroup_Size_X"]))].append(
+                    int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    with open(out_path, "w", newline="") as g:
+        w = csv.writer(g)
+        w.writerow(["Kernel", "Grid_Size_X", "Workgroup_Size_X", "Games", "Calls", "AverageNs", "MedianNs", "MinNs", "MaxNs"])
+        for (k, grid, wg), v in sorted(acc.items()):
+            v.sort()
+            w.writerow([k, grid, wg, grid // wg * 64, len(v), round(sum(v) / len(v), 1), v[len(v) // 2], v[0], v[-1]])
+
+
 def find(run_dir, suffix):
     hits = sorted(Path(run_dir).rglob(f"*{suffix}"))
     return hits[0] if hits else None
@@ -88,6 +106,9 @@ def main():
         stats = find(run, "_kernel_stats.csv")
         if stats is not None:
             shutil.copy(stats, dst / f"{tag}_{name}_kernel_stats.csv")
+            tr = find(run, "_kernel_trace.csv")
+            if tr is not None:
+                stats_by_grid(tr, dst / f"{tag}_{name}_step_kernels_by_grid.csv")
         cc = find(run, "_counter_collection.csv")
         if cc is None:
             continue

@@ -26,7 +26,7 @@ run() {  # name, rocprof args..., -- , program args
     local name=$1
     shift
     echo "== $name" | tee -a "$OUT/log.txt"
-    rocprofv3 -d "$OUT/$name" -o run "$@" > "$OUT/$name.log" 2>&1 || { echo "rocprofv3 failed: $name (see $OUT/$name.log)" | tee -a "$OUT/log.txt"; tail -5 "$OUT/$name.log"; return 1; }
+    rocprofv3 -d "$OUT/$name" -o run -f csv "$@" > "$OUT/$name.log" 2>&1 || { echo "rocprofv3 failed: $name (see $OUT/$name.log)" | tee -a "$OUT/log.txt"; tail -5 "$OUT/$name.log"; return 1; }
 }
 
 pmc_set() {  # prefix, bench args...
