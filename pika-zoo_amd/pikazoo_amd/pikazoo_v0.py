@@ -6,7 +6,7 @@
 ``env(**kwargs)`` builds the batched MI355X environment (:class:`pikazoo_amd.env.raw_env`); the keyword
 arguments of the reference (``winning_score``, ``serve``, ``is_player1_computer``, ``is_player2_computer``,
 ``render_mode``) keep their meaning, the batched ones (``num_envs``, ``device``, ``seed``, ``env_id_base``,
-``auto_reset``, ``validate_actions``, ``scalar_api``) are documented on the class.
+``auto_reset``, ``validate_actions``, ``scalar_api``, ``flight_tables``) are documented on the class.
 """
 from . import env as _batched
 
