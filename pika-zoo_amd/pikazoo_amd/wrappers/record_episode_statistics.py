@@ -10,7 +10,7 @@ the rewards as seen at the wrapper's position in the stack (inside or outside th
 Numerics: directly on the env the sums are exact int32.  Above a float reward wrapper the kernel adds float32
 rewards in float32, where the reference adds Python floats (float64, record_episode_statistics.py:31): the two
 agree within 2e-4 over the reference fixtures' episodes (tests/test_gpu_parity.py) and drift apart slowly with the
-episode length; the CPU oracle does the same float32 adds, so HIP vs oracle is bit-exact.
+episode length.
 """
 from __future__ import annotations
 
