@@ -209,6 +209,37 @@ int pz_step_many(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg
 int pz_random_actions(int32_t *act_p1, int32_t *act_p2, int64_t n, int64_t env_id_base,
                       uint64_t action_seed, uint64_t t, int32_t n_actions, void *stream);
 
+/* ---- raw_env.render, render_mode="rgb_array" : pikazoo_env.py:250-384 ------------------------
+ * The frame of game lanes[j] (lanes == NULL: game j) for j < m, drawn from the state alone, in the order of
+ * raw_env.draw (:250-255): background (draw_background :296-325, composed once by the host into `background`,
+ * RGBA8 [304][432]) -> players and their shadows (draw_player :257-278: sprite
+ * get_frame_number_for_player_animated_sprite(state, frame_number) :46-68, mirrored by the diving rules :263-264,
+ * centred on (x, y); shadows centred on (x, 273)) -> ball (draw_ball :280-290: ball[rotation] with
+ * rotation = fine_rotation // 10 physics.py:388, shadow, and on a power hit the hyper ball / trail at the two
+ * previous positions) -> score boards (:327-336).  Sprites are RGBA8 (R | G<<8 | B<<16 | A<<24) in `atlas`,
+ * described by `sprites[PZ_SPRITE_COUNT]` (device memory); blits use pygame's per-pixel-alpha rule
+ * dC = (((sC - dC) * sA + sC) >> 8) + dC.  NOT drawn: clouds and waves (they animate from the env RNG and
+ * state outside the 44 words, cloud_and_wave.py:53-78) and the punch effect (its radius is mutated by the
+ * reference's render itself, :292-293).  frames: uint8 [m][304][432][3].  Nothing is written to `state`. */
+#define PZ_FRAME_WIDTH 432
+#define PZ_FRAME_HEIGHT 304
+enum pz_sprite_id {
+    PZ_SPRITE_PIKACHU = 0,        /* 28: pikachu_<state>_<frame>.png in the order of get_all_image :445-474 */
+    PZ_SPRITE_BALL = 28,          /* 6: ball_0..4, ball_hyper (the tuple `self.ball`, :395-402) */
+    PZ_SPRITE_BALL_HYPER = 33,
+    PZ_SPRITE_BALL_TRAIL = 34,
+    PZ_SPRITE_SHADOW = 35,
+    PZ_SPRITE_NUMBER = 36,        /* 10: number_0..9 */
+    PZ_SPRITE_COUNT = 46
+};
+typedef struct pz_sprite {
+    int32_t offset;   /* first pixel in the atlas */
+    int32_t width, height;
+} pz_sprite;
+int pz_render(const int32_t *state, int64_t n, int64_t stride, const int32_t *lanes, int64_t m,
+              const uint32_t *atlas, const pz_sprite *sprites, const uint32_t *background,
+              uint8_t *frames, void *stream);
+
 /* ---- self-test hook ------------------------------------------------------------------------
  * The computer player's flight predictors (calculate_expected_landing_point_x_for
  * physics.py:643-686 when full_net != 0, expected_landing_point_x_when_power_hit

@@ -371,9 +371,19 @@ __device__ unsigned long long g_pz_stamps[8192 * 8];
         }                                                                                  \
     } while (0)
 #define PZ_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// the pair kernel: lane 0 of BOTH waves, slot 2 * workgroup + role
+#define PZ_PAIR_STAMP(role, k)                                                             \
+    do {                                                                                   \
+        if (blockIdx.x < 4096 && lane == 0) {                                              \
+            unsigned long long t_;                                                         \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
+            g_pz_stamps[(blockIdx.x * 2 + (role)) * 8 + (k)] = t_;                          \
+        }                                                                                  \
+    } while (0)
 #else
 #define PZ_STAMP(k)
 #define PZ_DRAIN_VMEM()
+#define PZ_PAIR_STAMP(role, k)
 #endif
 
 #ifdef PZ_ABLATE
@@ -744,6 +754,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     Game g{};
     const RngId id = make_rng_id(a.cfg, live ? i : 0);
     const FlightLut lut = make_lut(a.tables);
+    PZ_PAIR_STAMP(ROLE, 0);
     const int a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.voff, 0, 0);
     const int a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.voff, 0, 0);
     EpisodeStats st{0u, 0u, 0};
@@ -784,6 +795,8 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     const Game loaded = g;  // what the columns held before the frame
     const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     bool frozen = false;
+    PZ_DRAIN_VMEM();
+    PZ_PAIR_STAMP(ROLE, 1);
 #ifdef PZ_ABLATE
     g_pz_ablate_bits = a.cfg.reserved;  // every lane stores the same value; read by the hooks in pz_physics.hpp
 #endif
@@ -792,6 +805,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
                                                         lane, lut, after_hit);
     const Rewards rw = shape_rewards(a.cfg, g, reward, frozen);
     if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
+    PZ_PAIR_STAMP(ROLE, 2);
 
     if (live) {
         // changed-only write-back of the rarely changing columns, as in store_game_changed
@@ -827,6 +841,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         const unsigned int bits = as_float ? __float_as_uint(ROLE == 0 ? rw.f1 : rw.f2)
                                            : (unsigned int)(ROLE == 0 ? rw.i1 : rw.i2);
         __builtin_amdgcn_raw_buffer_store_b32(bits, rew, io.voff, 0, 0);
+        PZ_PAIR_STAMP(ROLE, 3);
         const Player& me = ROLE == 0 ? g.p1 : g.p2;
         const Player& opp = ROLE == 0 ? g.p2 : g.p1;
         if (a.cfg.normalize_obs)
@@ -835,7 +850,11 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
             stage_one_obs_t<false>(me, opp, g.b, lds_obs[ROLE], lane);
     }
     __syncthreads();
+    PZ_PAIR_STAMP(ROLE, 4);
     flush_rows(lds_obs[ROLE], ROLE == 0 ? a.obs_p1 : a.obs_p2, n32 * kRowBytes, lane);
+    PZ_PAIR_STAMP(ROLE, 5);
+    PZ_DRAIN_VMEM();
+    PZ_PAIR_STAMP(ROLE, 6);
     // last: after a ball-player collision the value comes from a table gather issued at the end of the frame
     if (kKeepsEx) {
         const int ex = lut.landing_finish(after_hit, g.b.x, g.b.y, g.b.xv, g.b.yv, g.b.ex);
@@ -966,6 +985,97 @@ __global__ __launch_bounds__(256) void build_power_hit_table_kernel(uint16_t* ta
         v = (uint16_t)predict_landing_x_iterative<false>(x, y, sxv, ayv * ydir * 2);  // :845
     }
     table[t] = v;
+}
+
+// ---- rgb_array frames from the state (pz_render; raw_env.render pikazoo_env.py:250-384) -------------------------
+// One thread per four horizontally adjacent pixels (12 output bytes = three dwords; a wave writes 768 contiguous
+// bytes), grid = (pixel groups, frames).  The draw list of a frame is a handful of blits derived from wave-uniform
+// state words, so every thread walks the same short list and tests its pixels against each rectangle.
+struct Blit {
+    int sprite, x0, y0, flip;
+};
+
+__device__ __forceinline__ uint32_t blend_over(uint32_t dst, uint32_t src)
+{
+    // pygame's per-pixel-alpha blit onto an opaque surface: dC = (((sC - dC) * sA + sC) >> 8) + dC, skipped for sA == 0
+    const int a = (int)(src >> 24);
+    if (a == 0) return dst;
+    uint32_t out = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int sc = (int)((src >> (8 * c)) & 0xFFu), dc = (int)((dst >> (8 * c)) & 0xFFu);
+        const int v = (((sc - dc) * a + sc) >> 8) + dc;
+        out |= ((uint32_t)v & 0xFFu) << (8 * c);
+    }
+    return out;
+}
+
+__global__ __launch_bounds__(256) void render_kernel(const int32_t* __restrict__ state, int64_t n, int64_t stride,
+                                                     const int32_t* __restrict__ lanes, const uint32_t* __restrict__ atlas,
+                                                     const pz_sprite* __restrict__ sprites,
+                                                     const uint32_t* __restrict__ background, uint8_t* __restrict__ frames)
+{
+    constexpr int kGroupsPerRow = PZ_FRAME_WIDTH / 4;
+    const int64_t game = lanes != nullptr ? (int64_t)lanes[blockIdx.y] : (int64_t)blockIdx.y;  // wave-uniform
+    const int g = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (g >= kGroupsPerRow * PZ_FRAME_HEIGHT || game < 0 || game >= n) return;
+    const int row = g / kGroupsPerRow, col = (g - row * kGroupsPerRow) * 4;
+    auto word = [&](int f) { return state[(int64_t)f * stride + game]; };
+
+    // the draw list, in the order of raw_env.draw (:250-255): twelve fixed slots (sprite < 0: not drawn), so that the
+    // list stays in registers
+    Blit list[12];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {  // draw_player :257-275
+        const int c0 = p * PZ_P_WORDS;
+        const int st = word(c0 + PZ_P_STATE), fr = word(c0 + PZ_P_FRAME_NUMBER), dive = word(c0 + PZ_P_DIVING_DIRECTION);
+        const int idx = st < 4 ? 5 * st + fr : (st == 4 ? 17 + fr : 18 + 5 * (st - 5) + fr);  // :63-68
+        const bool diving = st == 3 || st == 4;
+        const bool flip = p == 0 ? (diving && dive == -1) : !(diving && dive == 1);  // :263-264
+        list[p] = Blit{PZ_SPRITE_PIKACHU + min(max(idx, 0), 27), word(c0 + PZ_P_X), word(c0 + PZ_P_Y), flip ? 3 : 1};
+    }
+    list[2] = Blit{PZ_SPRITE_SHADOW, word(PZ_P_X), 273, 1};                     // :277-278
+    list[3] = Blit{PZ_SPRITE_SHADOW, word(PZ_P_WORDS + PZ_P_X), 273, 1};
+    const int rotation = min(max(word(PZ_B_FINE_ROTATION) / 10, 0), 5);         // physics.py:388
+    list[4] = Blit{PZ_SPRITE_BALL + rotation, word(PZ_B_X), word(PZ_B_Y), 1};   // draw_ball :282-290
+    list[5] = Blit{PZ_SPRITE_SHADOW, word(PZ_B_X), 273, 1};
+    const bool power = word(PZ_B_IS_POWER_HIT) != 0;
+    list[6] = Blit{power ? PZ_SPRITE_BALL_HYPER : -1, word(PZ_B_PREVIOUS_X), word(PZ_B_PREVIOUS_Y), 1};
+    list[7] = Blit{power ? PZ_SPRITE_BALL_TRAIL : -1, word(PZ_B_PREVIOUS_PREVIOUS_X), word(PZ_B_PREVIOUS_PREVIOUS_Y), 1};
+    const int s1 = word(PZ_E_SCORE_P1), s2 = word(PZ_E_SCORE_P2);                // :327-336 (top-left blits)
+    list[8] = Blit{s1 >= 10 ? PZ_SPRITE_NUMBER + 1 : -1, 14, 10, 0};
+    list[9] = Blit{PZ_SPRITE_NUMBER + s1 % 10, 14 + 32, 10, 0};
+    list[10] = Blit{s2 >= 10 ? PZ_SPRITE_NUMBER + 1 : -1, PZ_FRAME_WIDTH - 32 - 32 - 14, 10, 0};
+    list[11] = Blit{PZ_SPRITE_NUMBER + s2 % 10, PZ_FRAME_WIDTH - 32 - 32 - 14 + 32, 10, 0};
+
+    uint32_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) px[k] = background[row * PZ_FRAME_WIDTH + col + k];
+#pragma unroll
+    for (int b = 0; b < 12; ++b) {
+        if (list[b].sprite < 0) continue;
+        const pz_sprite sp = sprites[list[b].sprite];
+        const bool centred = (list[b].flip & 1) != 0, mirrored = (list[b].flip & 2) != 0;
+        const int x0 = centred ? list[b].x0 - sp.width / 2 : list[b].x0;    // blit_center :40-43
+        const int y0 = centred ? list[b].y0 - sp.height / 2 : list[b].y0;
+        const int sy = row - y0;
+        if ((unsigned)sy >= (unsigned)sp.height || col + 3 < x0 || col >= x0 + sp.width) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int sx = col + k - x0;
+            if ((unsigned)sx < (unsigned)sp.width)
+                px[k] = blend_over(px[k], atlas[sp.offset + sy * sp.width + (mirrored ? sp.width - 1 - sx : sx)]);
+        }
+    }
+    // 4 x RGB = 12 bytes = 3 dwords
+    const uint32_t r0 = (px[0] & 0xFFFFFFu) | (px[1] << 24);
+    const uint32_t r1 = ((px[1] >> 8) & 0xFFFFu) | (px[2] << 16);
+    const uint32_t r2 = ((px[2] >> 16) & 0xFFu) | (px[3] << 8);
+    uint32_t* out = reinterpret_cast<uint32_t*>(frames + ((int64_t)blockIdx.y * PZ_FRAME_HEIGHT + row) * (PZ_FRAME_WIDTH * 3) +
+                                                col * 3);
+    out[0] = r0;
+    out[1] = r1;
+    out[2] = r2;
 }
 
 // Self-test hook: both forms of the flight predictor on caller-supplied ball states.
@@ -1224,6 +1334,19 @@ int pz_random_actions(int32_t* act_p1, int32_t* act_p2, int64_t n, int64_t env_i
     if (n == 0) return PZ_OK;
     hipLaunchKernelGGL(random_actions_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, act_p1,
                        act_p2, n, env_id_base, action_seed, t, (uint32_t)n_actions);
+    return (int)hipGetLastError();
+}
+
+int pz_render(const int32_t* state, int64_t n, int64_t stride, const int32_t* lanes, int64_t m, const uint32_t* atlas,
+              const pz_sprite* sprites, const uint32_t* background, uint8_t* frames, void* stream)
+{
+    if (!state || !atlas || !sprites || !background || !frames) return PZ_E_NULL;
+    if (n < 0 || stride < n || stride > kMaxLanesPerLaunch || m < 0 || m > 65535) return PZ_E_SIZE;
+    if ((lanes == nullptr && m > n) || (reinterpret_cast<uintptr_t>(frames) & 3u) != 0) return lanes == nullptr && m > n ? PZ_E_SIZE : PZ_E_ALIGN;
+    if (m == 0) return PZ_OK;
+    const dim3 grid(blocks_for((int64_t)(PZ_FRAME_WIDTH / 4) * PZ_FRAME_HEIGHT, 256), (unsigned int)m);
+    hipLaunchKernelGGL(render_kernel, grid, dim3(256), 0, (hipStream_t)stream, state, n, stride, lanes, atlas, sprites,
+                       background, frames);
     return (int)hipGetLastError();
 }
 

@@ -76,6 +76,7 @@ _SIGNATURES = {
                                _P, _P, _P]),
     "pz_random_actions": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _P]),
     "pz_selftest_predictor": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
+    "pz_render": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

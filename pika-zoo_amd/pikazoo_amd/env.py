@@ -81,7 +81,10 @@ class raw_env:
 
     Reference kwargs (pikazoo_env.py:79-86): ``winning_score``, ``serve`` in {"winner",
     "alternate", "random"}, ``is_player1_computer``, ``is_player2_computer``, ``render_mode``
-    (must be None: rendering is out of scope of the step path).
+    (None or "rgb_array": :meth:`render` draws frames on the GPU from the state; the sprites come from
+    ``sprite_dir`` -- the reference's ``pikazoo/env/img`` directory, found by itself when the reference
+    package is installed -- or from a ready ``sprites`` set, see :mod:`pikazoo_amd.render`; there is no
+    "human" window).
 
     Batched-env kwargs: ``num_envs``; ``device`` (a CUDA/HIP device); ``seed`` (Philox key of
     the env RNG stream -- the reference seeds PCG64 from OS entropy and ignores ``reset(seed)``,
@@ -99,15 +102,16 @@ class raw_env:
     ``clone()`` what must outlive it.
     """
 
-    metadata = {"render_modes": [], "name": "pikazoo_v0", "render_fps": 20, "is_parallelizable": True}
+    metadata = {"render_modes": ["rgb_array"], "name": "pikazoo_v0", "render_fps": 20, "is_parallelizable": True}
 
     def __init__(self, winning_score: int = 15, serve: str = "winner", is_player1_computer: bool = False,
                  is_player2_computer: bool = False, render_mode=None, *, num_envs: int = 1,
                  device="cuda", seed: int = 0, env_id_base: int = 0, auto_reset: Optional[bool] = None,
-                 validate_actions: bool = True, scalar_api: bool = False, flight_tables: bool = True):
+                 validate_actions: bool = True, scalar_api: bool = False, flight_tables: bool = True,
+                 sprite_dir=None, sprites=None):
         assert serve in ("winner", "alternate", "random")  # pikazoo_env.py:104
-        if render_mode is not None:
-            raise NotImplementedError("rendering is outside the step path; use render_mode=None")
+        if render_mode not in (None, "rgb_array"):
+            raise NotImplementedError('render_mode must be None or "rgb_array" (no "human" window on a GPU batch)')
         if int(winning_score) < 1:
             raise ValueError("winning_score must be >= 1")
         if int(num_envs) < 1:
@@ -131,7 +135,9 @@ class raw_env:
         self.num_envs = int(num_envs)
         self.winning_score = int(winning_score)
         self.serve = serve
-        self.render_mode = None
+        self.render_mode = render_mode
+        self._sprites = sprites
+        self._sprite_dir = sprite_dir
         self.auto_reset = bool(auto_reset)
         self.validate_actions = bool(validate_actions)
         self.scalar_api = bool(scalar_api)
@@ -587,8 +593,36 @@ class raw_env:
         self.steps_done = int(sd["steps_done"])
         self.agents = self.possible_agents[:]
 
-    def render(self):
-        raise NotImplementedError("rendering is outside the step path (render_mode=None only)")
+    def render(self, lanes=None, out: Optional[torch.Tensor] = None):
+        """``rgb_array`` frames of the current state (pikazoo_env.py:250-384, drawn by ``pz_render``):
+        ``uint8[m, 304, 432, 3]`` for the games `lanes` (an int sequence / tensor; default: every game, as long
+        as that stays below 1 GiB); ``scalar_api`` envs get the reference's ``[304, 432, 3]`` numpy array.
+        Clouds, waves and the punch effect are not drawn (they are not a function of the game state)."""
+        if self.render_mode is None:  # the reference warns and returns None (pikazoo_env.py:355-357)
+            import warnings
+
+            warnings.warn("You are calling render method without specifying any render mode.")
+            return None
+        from . import render as _render
+
+        if self._sprites is None:
+            d = self._sprite_dir or _render.default_image_dir()
+            if d is None:
+                raise FileNotFoundError(
+                    "render needs the reference's sprites: pass sprite_dir=<.../pikazoo/env/img> (or sprites=) to the "
+                    "env; they are not redistributed with this package")
+            self._sprites = _render.load_sprites(d, self.device)
+        lane_t = None
+        if lanes is not None:
+            lane_t = torch.as_tensor(lanes, device=self.device).reshape(-1).to(torch.int32).contiguous()
+            if lane_t.numel() and (int(lane_t.min()) < 0 or int(lane_t.max()) >= self.num_envs):
+                raise IndexError("lane out of range")
+        elif self.num_envs * _render.HEIGHT * _render.WIDTH * 3 > (1 << 30):
+            raise ValueError(f"rendering all {self.num_envs} games needs more than 1 GiB: pass lanes=")
+        with torch.cuda.device(self.device):
+            frames = _render.render(self._lib, self.state, self.num_envs, self._stride, self._sprites, lane_t,
+                                    self._stream(), out)
+        return frames[0].cpu().numpy() if self.scalar_api else frames
 
     def close(self):
         pass

@@ -39,6 +39,11 @@ def main():
     lib.pz_reset.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P]
     lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P, P, P]
     lib.pz_debug_read_stamps.argtypes = [P, C.c_int64]
+    tb = None
+    if "--tables" in args:
+        lib.pz_flight_table_bytes.restype = C.c_int64
+        lib.pz_flight_table_bytes.argtypes = [C.c_int32]
+        lib.pz_build_flight_tables.argtypes = [P, P, P]
     dev = torch.device("cuda:0")
     cfg = _native.PzConfig()
     cfg.winning_score, cfg.auto_reset, cfg.seed, cfg.p2_computer = 15, 1, 0, int(ai)
@@ -48,6 +53,12 @@ def main():
     term = torch.zeros(n, dtype=torch.uint8, device=dev)
     acts = torch.randint(0, 18, (64, 2, n), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    if "--tables" in args:
+        t_land = torch.empty(lib.pz_flight_table_bytes(0), dtype=torch.uint8, device=dev)
+        t_hit = torch.empty(lib.pz_flight_table_bytes(1), dtype=torch.uint8, device=dev)
+        assert lib.pz_build_flight_tables(t_land.data_ptr(), t_hit.data_ptr(), stream) == 0
+        tables = _native.PzFlightTables(t_land.data_ptr(), t_hit.data_ptr())
+        tb = C.byref(tables)
     lib.pz_init(state.data_ptr(), n, n, C.byref(cfg), stream)
     lib.pz_reset(state.data_ptr(), n, n, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(), None, stream)
 
@@ -55,11 +66,12 @@ def main():
         for t in range(steps):
             a = acts[t % 64]
             lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
-                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), None, None, stream)
+                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), None, tb, stream)
 
     run(800)
     torch.cuda.synchronize()
-    waves = min((n + 63) // 64, 8192)
+    pair = n < 393216 and (not ai or "--tables" in args)  # the two-wave launch: slot = 2 * workgroup + role
+    waves = min((n + 63) // 64 * (2 if pair else 1), 8192)
     buf = np.zeros(8192 * 8, np.uint64)
     names = ["start", "loaded", "computed", "state stores issued", "obs staged", "obs stores issued", "all stores done"]
     for rep in range(3):
@@ -75,6 +87,11 @@ def main():
             print(f"  {nm:22s} min {c.min():6.2f}  median {np.median(c):6.2f}  p95 {np.percentile(c, 95):6.2f}  max {c.max():6.2f}")
         d = np.diff(rel, axis=1)
         print("  per-wave phase durations (median): " + ", ".join(f"{names[k + 1]} {np.median(d[:, k]):.2f}" for k in range(6)))
+        if pair:
+            for role in (0, 1):
+                dr = d[role::2]
+                print(f"    wave of player {role + 1} (median): " + ", ".join(f"{names[k + 1]} {np.median(dr[:, k]):.2f}" for k in range(6)))
+            continue
         fb = np.zeros(8192 * 8, np.uint64)
         lib.pz_debug_read_frame_stamps.argtypes = [P, C.c_int64]
         assert lib.pz_debug_read_frame_stamps(fb.ctypes.data, 8192 * 8) == 0
