@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PZ_ABI_VERSION 3
+#define PZ_ABI_VERSION 4
 #define PZ_STATE_WORDS 44
 #define PZ_OBS_DIM 35
 
@@ -144,7 +144,7 @@ int pz_init(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg, voi
  * flags and per-round fields are re-initialised, carry-over fields are kept, draws continue
  * from the lane's counter.  Observations of ALL lanes are written (obs_* may be NULL). */
 int pz_reset(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
-             const uint8_t *mask, int32_t *obs_p1, int32_t *obs_p2, int32_t *episode_stats,
+             const uint8_t *mask, int32_t *obs_p1, int32_t *obs_p2, void *episode_stats,
              void *stream);
 
 /* ---- raw_env._get_obs : pikazoo_env.py:576-624 (normalize != 0: NormalizeObservation on top) */
@@ -156,16 +156,18 @@ int pz_observe(const int32_t *state, int64_t n, int64_t stride, int32_t normaliz
  * rew_p1/rew_p2: int32[n] (+1/-1/0), or float32[n] when cfg->ballpos_reward or cfg->normal_state_mode.
  * terminated:    uint8[n] = game_ended after this frame (terminations of both agents);
  *                truncations are always False in the reference (:234) and are not written.
- * episode_stats: NULL, or 4-byte words [3][stride] = episode return of player 1, of player 2
- *                (typed like the rewards) and episode length -- what RecordEpisodeStatistics
- *                reports as infos[agent]["episode"] = {"r", "l"} on a terminal frame; zeroed by
- *                reset (pz_reset or the in-place auto reset). Used when cfg->episode_stats_mode != 0.
+ * episode_stats: NULL, or 20 * stride bytes (8-byte aligned): double[2][stride] = running episode return of
+ *                player 1 / player 2, then int32[stride] = episode length -- what RecordEpisodeStatistics
+ *                reports as infos[agent]["episode"] = {"r", "l"} on a terminal frame; zeroed by reset (pz_reset
+ *                or the in-place auto reset). Used when cfg->episode_stats_mode != 0.  The returns are summed
+ *                in float64 like the reference's Python floats (record_episode_statistics.py:31); float32
+ *                rewards are widened before the add.
  * With cfg->normalize_obs the observation buffers receive float32 bit patterns.
  * tables: NULL, or the flight look-up tables above (used when a player is the computer). */
 int pz_step(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
             const int32_t *act_p1, const int32_t *act_p2,
             int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
-            uint8_t *terminated, int32_t *episode_stats, const pz_flight_tables *tables,
+            uint8_t *terminated, void *episode_stats, const pz_flight_tables *tables,
             void *stream);
 
 /* ---- the same frame with the uniform random policy drawn on device ----------------------
@@ -178,7 +180,7 @@ int pz_step(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
 int pz_step_random(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
                    uint64_t action_seed, uint64_t t0, int32_t k,
                    int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
-                   uint8_t *terminated, int32_t *episode_stats, int64_t *episodes_done,
+                   uint8_t *terminated, void *episode_stats, int64_t *episodes_done,
                    const pz_flight_tables *tables, void *stream);
 
 /* ---- a k-frame rollout of the random policy with EVERY frame's outputs kept ---------------
@@ -192,7 +194,7 @@ int pz_step_random(int32_t *state, int64_t n, int64_t stride, const pz_config *c
 int pz_rollout_random(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
                       uint64_t action_seed, uint64_t t0, int32_t k, int32_t *actions,
                       int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
-                      uint8_t *terminated, int32_t *episode_stats, int64_t *episodes_done,
+                      uint8_t *terminated, void *episode_stats, int64_t *episodes_done,
                       const pz_flight_tables *tables, void *stream);
 
 /* ---- k frames of GIVEN actions in one launch, every frame's outputs kept -------------------
@@ -202,7 +204,7 @@ int pz_rollout_random(int32_t *state, int64_t n, int64_t stride, const pz_config
 int pz_step_many(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
                  const int32_t *actions, int32_t k,
                  int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
-                 uint8_t *terminated, int32_t *episode_stats, int64_t *episodes_done,
+                 uint8_t *terminated, void *episode_stats, int64_t *episodes_done,
                  const pz_flight_tables *tables, void *stream);
 
 /* ---- the policy stream alone (for hosts that want the actions in HBM) -------------------- */

@@ -754,27 +754,27 @@ static void store_game(const Game *g, int32_t *s, int64_t stride)
 
 /* ---- raw_env.step: pikazoo_env.py:175-240, one game -------------------------------------- */
 typedef struct {
-    int32_t *ret1, *ret2, *len; /* this lane's episode-statistics words (NULL = off) */
+    double *ret1, *ret2; /* this lane's running episode returns (NULL = off) ... */
+    int32_t *len;        /* ... and episode length */
 } Stats;
 
 static int rewards_are_float(const pzo_config *cfg) { return cfg->ballpos_reward || cfg->normal_state_mode; }
 
 static void stats_zero(const Stats *st)
 {
-    if (st && st->len) { *st->ret1 = 0; *st->ret2 = 0; *st->len = 0; } /* 0 == 0.0f bit pattern */
+    if (st && st->len) { *st->ret1 = 0.0; *st->ret2 = 0.0; *st->len = 0; }
 }
 
 static void stats_add(const Stats *st, const pzo_config *cfg, float f1, float f2, int i1, int i2, int as_float)
 {
     if (!st || !st->len) return;
     (void)cfg;
+    /* record_episode_statistics.py:31 sums Python floats: float64.  The fused wrappers' rewards are float32
+     * (f1, f2), widened here; the env's own rewards are the integers +-1 / 0. */
     if (as_float) {
-        float a, b;
-        memcpy(&a, st->ret1, 4); memcpy(&b, st->ret2, 4);
-        a += f1; b += f2;
-        memcpy(st->ret1, &a, 4); memcpy(st->ret2, &b, 4);
+        *st->ret1 += (double)f1; *st->ret2 += (double)f2;
     } else {
-        *st->ret1 += i1; *st->ret2 += i2;
+        *st->ret1 += (double)i1; *st->ret2 += (double)i2;
     }
     *st->len += 1;
 }
@@ -878,19 +878,20 @@ void pzo_init(int32_t *state, int64_t n, int64_t stride, const pzo_config *cfg)
     }
 }
 
-static Stats lane_stats(int32_t *episode_stats, int64_t stride, int64_t i)
+/* episode_stats buffer: double[2][stride] returns, then int32[stride] lengths (20 * stride bytes) */
+static Stats lane_stats(void *episode_stats, int64_t stride, int64_t i)
 {
     Stats st = {0, 0, 0};
     if (episode_stats) {
-        st.ret1 = episode_stats + i;
-        st.ret2 = episode_stats + stride + i;
-        st.len = episode_stats + 2 * stride + i;
+        st.ret1 = (double *)episode_stats + i;
+        st.ret2 = (double *)episode_stats + stride + i;
+        st.len = (int32_t *)((double *)episode_stats + 2 * stride) + i;
     }
     return st;
 }
 
 void pzo_reset(int32_t *state, int64_t n, int64_t stride, const pzo_config *cfg,
-               const uint8_t *mask, int32_t *obs_p1, int32_t *obs_p2, int32_t *episode_stats)
+               const uint8_t *mask, int32_t *obs_p1, int32_t *obs_p2, void *episode_stats)
 {
     for (int64_t i = 0; i < n; ++i) {
         Game g;
@@ -919,7 +920,7 @@ void pzo_observe(const int32_t *state, int64_t n, int64_t stride, int32_t normal
 
 static void step_range(int32_t *state, int64_t lo, int64_t hi, int64_t stride, const pzo_config *cfg,
                        const int32_t *act_p1, const int32_t *act_p2, int32_t *obs_p1, int32_t *obs_p2,
-                       void *rew_p1, void *rew_p2, uint8_t *terminated, int32_t *episode_stats)
+                       void *rew_p1, void *rew_p2, uint8_t *terminated, void *episode_stats)
 {
     for (int64_t i = lo; i < hi; ++i) {
         Game g;
@@ -933,7 +934,7 @@ static void step_range(int32_t *state, int64_t lo, int64_t hi, int64_t stride, c
 
 void pzo_step(int32_t *state, int64_t n, int64_t stride, const pzo_config *cfg,
               const int32_t *act_p1, const int32_t *act_p2, int32_t *obs_p1, int32_t *obs_p2,
-              void *rew_p1, void *rew_p2, uint8_t *terminated, int32_t *episode_stats, int nthreads)
+              void *rew_p1, void *rew_p2, uint8_t *terminated, void *episode_stats, int nthreads)
 {
     if (nthreads <= 1) {
         step_range(state, 0, n, stride, cfg, act_p1, act_p2, obs_p1, obs_p2, rew_p1, rew_p2, terminated,
@@ -951,7 +952,7 @@ void pzo_step(int32_t *state, int64_t n, int64_t stride, const pzo_config *cfg,
 void pzo_rollout_random(int32_t *state, int64_t n, int64_t stride, const pzo_config *cfg,
                         uint64_t action_seed, uint64_t t0, int32_t k,
                         int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
-                        uint8_t *terminated, int32_t *episode_stats, int64_t *episodes_finished, int nthreads)
+                        uint8_t *terminated, void *episode_stats, int64_t *episodes_finished, int nthreads)
 {
     if (nthreads < 1)
         nthreads = 1;

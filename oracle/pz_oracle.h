@@ -85,22 +85,22 @@ void pzo_init(int32_t *state, int64_t n, int64_t stride, const pzo_config *cfg);
 /* raw_env.reset (pikazoo_env.py:149-173) on lanes with mask[i]!=0 (mask NULL = all);
  * observations written for every lane (obs may be NULL). */
 void pzo_reset(int32_t *state, int64_t n, int64_t stride, const pzo_config *cfg,
-               const uint8_t *mask, int32_t *obs_p1, int32_t *obs_p2, int32_t *episode_stats);
+               const uint8_t *mask, int32_t *obs_p1, int32_t *obs_p2, void *episode_stats);
 /* raw_env.step (pikazoo_env.py:175-240). rew_* are int32[n], or float32[n] when a reward
  * wrapper is fused (ballpos_reward or normal_state_mode); obs_* are int32[n][35], or float32
- * bit patterns when normalize_obs.  episode_stats (may be NULL): 4-byte words [3][stride] =
- * episode return of player 1, of player 2 (same type as the rewards), episode length.
+ * bit patterns when normalize_obs.  episode_stats (may be NULL): double[2][stride] + int32[stride] =
+ * episode return of player 1, of player 2 (float64 sums, record_episode_statistics.py:31), episode length.
  * nthreads<=1: scalar loop; >1: static lane partition (OpenMP). */
 void pzo_step(int32_t *state, int64_t n, int64_t stride, const pzo_config *cfg,
               const int32_t *act_p1, const int32_t *act_p2,
               int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
-              uint8_t *terminated, int32_t *episode_stats, int nthreads);
+              uint8_t *terminated, void *episode_stats, int nthreads);
 /* k steps of the random policy (actions from pzo_random_actions at t0..t0+k-1); outputs of
  * the last step are kept. Returns nothing; used for long digest runs and the CPU baseline. */
 void pzo_rollout_random(int32_t *state, int64_t n, int64_t stride, const pzo_config *cfg,
                         uint64_t action_seed, uint64_t t0, int32_t k,
                         int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
-                        uint8_t *terminated, int32_t *episode_stats, int64_t *episodes_finished,
+                        uint8_t *terminated, void *episode_stats, int64_t *episodes_finished,
                         int nthreads);
 /* _get_obs (pikazoo_env.py:576-624) from the state, no mutation */
 void pzo_observe(const int32_t *state, int64_t n, int64_t stride, int32_t normalize,

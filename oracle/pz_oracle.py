@@ -199,8 +199,8 @@ class OracleEnv:
         rdt = np.float32 if self.float_rewards else np.int32
         self.rew = [np.zeros(self.n, rdt) for _ in range(2)]
         self.term = np.zeros(self.n, np.uint8)
-        # RecordEpisodeStatistics words: [return p1, return p2, length] x n (returns typed like the rewards)
-        self.stats = np.zeros((3, self.n), np.int32) if cfg.episode_stats_mode else None
+        # RecordEpisodeStatistics buffer: float64[2][n] running returns, then int32[n] lengths (20 n bytes)
+        self.stats = np.zeros(20 * self.n, np.uint8) if cfg.episode_stats_mode else None
         lib().pzo_init(_p(self.state), self.n, self.n, C.byref(cfg))
 
     def _stats_ptr(self):
@@ -208,12 +208,12 @@ class OracleEnv:
 
     @property
     def episode_returns(self):
-        r = self.stats[:2]
-        return r.view(np.float32) if self.float_rewards else r
+        """float64 [2, n]: running returns of player 1 / player 2 (view of the statistics buffer)."""
+        return self.stats[:16 * self.n].view(np.float64).reshape(2, self.n)
 
     @property
     def episode_lengths(self):
-        return self.stats[2]
+        return self.stats[16 * self.n:].view(np.int32)
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)

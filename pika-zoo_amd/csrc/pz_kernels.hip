@@ -85,7 +85,7 @@ struct StepArgs {
     void* rew_p1;
     void* rew_p2;
     uint8_t* terminated;
-    int32_t* episode_stats;  // [3][stride] words: return p1, return p2, length (nullptr = off)
+    void* episode_stats;  // double[2][stride] returns + int32[stride] lengths (nullptr = off)
     unsigned long long* episodes_done;
     pz_flight_tables tables;  // device pointers or NULL (pz_flight_tables in the header)
     pz_config cfg;
@@ -440,25 +440,65 @@ __device__ __forceinline__ Rewards shape_rewards(const pz_config& cfg, const Gam
     return r;
 }
 
-// RecordEpisodeStatistics (record_episode_statistics.py:27-40) as three per-game words.
+// RecordEpisodeStatistics (record_episode_statistics.py:27-40): per game the two running returns as float64 -- the
+// reference sums Python floats (:31), and so do we: float32 rewards are widened before the add, the env's own +-1/0
+// sum exactly -- and the episode length.  Buffer layout (pz_step in the header): double[2][stride], int32[stride].
 struct EpisodeStats {
-    uint32_t r1, r2;  // running returns, float32 or int32 bit patterns (typed like the rewards)
+    double r1, r2;
     int len;
 };
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct StatsIO {
+    Rsrc rsrc;
+    uint32_t stride;  // games per row
+    uint32_t lane;    // this lane's game index inside the batch
+    __device__ __forceinline__ double ld_ret(int agent) const
+    {
+        const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8u, (uint32_t)agent * stride * 8u, 0);
+        return __hiloint2double((int)w.y, (int)w.x);
+    }
+    __device__ __forceinline__ void st_ret(int agent, double v) const
+    {
+        const u32x2 w = {(unsigned int)__double2loint(v), (unsigned int)__double2hiint(v)};
+        __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, lane * 8u, (uint32_t)agent * stride * 8u, 0);
+    }
+    __device__ __forceinline__ int ld_len() const
+    {
+        return (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4u, stride * 16u, 0);
+    }
+    __device__ __forceinline__ void st_len(int v) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned int)v, rsrc, lane * 4u, stride * 16u, 0);
+    }
+    __device__ __forceinline__ void load(EpisodeStats& st) const
+    {
+        st.r1 = ld_ret(0);
+        st.r2 = ld_ret(1);
+        st.len = ld_len();
+    }
+    __device__ __forceinline__ void store(const EpisodeStats& st) const
+    {
+        st_ret(0, st.r1);
+        st_ret(1, st.r2);
+        st_len(st.len);
+    }
+};
+
+// `enabled` false: an empty descriptor (loads return 0, stores are dropped)
+__device__ __forceinline__ StatsIO make_stats_io(const void* episode_stats, bool enabled, int64_t stride, int64_t lane)
+{
+    return StatsIO{make_rsrc(episode_stats, enabled ? (uint32_t)(stride * 20) : 0u), (uint32_t)stride, (uint32_t)lane};
+}
 
 __device__ __forceinline__ void stats_update(EpisodeStats& st, const pz_config& cfg, const Rewards& r, bool was_reset,
                                              bool counted, bool as_float)
 {
-    if (was_reset) st = EpisodeStats{0u, 0u, 0};  // reset() zeroes the sums (:23-25); 0 is 0.0f too
+    if (was_reset) st = EpisodeStats{0.0, 0.0, 0};  // reset() zeroes the sums (:23-25)
     if (!counted) return;
-    const bool raw = cfg.episode_stats_mode == 1;
-    if (as_float) {
-        st.r1 = __float_as_uint(__uint_as_float(st.r1) + (raw ? (float)r.i1 : r.f1));
-        st.r2 = __float_as_uint(__uint_as_float(st.r2) + (raw ? (float)r.i2 : r.f2));
-    } else {
-        st.r1 += (uint32_t)r.i1;
-        st.r2 += (uint32_t)r.i2;
-    }
+    const bool raw = cfg.episode_stats_mode == 1 || !as_float;
+    st.r1 += raw ? (double)r.i1 : (double)r.f1;
+    st.r2 += raw ? (double)r.i2 : (double)r.f2;
     st.len += 1;
 }
 
@@ -616,8 +656,7 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
                      (uint32_t)i * 4u};
     const bool as_float = a.cfg.ballpos_reward != 0 || a.cfg.normal_state_mode != 0;
     const bool with_stats = a.episode_stats != nullptr && a.cfg.episode_stats_mode != 0;  // uniform
-    const StateIO sio{make_rsrc(a.episode_stats, with_stats ? (uint32_t)(a.stride * 12) : 0u),
-                      (uint32_t)a.stride * 4u, (uint32_t)i * 4u};
+    const StatsIO sio = make_stats_io(a.episode_stats, with_stats, a.stride, i);
 
     Game g{};
     const RngId id = make_rng_id(a.cfg, live ? i : 0);
@@ -635,14 +674,10 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
         a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.voff, 0, 0);
         a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.voff, 0, 0);
     }
-    EpisodeStats st{0u, 0u, 0};
+    EpisodeStats st{0.0, 0.0, 0};
     if (live) {
         load_game(g, io);
-        if (with_stats) {
-            st.r1 = (uint32_t)sio.ld(0);
-            st.r2 = (uint32_t)sio.ld(1);
-            st.len = sio.ld(2);
-        }
+        if (with_stats) sio.load(st);
     }
     const Game loaded = g;  // SPARSE: what the columns held before the frame
     PZ_DRAIN_VMEM();
@@ -709,11 +744,7 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
             store_game_changed(g, loaded, io, ex_pending);
         else
             store_game(g, io, ex_pending);
-        if (with_stats) {
-            sio.st(0, (int)st.r1);
-            sio.st(1, (int)st.r2);
-            sio.st(2, st.len);
-        }
+        if (with_stats) sio.store(st);
     }
     if (MODE != kRollout && MODE != kTape) emit_outputs(a, g, rw, as_float, live, i, lane, 0, lds_obs, PZ_SKIP_OBS);
     PZ_STAMP(5);
@@ -747,8 +778,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
                      (uint32_t)i * 4u};
     const bool as_float = a.cfg.ballpos_reward != 0 || a.cfg.normal_state_mode != 0;
     const bool with_stats = ROLE == 0 && a.episode_stats != nullptr && a.cfg.episode_stats_mode != 0;
-    const StateIO sio{make_rsrc(a.episode_stats, with_stats ? (uint32_t)(a.stride * 12) : 0u),
-                      (uint32_t)a.stride * 4u, (uint32_t)i * 4u};
+    const StatsIO sio = make_stats_io(a.episode_stats, with_stats, a.stride, i);
     constexpr int kOwn = ROLE * PZ_P_WORDS, kOther = (1 - ROLE) * PZ_P_WORDS;
 
     Game g{};
@@ -757,7 +787,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     PZ_PAIR_STAMP(ROLE, 0);
     const int a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.voff, 0, 0);
     const int a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.voff, 0, 0);
-    EpisodeStats st{0u, 0u, 0};
+    EpisodeStats st{0.0, 0.0, 0};
     if (live) {
         g.e.round_ended = io.ld(PZ_E_ROUND_ENDED);
         g.e.game_ended = io.ld(PZ_E_GAME_ENDED);
@@ -786,11 +816,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
             other.state = io.ld(kOther + PZ_P_STATE);
             other.dive = io.ld(kOther + PZ_P_DIVING_DIRECTION);
         }
-        if (with_stats) {
-            st.r1 = (uint32_t)sio.ld(0);
-            st.r2 = (uint32_t)sio.ld(1);
-            st.len = sio.ld(2);
-        }
+        if (with_stats) sio.load(st);
     }
     const Game loaded = g;  // what the columns held before the frame
     const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
@@ -823,11 +849,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
             if (g.e.round_ended != loaded.e.round_ended) io.st(PZ_E_ROUND_ENDED, g.e.round_ended);
             if (g.e.game_ended != loaded.e.game_ended) io.st(PZ_E_GAME_ENDED, g.e.game_ended);
             if (g.e.rng != loaded.e.rng) io.st(PZ_E_RNG_DRAW_COUNTER, (int32_t)g.e.rng);
-            if (with_stats) {
-                sio.st(0, (int)st.r1);
-                sio.st(1, (int)st.r2);
-                sio.st(2, st.len);
-            }
+            if (with_stats) sio.store(st);
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, make_rsrc(a.terminated, n32),
                                                  (uint32_t)i, 0, 0);
         } else {
@@ -894,7 +916,7 @@ __global__ __launch_bounds__(kLanes) void init_kernel(int32_t* state, int64_t n,
 
 __global__ __launch_bounds__(kLanes) void reset_kernel(int32_t* state, int64_t n, int64_t stride, const pz_config cfg,
                                                        const uint8_t* mask, int32_t* obs_p1, int32_t* obs_p2,
-                                                       int32_t* episode_stats)
+                                                       void* episode_stats)
 {
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     const int lane = threadIdx.x;
@@ -908,11 +930,8 @@ __global__ __launch_bounds__(kLanes) void reset_kernel(int32_t* state, int64_t n
             const RngId id = make_rng_id(cfg, i);
             reset_game(g, cfg, id);
             store_game(g, io);
-            if (episode_stats != nullptr) {  // RecordEpisodeStatistics.reset (:23-25)
-                episode_stats[i] = 0;
-                episode_stats[stride + i] = 0;
-                episode_stats[2 * stride + i] = 0;
-            }
+            if (episode_stats != nullptr)  // RecordEpisodeStatistics.reset (:23-25)
+                make_stats_io(episode_stats, true, stride, i).store(EpisodeStats{0.0, 0.0, 0});
         }
         stage_obs(g, lds_obs[0], lds_obs[1], lane, cfg.normalize_obs != 0);
     }
@@ -1243,7 +1262,7 @@ int pz_init(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, voi
 }
 
 int pz_reset(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, const uint8_t* mask, int32_t* obs_p1,
-             int32_t* obs_p2, int32_t* episode_stats, void* stream)
+             int32_t* obs_p2, void* episode_stats, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
@@ -1267,7 +1286,7 @@ int pz_observe(const int32_t* state, int64_t n, int64_t stride, int32_t normaliz
 
 int pz_step(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, const int32_t* act_p1,
             const int32_t* act_p2, int32_t* obs_p1, int32_t* obs_p2, void* rew_p1, void* rew_p2, uint8_t* terminated,
-            int32_t* episode_stats, const pz_flight_tables* tables, void* stream)
+            void* episode_stats, const pz_flight_tables* tables, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (!act_p1 || !act_p2 || !obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
@@ -1281,7 +1300,7 @@ int pz_step(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, con
 
 int pz_step_random(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, uint64_t action_seed, uint64_t t0,
                    int32_t k, int32_t* obs_p1, int32_t* obs_p2, void* rew_p1, void* rew_p2, uint8_t* terminated,
-                   int32_t* episode_stats, int64_t* episodes_done, const pz_flight_tables* tables, void* stream)
+                   void* episode_stats, int64_t* episodes_done, const pz_flight_tables* tables, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (!obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
@@ -1296,7 +1315,7 @@ int pz_step_random(int32_t* state, int64_t n, int64_t stride, const pz_config* c
 
 int pz_rollout_random(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, uint64_t action_seed,
                       uint64_t t0, int32_t k, int32_t* actions, int32_t* obs_p1, int32_t* obs_p2, void* rew_p1,
-                      void* rew_p2, uint8_t* terminated, int32_t* episode_stats, int64_t* episodes_done,
+                      void* rew_p2, uint8_t* terminated, void* episode_stats, int64_t* episodes_done,
                       const pz_flight_tables* tables, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
@@ -1313,7 +1332,7 @@ int pz_rollout_random(int32_t* state, int64_t n, int64_t stride, const pz_config
 
 int pz_step_many(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, const int32_t* actions, int32_t k,
                  int32_t* obs_p1, int32_t* obs_p2, void* rew_p1, void* rew_p2, uint8_t* terminated,
-                 int32_t* episode_stats, int64_t* episodes_done, const pz_flight_tables* tables, void* stream)
+                 void* episode_stats, int64_t* episodes_done, const pz_flight_tables* tables, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (!actions || !obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;

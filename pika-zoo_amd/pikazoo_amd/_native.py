@@ -11,7 +11,7 @@ from pathlib import Path
 PKG_ROOT = Path(__file__).resolve().parent.parent  # .../pika-zoo_amd
 LIB_PATH = PKG_ROOT / "lib" / "libpikazoo_hip.so"
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 STATE_WORDS = 44
 OBS_DIM = 35
 SERVE_MODES = {"winner": 0, "alternate": 1, "random": 2}

@@ -176,7 +176,8 @@ class raw_env:
         self._term = self._term_u8.view(torch.bool)
         self._trunc = torch.zeros(n, dtype=torch.bool, device=dev)  # always False (pikazoo_env.py:234)
         self._episodes = torch.zeros(1, dtype=torch.int64, device=dev)
-        self._stats = None  # RecordEpisodeStatistics words [3, n], allocated when the wrapper is fused
+        self._stats = None  # RecordEpisodeStatistics buffer (20 bytes per game), allocated when the wrapper is fused
+        self._ep_returns = self._ep_lengths = None
         # raw pointers of the env-owned buffers (fixed for the env's lifetime) and the cached result tuple:
         # the dicts returned by step() hold views of those buffers, so they can be reused between steps
         self._ptrs = (self.state.data_ptr(), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
@@ -263,19 +264,20 @@ class raw_env:
             raise RuntimeError("RecordEpisodeStatistics is already applied")
         wrapped = bool(self._cfg.ballpos_reward or self._cfg.normal_state_mode)
         self._cfg.episode_stats_mode = 2 if wrapped else 1
-        self._stats_buf = torch.zeros((3, self._stride), dtype=torch.int32, device=self.device)
-        self._stats = self._stats_buf[:, :self.num_envs]
+        # include/pikazoo_hip.h: double[2][stride] running returns, then int32[stride] episode lengths
+        self._stats = torch.zeros(20 * self._stride, dtype=torch.uint8, device=self.device)
+        self._ep_returns = self._stats[:16 * self._stride].view(torch.float64).view(2, self._stride)[:, :self.num_envs]
+        self._ep_lengths = self._stats[16 * self._stride:].view(torch.int32)[:self.num_envs]
 
     @property
     def episode_returns(self) -> Optional[torch.Tensor]:
-        """``[2, num_envs]`` running episode returns (player_1, player_2), typed like the rewards."""
-        if self._stats is None:
-            return None
-        return self._stats[:2].view(torch.float32) if self.reward_dtype == torch.float32 else self._stats[:2]
+        """``float64[2, num_envs]`` running episode returns (player_1, player_2): summed in float64 like the
+        reference's Python floats (record_episode_statistics.py:31); live view of the kernel's buffer."""
+        return self._ep_returns
 
     @property
     def episode_lengths(self) -> Optional[torch.Tensor]:
-        return None if self._stats is None else self._stats[2]
+        return self._ep_lengths
 
     @property
     def n_actions(self) -> int:
@@ -322,7 +324,7 @@ class raw_env:
             # lane, meaningful where terminations[agent] is True (running sums elsewhere)
             ret = self.episode_returns
             for i, a in enumerate(self.agents):
-                infos[a]["episode"] = {"r": ret[i], "l": self._stats[2]}
+                infos[a]["episode"] = {"r": ret[i], "l": self._ep_lengths}
         return infos
 
     def _pack_obs(self):
@@ -352,7 +354,7 @@ class raw_env:
         if self._stats is not None and ended:
             ret = self.episode_returns
             for i, a in enumerate(agents):
-                infos[a]["episode"] = {"r": ret[i][0].item(), "l": int(self._stats[2][0].item())}
+                infos[a]["episode"] = {"r": ret[i][0].item(), "l": int(self._ep_lengths[0].item())}
         out = (self._pack_obs(), {a: rew[i][0].item() for i, a in enumerate(agents)},
                {a: ended for a in agents}, {a: False for a in agents}, infos)
         if ended and not self.auto_reset:

@@ -67,7 +67,7 @@ def test_hip_matches_reference_trajectory(name, tables):
     h_state = torch.empty((T, 44, L), dtype=torch.int32, device=dev)
     h_obs = torch.empty((T, 2, L, 35), dtype=raw.obs_dtype, device=dev)
     has_stats = raw.episode_lengths is not None
-    h_epr = torch.zeros((T, 2, L), dtype=raw.reward_dtype, device=dev)
+    h_epr = torch.zeros((T, 2, L), dtype=torch.float64, device=dev)
     h_epl = torch.zeros((T, L), dtype=torch.int32, device=dev)
     h_rew = torch.empty((T, 2, L), dtype=raw.reward_dtype, device=dev)
     h_term = torch.empty((T, L), dtype=torch.bool, device=dev)
@@ -100,7 +100,8 @@ def test_hip_matches_reference_trajectory(name, tables):
         assert np.array_equal(done, d["term"].astype(bool))
         assert np.array_equal(cpu(h_epl)[done], d["ep_l"][done])
         for i in range(2):
-            np.testing.assert_allclose(cpu(h_epr)[:, i][done], d["ep_r"][:, i][done], rtol=0, atol=2e-4)
+            # float64 sums of float32 rewards vs the reference's float64 sums of float64 rewards
+            np.testing.assert_allclose(cpu(h_epr)[:, i][done], d["ep_r"][:, i][done], rtol=0, atol=2e-6)
     assert np.array_equal(h_term.astype(np.uint8), d["term"])
     if raw.reward_dtype == torch.float32:
         np.testing.assert_allclose(h_rew, d["rew"], rtol=0, atol=1e-6)
@@ -198,8 +199,9 @@ def test_hip_matches_oracle_random_batches(case, tables, oracle):
             assert np.array_equal(cpu(rew["player_2"]), rrew[1]), (case, t)
             assert np.array_equal(cpu(term["player_1"]).astype(np.uint8), rterm), (case, t)
             assert np.array_equal(cpu(infos["player_1"]["score"]), ref.state[38:40].T)
-            if ref.stats is not None:  # bit-exact, fp32 sums included (same order of the same adds)
-                assert np.array_equal(cpu(raw._stats), ref.stats), (case, t)
+            if ref.stats is not None:  # bit-exact, float64 sums included (same order of the same adds)
+                assert np.array_equal(cpu(raw.episode_returns), ref.episode_returns), (case, t)
+                assert raw.episode_returns.dtype == torch.float64
                 assert np.array_equal(cpu(infos["player_2"]["episode"]["l"]), ref.episode_lengths)
     assert ref.state[43].min() >= 4  # draws happened
 
@@ -660,7 +662,8 @@ def test_randomized_config_sweep_vs_oracle(oracle):
         cfg = _native.PzConfig.from_buffer_copy(ocfg)  # identical layout (checked by the CPU tests)
         ref = oracle.OracleEnv(n, ocfg, nthreads=2)
         state = torch.full((44, stride), -99, dtype=torch.int32, device=dev)
-        stats = torch.full((3, stride), 0, dtype=torch.int32, device=dev) if k["episode_stats"] else None
+        # episode statistics: double[2][stride] returns + int32[stride] lengths
+        stats = torch.zeros(20 * stride, dtype=torch.uint8, device=dev) if k["episode_stats"] else None
         obs = [torch.zeros((n, 35), dtype=torch.int32, device=dev) for _ in range(2)]
         rew = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
         term = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -702,7 +705,10 @@ def test_randomized_config_sweep_vs_oracle(oracle):
                                                                                            ref.rew[1].view(np.int32)), ctx
             assert np.array_equal(cpu(term), ref.term), ctx
             if stats is not None:
-                assert np.array_equal(cpu(stats[:, :n]), ref.stats), ctx
+                ret = stats[:16 * stride].view(torch.float64).view(2, stride)
+                assert np.array_equal(cpu(ret[:, :n]), ref.episode_returns), ctx
+                assert np.array_equal(cpu(stats[16 * stride:].view(torch.int32)[:n]), ref.episode_lengths), ctx
+                assert bool((ret[:, n:] == 0).all()), ctx
 
 
 @pytest.mark.parametrize("kw,steps,switch", [

@@ -91,7 +91,7 @@ def test_oracle_matches_reference_trajectory(oracle, name):
             assert np.array_equal(done, term.astype(bool))
             if done.any():
                 assert np.array_equal(env.episode_lengths[done], d["ep_l"][t][done])
-                np.testing.assert_allclose(env.episode_returns[:, done], d["ep_r"][t][:, done], rtol=0, atol=2e-4)
+                np.testing.assert_allclose(env.episode_returns[:, done], d["ep_r"][t][:, done], rtol=0, atol=2e-6)
         if fused:
             # reference adds a Python float to an int in float64 (reward_by_ball_position.py:29);
             # the build emits float32: tolerance = 1 ulp of fp32 at |r|<=~10 (1e-6 abs)
