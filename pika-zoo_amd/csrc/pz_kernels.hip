@@ -827,8 +827,9 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     g_pz_ablate_bits = a.cfg.reserved;  // every lane stores the same value; read by the hooks in pz_physics.hpp
 #endif
     LandingProbe after_hit{false, false, 0u};
+    bool bold_pending = false;  // a human player's new-round boldness draw, made behind the stores
     const int reward = step_games_pair<ROLE, AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, xchg, kLanes * PZ_OBS_DIM,
-                                                        lane, lut, after_hit);
+                                                        lane, lut, after_hit, bold_pending);
     const Rewards rw = shape_rewards(a.cfg, g, reward, frozen);
     if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
     PZ_PAIR_STAMP(ROLE, 2);
@@ -877,6 +878,10 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     PZ_PAIR_STAMP(ROLE, 5);
     PZ_DRAIN_VMEM();
     PZ_PAIR_STAMP(ROLE, 6);
+    if (bold_pending) {  // draw number loaded.rng + ROLE of the env stream: player 1's, then player 2's (physics.py:218)
+        uint32_t counter = loaded.e.rng + (uint32_t)ROLE;
+        io.st(kOwn + PZ_P_COMPUTER_BOLDNESS, rng_integers(id, counter, 5u));
+    }
     // last: after a ball-player collision the value comes from a table gather issued at the end of the frame
     if (kKeepsEx) {
         const int ex = lut.landing_finish(after_hit, g.b.x, g.b.y, g.b.xv, g.b.yv, g.b.ex);

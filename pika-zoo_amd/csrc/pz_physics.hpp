@@ -1115,7 +1115,7 @@ constexpr int kEarlyPostAt = 1024;  // word offset of the early post {x, draws} 
 template <int ROLE, bool AI1, bool AI2>
 __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2,
                                                bool live, bool& frozen, int32_t* __restrict__ xchg, int xchg_region,
-                                               int lane, const FlightLut& lut, LandingProbe& after_hit)
+                                               int lane, const FlightLut& lut, LandingProbe& after_hit, bool& bold_pending)
 {
     constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
     constexpr bool kOtherAI = ROLE == 0 ? AI2 : AI1;
@@ -1137,8 +1137,29 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             g.e.round_ended = 0;
             // draw order of the reference: player 1 boldness, player 2 boldness [, serve]; each wave
             // evaluates its own player's draw (index rng + ROLE)
-            uint32_t own_draw = g.e.rng + (uint32_t)ROLE;
-            player_new_round(own, ROLE == 0 ? 36 : kGroundWidth - 36, id, own_draw);
+#ifndef PZ_BOLD_IN_FRAME
+            if (!AI1 && !AI2) {
+                // human vs human: computer_boldness (drawn for humans too, physics.py:218) is read by nothing, so the
+                // wave resets its player here and leaves the draw -- a whole Philox block in front of the frame's
+                // first store -- to its caller, behind the stores (7.25 -> 7.15 us per launch; with a computer player
+                // in the game the human player's wave is not the one the launch waits for, and deferring cost 1 %)
+                const int keep = own.bold;
+                own.x = ROLE == 0 ? 36 : kGroundWidth - 36;
+                own.y = kPlayerGroundY;
+                own.yv = 0;
+                own.coll = 0;
+                own.state = 0;
+                own.frame = 0;
+                own.arm = 1;
+                own.delay = 0;
+                own.bold = keep;
+                bold_pending = true;
+            } else
+#endif
+            {
+                uint32_t own_draw = g.e.rng + (uint32_t)ROLE;
+                player_new_round(own, ROLE == 0 ? 36 : kGroundWidth - 36, id, own_draw);
+            }
             other.x = ROLE == 0 ? kGroundWidth - 36 : 36;
             other.y = kPlayerGroundY;
             other.yv = 0;
