@@ -1126,6 +1126,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     const bool active = live && !frozen;
     Input in1{0, 0, 0}, in2{0, 0, 0};
     bool ground = false;
+    PZ_FRAME_STAMP(0);
     if (active) {
         if (g.e.round_ended) {  // reset (:149-164) or new round (:176-180); game_ended implies round_ended
             if (g.e.game_ended) {
@@ -1137,7 +1138,6 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             g.e.round_ended = 0;
             // draw order of the reference: player 1 boldness, player 2 boldness [, serve]; each wave
             // evaluates its own player's draw (index rng + ROLE)
-#ifndef PZ_BOLD_IN_FRAME
             if (!AI1 && !AI2) {
                 // human vs human: computer_boldness (drawn for humans too, physics.py:218) is read by nothing, so the
                 // wave resets its player here and leaves the draw -- a whole Philox block in front of the frame's
@@ -1154,9 +1154,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
                 own.delay = 0;
                 own.bold = keep;
                 bold_pending = true;
-            } else
-#endif
-            {
+            } else {
                 uint32_t own_draw = g.e.rng + (uint32_t)ROLE;
                 player_new_round(own, ROLE == 0 ? 36 : kGroundWidth - 36, id, own_draw);
             }
@@ -1170,6 +1168,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             g.e.rng += 2u;
             ball_new_round(g.b, get_server(cfg, g.e, id));  // a random serve is drawn by both waves
         }
+        PZ_FRAME_STAMP(1);
         int other_prev = 0;  // the partner's key edge is only needed by the partner
         if (cfg.simplify_action) {
             in1 = decode_action(kSimpleTablesP1, a1, ROLE == 0 ? g.p1.hitprev : other_prev);
@@ -1178,8 +1177,10 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             in1 = decode_action(kFullTables, a1, ROLE == 0 ? g.p1.hitprev : other_prev);
             in2 = decode_action(kFullTables, a2, ROLE == 1 ? g.p2.hitprev : other_prev);
         }
+        PZ_FRAME_STAMP(2);
 
         ground = ball_world_step(g.b);
+        PZ_FRAME_STAMP(3);
     }
     const uint32_t rng_base = g.e.rng;  // the env stream before this frame's decisions
     uint32_t draws_own = 0, draws_other = 0;
@@ -1194,24 +1195,6 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             draws_other = (uint32_t)early[1];
         }
     }
-#ifdef PZ_NO_PREDRAWN  // tools/ab.py variant: the decision as the single-wave frame makes it (draws on demand)
-    if (kOwnAI) {
-        if (active) {
-            g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
-            if (ROLE == 1 && !AI1) {
-                const int vx = (other.state < 3) ? in1.xd * 6 : other.dive * 8;
-                const int nx = min(max(other.x + vx, kPlayerHalfLength), kGroundHalfWidth - kPlayerHalfLength);
-                other.x = (other.state == 4) ? other.x : nx;
-            }
-            uint32_t rng = rng_base + draws_other;
-            const HitScan hs = computer_decide_begin<ROLE == 1>(own, g.b, in_own, id, rng);
-            draws_own = rng - (rng_base + draws_other);
-            int ex[6] = {0, 0, 0, 0, 0, 0};
-            if (hs.need) lut.power_hit_candidates(g.b.x, g.b.y, abs(g.b.yv), ex);
-            computer_decide_finish<ROLE == 1>(hs, ex, own, other, in_own);
-        }
-    }
-#else
     if (kOwnAI) {
         if (active) {
             // :314-315 recomputes the landing point before each player; the ball does not move in between.
@@ -1240,8 +1223,8 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
                 draws_own = computer_decide_predrawn<ROLE == 1>(own, g.b, other.x, pre, scan, ex, in_own);
         }
     }
-#endif
     if (active) player_move<ROLE == 1>(own, in_own);
+    PZ_FRAME_STAMP(4);
     if (ROLE == 0 && AI1 && AI2) {
         if (active) {
             int32_t* early = xchg + (1 - ROLE) * xchg_region + kEarlyPostAt + lane * 2;
@@ -1286,6 +1269,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             }
         }
     }
+    PZ_FRAME_STAMP(5);
     int reward = 0;
     bool hit_processed = false;
     if (active) {
@@ -1310,10 +1294,12 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
 
         hit_processed = (hit1 | hit2) && !PZ_ABLATE_SKIP(128);
     }
+    PZ_FRAME_STAMP(6);
     // :331-332 -- predicted again after a processed collision (one evaluation after both collisions leaves what
     // the second of two would).  Nothing in the frame reads it any more: the gather is issued here and taken
     // by the caller behind its other stores (`after_hit`).
     if (kKeepsEx) after_hit = lut.landing_issue(hit_processed, g.b.x, g.b.y, g.b.xv, g.b.yv);
+    PZ_FRAME_STAMP(7);
     return reward;
 }
 

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Long parity run on the GPU box (diagnostic, beyond the pytest suite): 65 536 games stepped through the single-frame
+launch (`pz_step`: the pair kernel / scout kernel, actions from HBM) for tens of thousands of frames per
+configuration, full state compared with the CPU oracle every `--every` frames on EVERY lane.
+
+    python tools/soak.py [--frames 20000] [--every 2000] [--n 65536]
+"""
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "pika-zoo_amd"))
+sys.path.insert(0, str(REPO))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import pz_oracle as po  # noqa: E402
+from pikazoo_amd import pikazoo_v0  # noqa: E402
+from pikazoo_amd.wrappers import (RecordEpisodeStatistics, RewardByBallPosition, RewardInNormalState,  # noqa: E402
+                                  SimplifyAction)
+
+TABLE = (0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01)
+
+
+def main():
+    args = sys.argv[1:]
+    frames = int(args[args.index("--frames") + 1]) if "--frames" in args else 20000
+    every = int(args[args.index("--every") + 1]) if "--every" in args else 2000
+    n = int(args[args.index("--n") + 1]) if "--n" in args else 65536
+    configs = [
+        ("human_vs_human (pair kernel)", dict(), dict(), None),
+        ("config 3: p2 computer, flight tables (pair kernel)", dict(is_player2_computer=True), dict(is_player2_computer=True), None),
+        ("config 3: p2 computer, computed predictors (scout kernel)", dict(is_player2_computer=True, flight_tables=False),
+         dict(is_player2_computer=True), None),
+        ("both computer, random serve, tables", dict(is_player1_computer=True, is_player2_computer=True, serve="random"),
+         dict(is_player1_computer=True, is_player2_computer=True, serve="random"), None),
+        ("config 5 + RewardInNormalState + RecordEpisodeStatistics", dict(), dict(), "wrappers"),
+    ]
+    po.build()
+    ok = True
+    for name, kw, okw, wr in configs:
+        env = pikazoo_v0.env(num_envs=n, device="cuda:0", seed=123, env_id_base=1 << 34, validate_actions=False, **kw)
+        ocfg_kw = dict(seed=123, env_id_base=1 << 34, **okw)
+        if wr:
+            env = RecordEpisodeStatistics(RewardInNormalState(RewardByBallPosition(SimplifyAction(env), TABLE), -0.001))
+            ocfg_kw.update(simplify_action=True, additional_reward=TABLE, normal_state_reward=-0.001,
+                           normal_state_outside=True, episode_stats=2)
+        raw = env.unwrapped
+        ref = po.OracleEnv(n, po.make_config(**ocfg_kw), nthreads=16)
+        env.reset(), ref.reset()
+        t0 = time.perf_counter()
+        eps = 0
+        for start in range(0, frames, every):
+            for t in range(start, start + every):
+                env.step(raw.random_actions(77, t))
+            eps += ref.rollout_random(77, start, every)
+            same = np.array_equal(raw.state.cpu().numpy(), ref.state)
+            if wr:
+                same = same and np.array_equal(raw.episode_returns.cpu().numpy(), ref.episode_returns) and \
+                    np.array_equal(raw.episode_lengths.cpu().numpy(), ref.episode_lengths)
+            if not same:
+                ok = False
+                print(f"MISMATCH {name}: after {start + every} frames", flush=True)
+                break
+        print(f"{name}: {n} games x {start + every} frames = {n * (start + every) / 1e9:.2f} G game-steps bit-exact vs oracle "
+              f"on every lane: {same}; {eps} episodes finished; {time.perf_counter() - t0:.0f} s", flush=True)
+    print("SOAK", "PASSED" if ok else "FAILED")
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -91,14 +91,14 @@ def main():
             for role in (0, 1):
                 dr = d[role::2]
                 print(f"    wave of player {role + 1} (median): " + ", ".join(f"{names[k + 1]} {np.median(dr[:, k]):.2f}" for k in range(6)))
-            continue
         fb = np.zeros(8192 * 8, np.uint64)
         lib.pz_debug_read_frame_stamps.argtypes = [P, C.c_int64]
         assert lib.pz_debug_read_frame_stamps(fb.ctypes.data, 8192 * 8) == 0
-        fs = fb.reshape(8192, 8)[:waves].astype(np.int64)
+        fs = fb.reshape(8192, 8)[:(waves // 2 if pair else waves)].astype(np.int64)  # pair: lane 0 of the player-1 wave
         fd = np.diff(fs, axis=1)  # shader-clock cycles (s_memtime)
-        fnames = ["round start", "action decode", "ball-world", "AI1 + player 1", "AI2 + player 2", "collisions",
-                  "scoring"]
+        fnames = (["round start", "action decode", "ball-world", "decision + own move", "exchange", "collisions + scoring",
+                   "tail"] if pair else
+                  ["round start", "action decode", "ball-world", "AI1 + player 1", "AI2 + player 2", "collisions", "scoring"])
         print("  frame sub-phases, shader cycles per wave (median / p95): " +
               ", ".join(f"{fnames[k]} {int(np.median(fd[:, k]))}/{int(np.percentile(fd[:, k], 95))}" for k in range(7)) +
               f"; whole frame {int(np.median(fs[:, 7] - fs[:, 0]))}")
