@@ -59,6 +59,7 @@ class PhiloxShim:
 
 
 _NEXT_SHIM: list = []
+_NEXT_SAMPLES: list = []  # what the stubbed Discrete.sample() returns next (ConvertSingleAgent's opponent draws)
 
 
 def _np_random_stub(seed=None):
@@ -79,6 +80,12 @@ def install_stubs():
     class Discrete(Space):
         def __init__(self, n):
             self.n = n
+
+        def sample(self):
+            # gymnasium's sampler is an unseeded third-party RNG; the harness feeds it the stream it wants recorded
+            v = _NEXT_SAMPLES.pop(0)
+            assert 0 <= v < self.n
+            return v
 
     class Box(Space):
         def __init__(self, low, high, shape=None, dtype=None):
@@ -336,6 +343,52 @@ def capture(name: str, lanes: int, steps: int, seed: int, action_seed: int, env_
     return out
 
 
+def capture_single_agent(name: str, lanes: int, steps: int, seed: int, action_seed: int, opponent_seed: int,
+                         env_id_base: int, side: str, env_kwargs: dict) -> dict:
+    """The reference's ``ConvertSingleAgent`` (wrappers/convert_single_agent.py) around the unmodified env: the
+    controlled side plays policy stream `action_seed`, the other side's ``action_space(other).sample()`` is fed policy
+    stream `opponent_seed` (word 0 / 1 of the draw for player_1 / player_2 -- what the product's wrapper draws on
+    device).  Stores what the wrapper returns for the controlled side at every step."""
+    install_stubs()
+    import pikazoo.wrappers as ref_wrappers
+
+    me = 0 if side == "player_1" else 1
+    envs = []
+    for i in range(lanes):
+        env, raw, shim = make_reference_env(seed, env_id_base + i, None, **env_kwargs)
+        envs.append((ref_wrappers.ConvertSingleAgent(env, side), raw, shim))
+    obs_reset = np.zeros((lanes, po.OBS), np.int32)
+    for i, (env, raw, shim) in enumerate(envs):
+        o, info = env.reset()
+        obs_reset[i] = o
+        assert list(info) == ["score"]
+    actions = np.zeros((steps, lanes), np.int32)
+    sampled = np.zeros((steps, lanes), np.int32)
+    obs = np.zeros((steps, lanes, po.OBS), np.int32)
+    rew = np.zeros((steps, lanes), np.int32)
+    term = np.zeros((steps, lanes), np.uint8)
+    score = np.zeros((steps, lanes, 2), np.int32)
+    states = np.zeros((steps, po.W, lanes), np.int32)
+    for t in range(steps):
+        own = po.random_actions(lanes, env_id_base, action_seed, t, 18)[me]
+        opp = po.random_actions(lanes, env_id_base, opponent_seed, t, 18)[1 - me]
+        for i, (env, raw, shim) in enumerate(envs):
+            if not raw.agents:
+                env.reset()
+            _NEXT_SAMPLES.append(int(opp[i]))
+            o, r, te, tr, info = env.step(int(own[i]))
+            assert not _NEXT_SAMPLES and tr is False
+            obs[t, i], rew[t, i], term[t, i], score[t, i] = o, r, int(te), info["score"]
+            states[t, :, i] = extract_state(raw, shim)
+        actions[t], sampled[t] = own, opp
+    meta = dict(name=name, lanes=lanes, steps=steps, seed=seed, action_seed=action_seed, opponent_seed=opponent_seed,
+                env_id_base=env_id_base, side=side, env_kwargs=env_kwargs)
+    return dict(meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), obs_reset=obs_reset,
+                actions=actions.astype(np.uint8), sampled=sampled.astype(np.uint8), obs=obs.astype(np.int16),
+                rew=rew.astype(np.int8), term=term, score=score.astype(np.int8), states=states.astype(np.int16),
+                rng_counter=states[:, po.E_RNG_COUNTER, :].astype(np.int32))
+
+
 TEST_TABLE = (0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01)  # SURVEY 8(d) config 5
 INT_TABLE = (1, -2, 3, -4, 5, -6, 7, -8)
 
@@ -382,6 +435,12 @@ FIXTURES += [
     ("cfg1_one_env_10k", 1, 10000, dict(), None),
 ]
 
+SINGLE_AGENT_RUNS = [
+    # name, lanes, steps, side, env_kwargs
+    ("single_agent_player_2", 4, 1200, "player_2", dict(winning_score=2, serve="winner")),
+    ("single_agent_player_1_vs_computer", 4, 1200, "player_1", dict(winning_score=2, is_player2_computer=True)),
+]
+
 DIGEST_RUNS = [
     ("digest_human_human", 48, 20000, dict(winning_score=15, serve="winner"), None),
     ("digest_p2_computer", 48, 20000, dict(winning_score=15, serve="winner", is_player2_computer=True), None),
@@ -410,6 +469,14 @@ def main(argv=None):
         meta = json.loads(bytes(data["meta"]).decode())
         print(f"{name}: {lanes}x{steps} episodes={meta['episodes']} "
               f"{(GOLDEN / (name + '.npz')).stat().st_size / 1e3:.0f} kB {time.time() - t0:.1f}s")
+    for k, (name, lanes, steps, side, kw) in enumerate(SINGLE_AGENT_RUNS):
+        if args.only and args.only != name:
+            continue
+        data = capture_single_agent(name, lanes, steps, seed=4242 + k, action_seed=31 + k, opponent_seed=900 + k,
+                                    env_id_base=7000 + 10 * k, side=side, env_kwargs=kw)
+        np.savez_compressed(GOLDEN / f"{name}.npz", **data)
+        print(f"{name}: {lanes}x{steps} terminations={int(data['term'].sum())} "
+              f"{(GOLDEN / (name + '.npz')).stat().st_size / 1e3:.0f} kB")
     if not args.skip_digests:
         for k, (name, lanes, steps, kw, wr) in enumerate(DIGEST_RUNS):
             if args.only and args.only != name:

@@ -344,3 +344,38 @@ def test_checkpoint_round_trip_with_fused_statistics():
     plain = pikazoo_v0.env(num_envs=512, seed=5, env_id_base=40, winning_score=1, is_player2_computer=True)
     with pytest.raises(ValueError):
         plain.load_state_dict(sd)
+
+
+@pytest.mark.parametrize("name", ["single_agent_player_2", "single_agent_player_1_vs_computer"])
+def test_convert_single_agent_matches_the_reference_wrapper(name):
+    """ConvertSingleAgent against fixtures captured from the reference's own wrapper class
+    (wrappers/convert_single_agent.py:16-28; its `action_space(other).sample()` fed the policy stream the product's
+    wrapper draws on device): what step() returns for the controlled side, frame by frame."""
+    from conftest import load_golden
+    from pikazoo_amd import pikazoo_v0
+    from pikazoo_amd.wrappers import ConvertSingleAgent
+
+    d = load_golden(name)
+    meta = d["meta"]
+    env = pikazoo_v0.env(num_envs=meta["lanes"], seed=meta["seed"], env_id_base=meta["env_id_base"],
+                         validate_actions=False, **meta["env_kwargs"])
+    single = ConvertSingleAgent(env, meta["side"], opponent_seed=meta["opponent_seed"])
+    obs, info = single.reset()
+    assert np.array_equal(obs.cpu().numpy(), d["obs_reset"]) and "score" in info
+    acts = torch.as_tensor(d["actions"].astype(np.int32), device="cuda:0")
+    T, L = meta["steps"], meta["lanes"]
+    h_obs = torch.empty((T, L, 35), dtype=torch.int32, device="cuda:0")
+    h_rew = torch.empty((T, L), dtype=torch.int32, device="cuda:0")
+    h_term = torch.empty((T, L), dtype=torch.bool, device="cuda:0")
+    h_score = torch.empty((T, L, 2), dtype=torch.int32, device="cuda:0")
+    for t in range(T):
+        o, r, term, trunc, info = single.step(acts[t])
+        h_obs[t].copy_(o), h_rew[t].copy_(r), h_term[t].copy_(term), h_score[t].copy_(info["score"])
+    assert not bool(trunc.any())
+    assert np.array_equal(h_obs.cpu().numpy(), d["obs"].astype(np.int32))
+    assert np.array_equal(h_rew.cpu().numpy(), d["rew"].astype(np.int32))
+    assert np.array_equal(h_term.cpu().numpy().astype(np.uint8), d["term"])
+    assert np.array_equal(h_score.cpu().numpy(), d["score"].astype(np.int32))
+    st = d["states"][-1].astype(np.int32)
+    st[43] = d["rng_counter"][-1]
+    assert np.array_equal(env.state.cpu().numpy(), st)

@@ -188,3 +188,38 @@ def test_flight_simulation_edge_cases(oracle):
     # power-hit predictor ignores the current x velocity (physics.py:841-845)
     assert oracle.expected_landing_x_power_hit(1, 1, 100, 100, -7, 10) == \
         oracle.expected_landing_x_power_hit(1, 1, 100, 100, 13, 10)
+
+
+SINGLE_AGENT_FIXTURES = ["single_agent_player_2", "single_agent_player_1_vs_computer"]
+
+
+@pytest.mark.parametrize("name", SINGLE_AGENT_FIXTURES)
+def test_oracle_matches_reference_single_agent_view(oracle, name):
+    """Fixtures captured from the reference's ConvertSingleAgent (wrappers/convert_single_agent.py:16-28): the
+    controlled side's actions and the opponent draws its `action_space(other).sample()` was fed.  The oracle stepped
+    with both reproduces the env's state and what the wrapper returned for the controlled side."""
+    d = load_golden(name)
+    meta = d["meta"]
+    me = 0 if meta["side"] == "player_1" else 1
+    kw = meta["env_kwargs"]
+    cfg = oracle.make_config(winning_score=kw.get("winning_score", 15), serve=kw.get("serve", "winner"),
+                             is_player1_computer=kw.get("is_player1_computer", False),
+                             is_player2_computer=kw.get("is_player2_computer", False),
+                             seed=meta["seed"], env_id_base=meta["env_id_base"])
+    env = oracle.OracleEnv(meta["lanes"], cfg)
+    obs0 = env.reset()
+    assert np.array_equal(obs0[me], d["obs_reset"])
+    for t in range(meta["steps"]):
+        own, opp = d["actions"][t].astype(np.int32), d["sampled"][t].astype(np.int32)
+        # both streams are the build's Philox policy stream (word `me` / `1 - me` of the draw)
+        assert np.array_equal(own, oracle.random_actions(meta["lanes"], meta["env_id_base"], meta["action_seed"], t)[me])
+        assert np.array_equal(opp, oracle.random_actions(meta["lanes"], meta["env_id_base"], meta["opponent_seed"], t)[1 - me])
+        a = [None, None]
+        a[me], a[1 - me] = own, opp
+        obs, rew, term = env.step(a[0], a[1])
+        st = d["states"][t].astype(np.int32)
+        st[43] = d["rng_counter"][t]
+        assert np.array_equal(env.state, st), (name, t)
+        assert np.array_equal(obs[me], d["obs"][t]) and np.array_equal(rew[me], d["rew"][t]), (name, t)
+        assert np.array_equal(term, d["term"][t]) and np.array_equal(env.state[38:40].T, d["score"][t]), (name, t)
+    assert d["term"].sum() > 10
