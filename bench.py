@@ -463,10 +463,20 @@ def main():
             "cfg5": ("65 536 games, fused SimplifyAction + RewardByBallPosition",
                      dict(num_envs=65536, wrappers=True)),
         }
+        # the flight tables are built once per device, outside every timed region: say what that costs
+        from pikazoo_amd import env as _env
+
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        tables_struct, t_landing, t_power_hit = _env.flight_tables(device)
+        torch.cuda.synchronize(device)
+        table_info = {"build_ms_once_per_device": (time.perf_counter() - t0) * 1e3,
+                      "bytes": int(t_landing.numel() + t_power_hit.numel())}
         for key, (wl, kw) in specs.items():
             r = measure(args, dist.weak_shard(kw["num_envs"], rank, world), device, **{**sub, **kw})
             r.pop("raw")
             configs[key] = config_entry(r, wl, kw["num_envs"])
+        configs["cfg3"]["flight_tables"] = table_info
 
     extra = {}
     if args.extra and world == 1:
