@@ -980,47 +980,73 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
         }
         __syncthreads();  // the scout starts on this frame's candidates
     }
-    if ((AI1 || AI2) && active) {
-        // :314-315 recomputes the landing point before each player; the ball does not move
-        // between the two calls, so one evaluation serves both.
-        g.b.ex = PZ_ABLATE_SKIP(32) ? g.b.x : lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
-    }
+    // With both flight tables every prediction is one gather and nothing needs the wave's cooperation: the decision
+    // runs as in the pair kernel (step_games_pair) -- both gathers issued, the first decision's three possible draws
+    // computed under them, branch-free decisions.  One candidate gather serves both players (same ball).
+    const bool by_tables = (AI1 || AI2) && SCOUT == kNoScout && lut.has_landing && lut.has_power_hit;  // wave-uniform
+    if (by_tables) {
+        if (active) {
+            const bool scan1 = AI1 && power_hit_scan_needed(g.p1, g.b);
+            const bool scan2 = AI2 && power_hit_scan_needed(g.p2, g.b);  // player 2 has not moved yet
+            const int ayv = abs(g.b.yv);
+            int ex[6] = {0, 0, 0, 0, 0, 0};
+            LandingProbe lp = lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv);
+            CandidateProbe cp = lut.candidates_issue(scan1 | scan2, g.b.x, g.b.y, ayv);
+            PreDrawn pre = predraw3(id, g.e.rng);
+            asm volatile("" : "+v"(pre.w0), "+v"(pre.w1), "+v"(pre.w2), "+v"(lp.value), "+v"(cp.value.x), "+v"(cp.value.y),
+                         "+v"(cp.value.z));  // keeps the Philox blocks under the gathers (see step_games_pair)
+            g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, 0);  // :314-315, one evaluation serves both
+            lut.candidates_finish(cp, g.b.x, g.b.y, ayv, ex);
+            if (AI1) g.e.rng += computer_decide_predrawn<false>(g.p1, g.b, g.p2.x, pre, scan1, ex, in1);
+            player_move<false>(g.p1, in1);
+            if (AI2) {
+                if (AI1) pre = predraw3(id, g.e.rng);  // player 2's draws continue where player 1's ended
+                g.e.rng += computer_decide_predrawn<true>(g.p2, g.b, g.p1.x, pre, scan2, ex, in2);
+            }
+        }
+    } else {
+        if ((AI1 || AI2) && active) {
+            // :314-315 recomputes the landing point before each player; the ball does not move
+            // between the two calls, so one evaluation serves both.
+            g.b.ex = PZ_ABLATE_SKIP(32) ? g.b.x : lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
+        }
 
-    if (AI1) {
-        HitScan hs{false, false};
-        int ex[6] = {0, 0, 0, 0, 0, 0};
-        if (active) hs = computer_decide_begin<false>(g.p1, g.b, in1, id, g.e.rng);
-        if (SCOUT) {
-            __syncthreads();  // the scout's candidates are in place
-            if (hs.need) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) ex[c] = link.cand[lane * kCandPitch + c];
+        if (AI1) {
+            HitScan hs{false, false};
+            int ex[6] = {0, 0, 0, 0, 0, 0};
+            if (active) hs = computer_decide_begin<false>(g.p1, g.b, in1, id, g.e.rng);
+            if (SCOUT) {
+                __syncthreads();  // the scout's candidates are in place
+                if (hs.need) {
+    #pragma unroll
+                    for (int c = 0; c < 6; ++c) ex[c] = link.cand[lane * kCandPitch + c];
+                }
+            } else if (lut.has_power_hit) {  // wave-uniform
+                if (hs.need) lut.power_hit_candidates(g.b.x, g.b.y, abs(g.b.yv), ex);
+            } else {
+                wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
             }
-        } else if (lut.has_power_hit) {  // wave-uniform
-            if (hs.need) lut.power_hit_candidates(g.b.x, g.b.y, abs(g.b.yv), ex);
-        } else {
-            wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
+            computer_decide_finish<false>(hs, ex, g.p1, g.p2, in1);
         }
-        computer_decide_finish<false>(hs, ex, g.p1, g.p2, in1);
-    }
-    if (active) player_move<false>(g.p1, in1);
-    PZ_FRAME_STAMP(4);
-    if (AI2) {
-        HitScan hs{false, false};
-        int ex[6] = {0, 0, 0, 0, 0, 0};
-        if (active) hs = computer_decide_begin<true>(g.p2, g.b, in2, id, g.e.rng);
-        if (SCOUT) {
-            if (!AI1) __syncthreads();  // (with two computer players the barrier above already passed)
-            if (hs.need) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) ex[c] = link.cand[lane * kCandPitch + c];
+        if (active) player_move<false>(g.p1, in1);
+        PZ_FRAME_STAMP(4);
+        if (AI2) {
+            HitScan hs{false, false};
+            int ex[6] = {0, 0, 0, 0, 0, 0};
+            if (active) hs = computer_decide_begin<true>(g.p2, g.b, in2, id, g.e.rng);
+            if (SCOUT) {
+                if (!AI1) __syncthreads();  // (with two computer players the barrier above already passed)
+                if (hs.need) {
+    #pragma unroll
+                    for (int c = 0; c < 6; ++c) ex[c] = link.cand[lane * kCandPitch + c];
+                }
+            } else if (lut.has_power_hit) {
+                if (hs.need) lut.power_hit_candidates(g.b.x, g.b.y, abs(g.b.yv), ex);
+            } else {
+                wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
             }
-        } else if (lut.has_power_hit) {
-            if (hs.need) lut.power_hit_candidates(g.b.x, g.b.y, abs(g.b.yv), ex);
-        } else {
-            wave_power_hit_candidates(hs.need, g.b, ex, scratch, lane);
+            computer_decide_finish<true>(hs, ex, g.p2, g.p1, in2);
         }
-        computer_decide_finish<true>(hs, ex, g.p2, g.p1, in2);
     }
 
     int reward = 0;
