@@ -1,14 +1,17 @@
 // pz_kernels.hip -- gfx950 kernels + C ABI of libpikazoo_hip.so (see include/pikazoo_hip.h).
 //
-// Launch geometry: one lane per game, one wave64 per workgroup (64 consecutive games).  A
-// workgroup reads its 44 state columns with fully coalesced dword loads (256 B per wave
-// instruction), runs the frame in registers, and writes the two row-major [n][35]
-// observation tensors through an LDS transpose so that the global stores are contiguous
-// 16-byte-per-lane streams (a wave's 64 rows are one contiguous 8 960-byte span).
-// 64-lane workgroups keep the transpose barrier-free across waves and give the dispatcher
-// 1 024 independent workgroups at the 65 536-game batch (4 per CU, one wave per SIMD).
+// Launch geometry: one lane per game, 64 consecutive games per workgroup.  A workgroup reads its 44 state
+// columns with fully coalesced dword loads (256 B per wave instruction), runs the frame in registers, and
+// writes the two row-major [n][35] observation tensors through an LDS transpose so that the global stores
+// are contiguous 16-byte-per-lane streams (a wave's 64 rows are one contiguous 8 960-byte span).  The
+// 65 536-game batch is 1 024 independent workgroups (4 per CU).
+//   * single-frame launches below 393 216 games: TWO waves per workgroup, split by player
+//     (step_pair_kernel / step_games_pair) -- a launch lasts about as long as one wave's
+//     load -> frame -> store chain plus the write drain, and the split halves the frame;
+//   * k-frame launches and larger batches: one wave per workgroup (step_kernel / step_games);
+//   * a computer player without flight tables: frame wave + scout wave (step_kernel<..., SCOUT>).
 //
-// At that batch every SIMD runs ONE wave, so nothing hides a wave's own instruction latency:
+// At these batch sizes a SIMD runs one or two waves, so nothing hides a wave's own instruction latency:
 // the per-wave timeline (tools/stamps.py) is load -> frame -> stores, serialized.  All global
 // traffic therefore goes through buffer descriptors (SRD in SGPRs + 32-bit lane offset + scalar
 // column offset): a memory instruction needs no per-lane 64-bit address arithmetic, which with

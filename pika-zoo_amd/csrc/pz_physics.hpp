@@ -2,8 +2,9 @@
 //
 // One lane = one independent Pikachu-Volleyball game held entirely in registers.  All
 // arithmetic is int32; there is no floating point on the path except the optional
-// RewardByBallPosition add.  Written for SIMT: short bodies are predicated selects, the
-// only real loops are the two ball-flight predictors of the rule-based computer player.
+// fused reward wrappers' adds.  Written for SIMT: short bodies are predicated selects, the
+// only real loops are the two ball-flight predictors of the rule-based computer player -- and
+// those are normally replaced by look-ups in the flight tables (FlightLut).
 //
 // Behavioural spec: helpingstar/pika-zoo @ 2024_10_08 (citations `file:line` are relative
 // to the reference checkout and name the rule each block implements).
