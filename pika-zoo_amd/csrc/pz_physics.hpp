@@ -1136,7 +1136,7 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
 // from its own, so a wave may reuse its own region afterwards without asking (the pair kernel aliases them
 // with the observation staging rows).  One __syncthreads(), two when both players are computers.
 // ---------------------------------------------------------------------------------------
-constexpr int kXchgWords = 11;    // 9 player words + decision word + pad: odd pitch, conflict-free LDS rows
+constexpr int kXchgPitch = 64;      // exchange word k of lane l lives at [k * 64 + l] (10 words: 9 player + decision)
 constexpr int kEarlyPostAt = 1024;  // word offset of the early post {x, draws} inside a region (2 x 64 words)
 
 template <int ROLE, bool AI1, bool AI2>
@@ -1263,32 +1263,33 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     // hand the own player to the partner wave: everything the collisions and the observations read
     // (frozen games exchange their unchanged players, so their observations stay complete)
     if (live) {
-        int32_t* mine = xchg + (1 - ROLE) * xchg_region + lane * kXchgWords;  // into the partner's region
-        mine[0] = own.x;
-        mine[1] = own.y;
-        mine[2] = own.yv;
-        mine[3] = own.state;
-        mine[4] = own.frame;
-        mine[5] = own.delay;
-        mine[6] = own.dive;
-        mine[7] = own.lying;
-        mine[8] = own.hitprev;
-        if (kOwnAI) mine[9] = (in_own.xd + 1) | ((in_own.yd + 1) << 2) | (int32_t)(draws_own << 4);
+        // word k of lane l at [k * 64 + l]: conflict-free, and pairs of words become one ds_write2st64_b32
+        int32_t* mine = xchg + (1 - ROLE) * xchg_region + lane;  // into the partner's region
+        mine[0 * kXchgPitch] = own.x;
+        mine[1 * kXchgPitch] = own.y;
+        mine[2 * kXchgPitch] = own.yv;
+        mine[3 * kXchgPitch] = own.state;
+        mine[4 * kXchgPitch] = own.frame;
+        mine[5 * kXchgPitch] = own.delay;
+        mine[6 * kXchgPitch] = own.dive;
+        mine[7 * kXchgPitch] = own.lying;
+        mine[8 * kXchgPitch] = own.hitprev;
+        if (kOwnAI) mine[9 * kXchgPitch] = (in_own.xd + 1) | ((in_own.yd + 1) << 2) | (int32_t)(draws_own << 4);
     }
     __syncthreads();
     if (live) {
-        const int32_t* theirs = xchg + ROLE * xchg_region + lane * kXchgWords;
-        other.x = theirs[0];
-        other.y = theirs[1];
-        other.yv = theirs[2];
-        other.state = theirs[3];
-        other.frame = theirs[4];
-        other.delay = theirs[5];
-        other.dive = theirs[6];
-        other.lying = theirs[7];
-        other.hitprev = theirs[8];
+        const int32_t* theirs = xchg + ROLE * xchg_region + lane;
+        other.x = theirs[0 * kXchgPitch];
+        other.y = theirs[1 * kXchgPitch];
+        other.yv = theirs[2 * kXchgPitch];
+        other.state = theirs[3 * kXchgPitch];
+        other.frame = theirs[4 * kXchgPitch];
+        other.delay = theirs[5 * kXchgPitch];
+        other.dive = theirs[6 * kXchgPitch];
+        other.lying = theirs[7 * kXchgPitch];
+        other.hitprev = theirs[8 * kXchgPitch];
         if (kOtherAI) {
-            const int32_t w = theirs[9];
+            const int32_t w = theirs[9 * kXchgPitch];
             if (active) {
                 in_other.xd = (w & 3) - 1;
                 in_other.yd = ((w >> 2) & 3) - 1;
