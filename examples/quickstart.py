@@ -32,8 +32,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        # any policy producing int tensors [n] works; here: uniform random for player_1 (player_2 is the AI)
-        actions = {a: torch.randint(0, 13, (n,), dtype=torch.int32, device="cuda:0") for a in env.agents}
+        # any policy producing int32 tensors [n] works; here: the env's own seeded device policy stream for player_1
+        # (player_2 is the rule-based AI; its action entry is read but does not steer it)
+        actions = env.unwrapped.random_actions(action_seed=7)
         obs, rewards, terminations, truncations, infos = env.step(actions)
         done = terminations["player_1"]
         finished += done.sum()
@@ -41,7 +42,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     finished, ret = int(finished), float(ret)
-    print(f"{n * steps / dt / 1e9:.2f} G env-steps/s incl. the torch.randint policy and the bookkeeping; "
+    print(f"{n * steps / dt / 1e9:.2f} G env-steps/s through env.step() incl. the policy launch and the torch bookkeeping "
+          f"(host-bound: five small torch kernels per step); "
           f"{finished} episodes finished, mean return of player_1 {ret / max(finished, 1):+.2f}")
 
     # open-loop throughput: k frames of the on-device random policy per launch, all outputs kept
@@ -54,6 +56,20 @@ def main():
     torch.cuda.synchronize()
     print(f"rollout_random: {n * 32 * 50 / (time.perf_counter() - t0) / 1e9:.2f} G env-steps/s; "
           f"trajectory obs {tuple(out['obs']['player_1'].shape)}")
+
+    # rgb_array frames of a few games, drawn on the GPU from the state.  The sprites are the reference's PNG files:
+    # point sprite_dir at <reference install>/pikazoo/env/img (found by itself when `pikazoo` is importable);
+    # without them this demo falls back to a synthetic sprite set of the same geometry.
+    from pikazoo_amd import render as pz_render
+
+    img_dir = pz_render.default_image_dir()
+    sprites = pz_render.load_sprites(img_dir, "cuda:0") if img_dir else pz_render.synthetic_sprites(0, "cuda:0")
+    viewer = pikazoo_v0.env(num_envs=1024, device="cuda:0", seed=0, render_mode="rgb_array", sprites=sprites,
+                            is_player1_computer=True, is_player2_computer=True)
+    viewer.reset()
+    viewer.step_random(action_seed=3, k=200)
+    frames = viewer.render(lanes=[0, 1, 2, 3])
+    print("render:", tuple(frames.shape), frames.dtype, "(reference sprites)" if img_dir else "(synthetic sprites)")
 
 
 if __name__ == "__main__":
