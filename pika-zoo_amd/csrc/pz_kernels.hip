@@ -397,9 +397,13 @@ __device__ unsigned long long g_pz_stamps[8192 * 8];
 // blocks, bit 9: no computer decision at all.
 #define PZ_SKIP_FRAME ((a.cfg.reserved & 8) != 0)
 #define PZ_SKIP_OBS ((a.cfg.reserved & 16) != 0)
+#define PZ_SKIP_STATE_STORES ((a.cfg.reserved & 1024) != 0)  // pair kernel: no state / reward / flag stores
+#define PZ_SKIP_OBS_STORES ((a.cfg.reserved & 2048) != 0)    // pair kernel: observations staged but not stored
 #else
 #define PZ_SKIP_FRAME false
 #define PZ_SKIP_OBS false
+#define PZ_SKIP_STATE_STORES false
+#define PZ_SKIP_OBS_STORES false
 #endif
 
 // ---- the fused step kernel -------------------------------------------------------------------
@@ -827,7 +831,9 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     PZ_DRAIN_VMEM();
     PZ_PAIR_STAMP(ROLE, 1);
 #ifdef PZ_ABLATE
-    g_pz_ablate_bits = a.cfg.reserved;  // every lane stores the same value; read by the hooks in pz_physics.hpp
+    // read by the hooks in pz_physics.hpp; one lane of the launch writes it (131 072 same-address stores would be the
+    // slowest thing in the kernel), the launches of one variant run back to back with the same bits
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_pz_ablate_bits = a.cfg.reserved;
 #endif
     LandingProbe after_hit{false, false, 0u};
     bool bold_pending = false;  // a human player's new-round boldness draw, made behind the stores
@@ -839,7 +845,23 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
 
     // the two halves of the write-back; their order is a compile-time choice (below)
     auto store_state = [&]() {
-        if (!live) return;
+#ifdef PZ_ABLATE
+        if (live && (a.cfg.reserved & 4096) != 0 && a.episode_stats != nullptr) {
+            // timing-only: what the always-written part of the state would cost as 16-byte column groups: three groups
+            // per wave into a scratch buffer handed in through the (unused) statistics pointer
+            const Rsrc scratch = make_rsrc(a.episode_stats, (uint32_t)(a.stride * 96));
+            const Player& p = ROLE == 0 ? g.p1 : g.p2;
+            const u32x4 w0 = {(uint32_t)p.x, (uint32_t)p.y, (uint32_t)p.yv, (uint32_t)p.frame};
+            const u32x4 w1 = {(uint32_t)p.delay, (uint32_t)p.hitprev, (uint32_t)p.state, (uint32_t)p.arm};
+            const u32x4 w2 = ROLE == 0 ? u32x4{(uint32_t)g.b.x, (uint32_t)g.b.y, (uint32_t)g.b.yv, (uint32_t)g.b.rot}
+                                       : u32x4{(uint32_t)g.b.px, (uint32_t)g.b.py, (uint32_t)g.b.ppx, (uint32_t)g.b.ppy};
+            const uint32_t pitch = (uint32_t)a.stride * 16u;
+            __builtin_amdgcn_raw_buffer_store_b128(w0, scratch, (uint32_t)i * 16u, (uint32_t)(ROLE * 3 + 0) * pitch, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(w1, scratch, (uint32_t)i * 16u, (uint32_t)(ROLE * 3 + 1) * pitch, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(w2, scratch, (uint32_t)i * 16u, (uint32_t)(ROLE * 3 + 2) * pitch, 0);
+        }
+#endif
+        if (!live || PZ_SKIP_STATE_STORES) return;
         // changed-only write-back of the rarely changing columns, as in store_game_changed
         store_player_changed(ROLE == 0 ? g.p1 : g.p2, ROLE == 0 ? loaded.p1 : loaded.p2, io, kOwn);
         if (ROLE == 0) {
@@ -885,6 +907,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         // so only the compiler has to be kept from reordering them -- no second workgroup barrier (7.24 -> 7.12 us).
         wave_lds_handover<false>();
         PZ_PAIR_STAMP(ROLE, 4);
+        if (PZ_SKIP_OBS_STORES) return;
         flush_rows(lds_obs[ROLE], ROLE == 0 ? a.obs_p1 : a.obs_p2, n32 * kRowBytes, lane);
         PZ_PAIR_STAMP(ROLE, 5);
     };

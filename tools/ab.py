@@ -132,19 +132,43 @@ def main():
     for nm in names:
         same = all(torch.equal(a, b) for a, b in zip(finals[nm], finals["base"]))
         print(f"  {nm}: trajectory identical to base: {same}")
+    # The K launches of a round are captured once per variant in a hipGraph and replayed: an eager ctypes launch
+    # costs the host ~7 us, which would hide every kernel faster than that ("--eager" keeps the direct calls).
     K, rounds = 400, 9
+    eager = "--eager" in args
+    side = torch.cuda.Stream()
+    graphs = {}
+    if not eager:
+        stream_holder = [stream]
+        for nm in names:
+            state.copy_(snapshot)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    stream = torch.cuda.current_stream().cuda_stream  # run() launches on the capture stream
+                    frames_per_graph = run(nm, K)
+            stream = stream_holder[0]
+            graphs[nm] = g
     times = {nm: [] for nm in names}
     for _ in range(rounds):
         for nm in names:
             state.copy_(snapshot)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            frames = run(nm, K)
-            e1.record()
+            if eager:
+                e0.record()
+                frames = run(nm, K)
+                e1.record()
+            else:
+                with torch.cuda.stream(side):
+                    e0.record(side)
+                    graphs[nm].replay()
+                    e1.record(side)
+                frames = frames_per_graph
             torch.cuda.synchronize()
             times[nm].append(e0.elapsed_time(e1) * 1e3 / frames)
-    print(f"n={n} p2_computer={ai} wrappers={wrappers} rollout={rollout}: us per "
+    print(f"n={n} p2_computer={ai} wrappers={wrappers} rollout={rollout} {'eager' if eager else 'hipGraph'}: us per "
           f"{'frame' if rollout else 'launch'}, median / min over {rounds} interleaved rounds of {K}")
     for nm in names:
         print(f"  {nm:28s} {statistics.median(times[nm]):7.3f} {min(times[nm]):7.3f}")

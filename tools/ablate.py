@@ -69,11 +69,14 @@ def main():
         for t in range(steps):
             a = acts[t % 64]
             lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
-                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), None, tb, stream)
+                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(),
+                        scratch.data_ptr() if (flags & 4096) else None, tb, stream)
 
     run(0, 600)  # desynchronise the games so divergence is realistic
     snapshot = state.clone()
-    variants = {"baseline": 0, "no_frame": 8, "no_obs": 16, "no_frame_no_obs": 24}
+    variants = {"baseline": 0, "no_state_stores": 1024, "no_obs_stores": 2048, "no_stores": 3072,
+                "wide_fake_state_stores": 1024 + 4096, "wide_fake_state_stores_no_obs": 1024 + 2048 + 4096}
+    scratch = torch.zeros(96 * n, dtype=torch.uint8, device=dev)
     if p2ai:
         variants = {"baseline": 0, "no_frame": 8, "no_landing_A": 32, "no_candidates": 64, "no_landing_B": 128,
                     "no_A_no_B": 160, "no_predictors": 224}
@@ -82,14 +85,28 @@ def main():
                              "no_decision_no_predictors_no_predraw": 512 + 256 + 224, "no_obs": 16})
     times = {k: [] for k in variants}
     K = 300
+    # one hipGraph of K launches per variant (the flag bits travel by value in the kernel arguments): an eager ctypes
+    # launch costs the host ~7 us and would hide every variant faster than that
+    side = torch.cuda.Stream()
+    graphs = {}
+    default_stream = stream
+    for name, flags in variants.items():
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                stream = torch.cuda.current_stream().cuda_stream
+                run(flags, K)
+        stream = default_stream
+        graphs[name] = g
     for rnd in range(7):
         for name, flags in variants.items():
             state.copy_(snapshot)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            run(flags, K)
-            e1.record()
+            with torch.cuda.stream(side):
+                e0.record(side)
+                graphs[name].replay()
+                e1.record(side)
             torch.cuda.synchronize()
             times[name].append(e0.elapsed_time(e1) * 1e3 / K)
     print(f"n={n} p2_computer={p2ai}: microseconds per launch (median / min over 7 interleaved rounds of {K})")
