@@ -75,7 +75,7 @@ struct StateIO {
     {
         return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (uint32_t)group * pitch, 0);
     }
-    __device__ __forceinline__ void st4(int group, u32x4 v) const
+    __device__ __forceinline__ void st4(int group, const u32x4& v) const
     {
         __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, (uint32_t)group * pitch, PZ_STATE_AUX);
     }
@@ -129,102 +129,136 @@ __device__ __forceinline__ FlightLut make_lut(const pz_flight_tables& t)
     return lut;
 }
 
-// ---- state groups <-> registers ------------------------------------------------------------
-// (group contents: include/pikazoo_hip.h; a player's computer_where_to_stand_by lives in env group B)
-__device__ __forceinline__ void player_from_groups(Player& p, u32x4 a, u32x4 b, u32x4 c)
+// ---- state columns <-> registers -----------------------------------------------------------
+__device__ __forceinline__ void load_player(Player& p, const StateIO& io, int c0)
 {
-    p.x = (int)a.x, p.y = (int)a.y, p.yv = (int)a.z, p.frame = (int)a.w;
-    p.delay = (int)b.x, p.hitprev = (int)b.y, p.state = (int)b.z, p.arm = (int)b.w;
-    p.dive = (int)c.x, p.lying = (int)c.y, p.coll = (int)c.z, p.bold = (int)c.w;
+    p.x = io.ld(c0 + PZ_P_X);
+    p.y = io.ld(c0 + PZ_P_Y);
+    p.yv = io.ld(c0 + PZ_P_Y_VELOCITY);
+    p.state = io.ld(c0 + PZ_P_STATE);
+    p.frame = io.ld(c0 + PZ_P_FRAME_NUMBER);
+    p.arm = io.ld(c0 + PZ_P_ARM_SWING_DIRECTION);
+    p.delay = io.ld(c0 + PZ_P_DELAY_BEFORE_NEXT_FRAME);
+    p.dive = io.ld(c0 + PZ_P_DIVING_DIRECTION);
+    p.lying = io.ld(c0 + PZ_P_LYING_DOWN_DURATION_LEFT);
+    p.coll = io.ld(c0 + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED);
+    p.bold = io.ld(c0 + PZ_P_COMPUTER_BOLDNESS);
+    p.standby = io.ld(c0 + PZ_P_COMPUTER_WHERE_TO_STAND_BY);
+    p.hitprev = io.ld(c0 + PZ_P_POWER_HIT_KEY_IS_DOWN_PREVIOUS);
 }
-__device__ __forceinline__ u32x4 player_group_a(const Player& p) { return u32x4{(uint32_t)p.x, (uint32_t)p.y, (uint32_t)p.yv, (uint32_t)p.frame}; }
-__device__ __forceinline__ u32x4 player_group_b(const Player& p) { return u32x4{(uint32_t)p.delay, (uint32_t)p.hitprev, (uint32_t)p.state, (uint32_t)p.arm}; }
-__device__ __forceinline__ u32x4 player_group_c(const Player& p) { return u32x4{(uint32_t)p.dive, (uint32_t)p.lying, (uint32_t)p.coll, (uint32_t)p.bold}; }
-__device__ __forceinline__ void ball_from_groups(Ball& q, u32x4 a, u32x4 t, u32x4 c)
-{
-    q.x = (int)a.x, q.y = (int)a.y, q.yv = (int)a.z, q.rot = (int)a.w;
-    q.px = (int)t.x, q.py = (int)t.y, q.ppx = (int)t.z, q.ppy = (int)t.w;
-    q.xv = (int)c.x, q.power = (int)c.y, q.ex = (int)c.z, q.punch = (int)c.w;
-}
-__device__ __forceinline__ u32x4 ball_group_a(const Ball& q) { return u32x4{(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.yv, (uint32_t)q.rot}; }
-__device__ __forceinline__ u32x4 ball_group_trail(const Ball& q) { return u32x4{(uint32_t)q.px, (uint32_t)q.py, (uint32_t)q.ppx, (uint32_t)q.ppy}; }
-__device__ __forceinline__ u32x4 ball_group_c(const Ball& q) { return u32x4{(uint32_t)q.xv, (uint32_t)q.power, (uint32_t)q.ex, (uint32_t)q.punch}; }
-// env group A: scores, server, draw counter; env group B: round / game flags + both players' stand-by words
-__device__ __forceinline__ void env_from_groups(Game& g, u32x4 a, u32x4 b)
-{
-    g.e.s1 = (int)a.x, g.e.s2 = (int)a.y, g.e.p2serve = (int)a.z, g.e.rng = a.w;
-    g.e.round_ended = (int)b.x, g.e.game_ended = (int)b.y, g.p1.standby = (int)b.z, g.p2.standby = (int)b.w;
-}
-__device__ __forceinline__ u32x4 env_group_a(const Game& g) { return u32x4{(uint32_t)g.e.s1, (uint32_t)g.e.s2, (uint32_t)g.e.p2serve, g.e.rng}; }
-__device__ __forceinline__ u32x4 env_group_b(const Game& g)
-{
-    return u32x4{(uint32_t)g.e.round_ended, (uint32_t)g.e.game_ended, (uint32_t)g.p1.standby, (uint32_t)g.p2.standby};
-}
-__device__ __forceinline__ bool differs(u32x4 a, u32x4 b) { return (a.x != b.x) | (a.y != b.y) | (a.z != b.z) | (a.w != b.w); }
 
 __device__ __forceinline__ void load_game(Game& g, const StateIO& io)
 {
     // env + ball first: the frame starts with the round bookkeeping and the ball-world step
-    const u32x4 ea = io.ld4(kGroupEnvA), eb = io.ld4(kGroupEnvB);
-    const u32x4 ba = io.ld4(kGroupBallA), bt = io.ld4(kGroupBallTrail), bc = io.ld4(kGroupBallC);
-    const u32x4 a1 = io.ld4(kGroupPlayerA), b1 = io.ld4(kGroupPlayerB), c1 = io.ld4(kGroupPlayerC);
-    const u32x4 a2 = io.ld4(3 + kGroupPlayerA), b2 = io.ld4(3 + kGroupPlayerB), c2 = io.ld4(3 + kGroupPlayerC);
-    player_from_groups(g.p1, a1, b1, c1);
-    player_from_groups(g.p2, a2, b2, c2);
-    ball_from_groups(g.b, ba, bt, bc);
-    env_from_groups(g, ea, eb);
+    g.e.round_ended = io.ld(PZ_E_ROUND_ENDED);
+    g.e.game_ended = io.ld(PZ_E_GAME_ENDED);
+    g.e.rng = (uint32_t)io.ld(PZ_E_RNG_DRAW_COUNTER);
+    g.e.s1 = io.ld(PZ_E_SCORE_P1);
+    g.e.s2 = io.ld(PZ_E_SCORE_P2);
+    g.e.p2serve = io.ld(PZ_E_IS_PLAYER2_SERVE);
+    g.b.x = io.ld(PZ_B_X);
+    g.b.y = io.ld(PZ_B_Y);
+    g.b.xv = io.ld(PZ_B_X_VELOCITY);
+    g.b.yv = io.ld(PZ_B_Y_VELOCITY);
+    g.b.power = io.ld(PZ_B_IS_POWER_HIT);
+    g.b.px = io.ld(PZ_B_PREVIOUS_X);
+    g.b.py = io.ld(PZ_B_PREVIOUS_Y);
+    g.b.ppx = io.ld(PZ_B_PREVIOUS_PREVIOUS_X);
+    g.b.ppy = io.ld(PZ_B_PREVIOUS_PREVIOUS_Y);
+    g.b.rot = io.ld(PZ_B_FINE_ROTATION);
+    g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);
+    g.b.punch = io.ld(PZ_B_PUNCH_EFFECT_X);
+    load_player(g.p1, io, 0);
+    load_player(g.p2, io, PZ_P_WORDS);
 }
 
-// skip_ex: the lane's expected_landing_point_x is stored by the scout wave (step_games<..., SCOUT>), a dword store
-// of another wave into ball group C: such a lane stores the group's other three words one by one
-__device__ __forceinline__ void store_ball_group_c(const Ball& q, const StateIO& io, bool skip_ex)
+__device__ __forceinline__ void store_player(const Player& p, const StateIO& io, int c0)
 {
-    if (!skip_ex) {
-        io.st4(kGroupBallC, ball_group_c(q));
-    } else {
-        io.st(PZ_B_X_VELOCITY, q.xv);
-        io.st(PZ_B_IS_POWER_HIT, q.power);
-        io.st(PZ_B_PUNCH_EFFECT_X, q.punch);
-    }
+    io.st(c0 + PZ_P_X, p.x);
+    io.st(c0 + PZ_P_Y, p.y);
+    io.st(c0 + PZ_P_Y_VELOCITY, p.yv);
+    io.st(c0 + PZ_P_STATE, p.state);
+    io.st(c0 + PZ_P_FRAME_NUMBER, p.frame);
+    io.st(c0 + PZ_P_ARM_SWING_DIRECTION, p.arm);
+    io.st(c0 + PZ_P_DELAY_BEFORE_NEXT_FRAME, p.delay);
+    io.st(c0 + PZ_P_DIVING_DIRECTION, p.dive);
+    io.st(c0 + PZ_P_LYING_DOWN_DURATION_LEFT, p.lying);
+    io.st(c0 + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED, p.coll);
+    io.st(c0 + PZ_P_COMPUTER_BOLDNESS, p.bold);
+    io.st(c0 + PZ_P_COMPUTER_WHERE_TO_STAND_BY, p.standby);
+    io.st(c0 + PZ_P_POWER_HIT_KEY_IS_DOWN_PREVIOUS, p.hitprev);
 }
 
+// skip_ex: the lane's expected_landing_point_x is stored by the scout wave (step_games<..., SCOUT>)
 __device__ __forceinline__ void store_game(const Game& g, const StateIO& io, bool skip_ex = false)
 {
-    io.st4(kGroupPlayerA, player_group_a(g.p1));
-    io.st4(kGroupPlayerB, player_group_b(g.p1));
-    io.st4(kGroupPlayerC, player_group_c(g.p1));
-    io.st4(3 + kGroupPlayerA, player_group_a(g.p2));
-    io.st4(3 + kGroupPlayerB, player_group_b(g.p2));
-    io.st4(3 + kGroupPlayerC, player_group_c(g.p2));
-    io.st4(kGroupBallA, ball_group_a(g.b));
-    io.st4(kGroupBallTrail, ball_group_trail(g.b));
-    store_ball_group_c(g.b, io, skip_ex);
-    io.st4(kGroupEnvA, env_group_a(g));
-    io.st4(kGroupEnvB, env_group_b(g));
+    store_player(g.p1, io, 0);
+    store_player(g.p2, io, PZ_P_WORDS);
+    io.st(PZ_B_X, g.b.x);
+    io.st(PZ_B_Y, g.b.y);
+    io.st(PZ_B_X_VELOCITY, g.b.xv);
+    io.st(PZ_B_Y_VELOCITY, g.b.yv);
+    io.st(PZ_B_IS_POWER_HIT, g.b.power);
+    io.st(PZ_B_PREVIOUS_X, g.b.px);
+    io.st(PZ_B_PREVIOUS_Y, g.b.py);
+    io.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
+    io.st(PZ_B_PREVIOUS_PREVIOUS_Y, g.b.ppy);
+    io.st(PZ_B_FINE_ROTATION, g.b.rot);
+    if (!skip_ex) io.st(PZ_B_EXPECTED_LANDING_POINT_X, g.b.ex);
+    io.st(PZ_B_PUNCH_EFFECT_X, g.b.punch);
+    io.st(PZ_E_SCORE_P1, g.e.s1);
+    io.st(PZ_E_SCORE_P2, g.e.s2);
+    io.st(PZ_E_IS_PLAYER2_SERVE, g.e.p2serve);
+    io.st(PZ_E_ROUND_ENDED, g.e.round_ended);
+    io.st(PZ_E_GAME_ENDED, g.e.game_ended);
+    io.st(PZ_E_RNG_DRAW_COUNTER, (int32_t)g.e.rng);
 }
 
-// Changed-only write-back, used by every launch that writes the state back after ONE frame.  The six groups of
-// words that change on nearly every frame are stored unconditionally; the five groups of words that change
-// rarely (diving / lying state, collision debounce, boldness; ball x velocity, power-hit flag, landing point,
-// punch x; scores, server, draw counter; round / game flags, stand-by words) are stored only by the lanes where
-// one of their words changed, and not at all when no lane of the wave changed -- most of their 32-byte sectors are
-// untouched by a frame of random play.  Measured (round 1, per-column form): -10 % per launch at 524 288 games,
-// -5 % at 65 536 in the pair kernel.
+// Changed-only write-back, used by every launch that writes the state back after ONE frame.  Columns
+// that change on nearly every frame are stored unconditionally; the 24 columns that change rarely
+// (scores, flags, boldness, diving/lying state, collision debounce, ball x velocity ...: on average
+// 80 % of their 32-byte sectors are untouched by a frame of random play) are stored only by the lanes
+// whose value changed, and not at all when no lane of the wave changed.  Measured: -10 % per launch at
+// 524 288 games, -5 % at 65 536 in the pair kernel (7.91 -> 7.48 us).
+__device__ __forceinline__ void store_player_changed(const Player& p, const Player& o, const StateIO& io, int c0)
+{
+    io.st(c0 + PZ_P_X, p.x);
+    io.st(c0 + PZ_P_Y, p.y);
+    io.st(c0 + PZ_P_Y_VELOCITY, p.yv);
+    io.st(c0 + PZ_P_FRAME_NUMBER, p.frame);
+    io.st(c0 + PZ_P_DELAY_BEFORE_NEXT_FRAME, p.delay);
+    io.st(c0 + PZ_P_POWER_HIT_KEY_IS_DOWN_PREVIOUS, p.hitprev);
+    if (p.state != o.state) io.st(c0 + PZ_P_STATE, p.state);
+    if (p.arm != o.arm) io.st(c0 + PZ_P_ARM_SWING_DIRECTION, p.arm);
+    if (p.dive != o.dive) io.st(c0 + PZ_P_DIVING_DIRECTION, p.dive);
+    if (p.lying != o.lying) io.st(c0 + PZ_P_LYING_DOWN_DURATION_LEFT, p.lying);
+    if (p.coll != o.coll) io.st(c0 + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED, p.coll);
+    if (p.bold != o.bold) io.st(c0 + PZ_P_COMPUTER_BOLDNESS, p.bold);
+    if (p.standby != o.standby) io.st(c0 + PZ_P_COMPUTER_WHERE_TO_STAND_BY, p.standby);
+}
+
 __device__ __forceinline__ void store_game_changed(const Game& g, const Game& o, const StateIO& io, bool skip_ex = false)
 {
-    io.st4(kGroupPlayerA, player_group_a(g.p1));
-    io.st4(kGroupPlayerB, player_group_b(g.p1));
-    io.st4(3 + kGroupPlayerA, player_group_a(g.p2));
-    io.st4(3 + kGroupPlayerB, player_group_b(g.p2));
-    io.st4(kGroupBallA, ball_group_a(g.b));
-    io.st4(kGroupBallTrail, ball_group_trail(g.b));
-    if (differs(player_group_c(g.p1), player_group_c(o.p1))) io.st4(kGroupPlayerC, player_group_c(g.p1));
-    if (differs(player_group_c(g.p2), player_group_c(o.p2))) io.st4(3 + kGroupPlayerC, player_group_c(g.p2));
-    u32x4 now = ball_group_c(g.b);
-    if (skip_ex) now.z = (uint32_t)o.b.ex;  // the landing point is the scout's to store: leave it out of the comparison
-    if (differs(now, ball_group_c(o.b))) store_ball_group_c(g.b, io, skip_ex);
-    if (differs(env_group_a(g), env_group_a(o))) io.st4(kGroupEnvA, env_group_a(g));
-    if (differs(env_group_b(g), env_group_b(o))) io.st4(kGroupEnvB, env_group_b(g));
+    store_player_changed(g.p1, o.p1, io, 0);
+    store_player_changed(g.p2, o.p2, io, PZ_P_WORDS);
+    io.st(PZ_B_X, g.b.x);
+    io.st(PZ_B_Y, g.b.y);
+    io.st(PZ_B_Y_VELOCITY, g.b.yv);
+    io.st(PZ_B_PREVIOUS_X, g.b.px);
+    io.st(PZ_B_PREVIOUS_Y, g.b.py);
+    io.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
+    io.st(PZ_B_PREVIOUS_PREVIOUS_Y, g.b.ppy);
+    io.st(PZ_B_FINE_ROTATION, g.b.rot);
+    if (g.b.xv != o.b.xv) io.st(PZ_B_X_VELOCITY, g.b.xv);
+    if (g.b.power != o.b.power) io.st(PZ_B_IS_POWER_HIT, g.b.power);
+    if (g.b.ex != o.b.ex && !skip_ex) io.st(PZ_B_EXPECTED_LANDING_POINT_X, g.b.ex);
+    if (g.b.punch != o.b.punch) io.st(PZ_B_PUNCH_EFFECT_X, g.b.punch);
+    if (g.e.s1 != o.e.s1) io.st(PZ_E_SCORE_P1, g.e.s1);
+    if (g.e.s2 != o.e.s2) io.st(PZ_E_SCORE_P2, g.e.s2);
+    if (g.e.p2serve != o.e.p2serve) io.st(PZ_E_IS_PLAYER2_SERVE, g.e.p2serve);
+    if (g.e.round_ended != o.e.round_ended) io.st(PZ_E_ROUND_ENDED, g.e.round_ended);
+    if (g.e.game_ended != o.e.game_ended) io.st(PZ_E_GAME_ENDED, g.e.game_ended);
+    if (g.e.rng != o.e.rng) io.st(PZ_E_RNG_DRAW_COUNTER, (int32_t)g.e.rng);
 }
 
 __device__ __forceinline__ RngId make_rng_id(const pz_config& cfg, int64_t lane_index)
@@ -756,19 +790,16 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
 
 // ---- the pair kernel: two waves per 64 games, split by player (see step_games_pair) ---------------
 // Used for single-frame launches below PZ_TWO_WAVE_MAX_LANES games: human-vs-human (the bench headline)
-// and, when flight tables are passed, every computer-player configuration.  Division of the 11 state groups:
-//   both waves load   ball A / trail / C, env A / B, the partner's group C (its collision flag)
-//   wave ROLE loads   its own player's groups A, B, C (+ what its computer player's decision reads of the partner)
-//   wave 0 stores     player 1 A, B, (C); ball A; (env A), (env B); episode statistics, `terminated`
-//   wave 1 stores     player 2 A, B, (C); ball trail; (ball C -- incl. expected_landing_point_x)
-// (parenthesised: only by lanes where a word of the group changed); each wave writes its own agent's reward and
-// observation tensor.  Nine 16-byte loads and three to seven 16-byte stores per wave instead of 32 + 27 dwords.
+// and, when flight tables are passed, every computer-player configuration.  Wave ROLE loads/stores its own
+// player's 13 columns, its half of the ball columns (both waves load all 12), player 1's wave also the 6
+// env columns, the episode statistics and `terminated`; each wave writes its own agent's reward and
+// observation tensor; the wave of the (last) computer player keeps ball.expected_landing_point_x.
 template <int ROLE, bool AI1, bool AI2>
 __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, int32_t (*lds_obs)[kLanes * PZ_OBS_DIM],
                                           int32_t* __restrict__ xchg, int lane)
 {
     constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
-    constexpr bool kKeepsEx = (AI1 || AI2) && ROLE == 1;
+    constexpr bool kKeepsEx = (AI1 || AI2) && (ROLE == 1 ? AI2 : !AI2);
     const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
     const bool live = i < hot.n;
     const uint32_t n32 = (uint32_t)hot.n;
@@ -776,7 +807,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     const bool as_float = a.cfg.ballpos_reward != 0 || a.cfg.normal_state_mode != 0;
     const bool with_stats = ROLE == 0 && a.episode_stats != nullptr && a.cfg.episode_stats_mode != 0;
     const StatsIO sio = make_stats_io(a.episode_stats, with_stats, a.stride, i);
-    constexpr int kOwnGroups = 3 * ROLE, kOtherGroups = 3 * (1 - ROLE);
+    constexpr int kOwn = ROLE * PZ_P_WORDS, kOther = (1 - ROLE) * PZ_P_WORDS;
 
     Game g{};
     const RngId id = make_rng_id(a.cfg, live ? i : 0);
@@ -786,24 +817,36 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     const int a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.lane4, 0, 0);
     EpisodeStats st{0.0, 0.0, 0};
     if (live) {
-        Player& own = ROLE == 0 ? g.p1 : g.p2;
+        g.e.round_ended = io.ld(PZ_E_ROUND_ENDED);
+        g.e.game_ended = io.ld(PZ_E_GAME_ENDED);
+        g.e.rng = (uint32_t)io.ld(PZ_E_RNG_DRAW_COUNTER);
+        g.e.s1 = io.ld(PZ_E_SCORE_P1);
+        g.e.s2 = io.ld(PZ_E_SCORE_P2);
+        g.e.p2serve = io.ld(PZ_E_IS_PLAYER2_SERVE);
+        g.b.x = io.ld(PZ_B_X);
+        g.b.y = io.ld(PZ_B_Y);
+        g.b.xv = io.ld(PZ_B_X_VELOCITY);
+        g.b.yv = io.ld(PZ_B_Y_VELOCITY);
+        g.b.power = io.ld(PZ_B_IS_POWER_HIT);
+        g.b.px = io.ld(PZ_B_PREVIOUS_X);
+        g.b.py = io.ld(PZ_B_PREVIOUS_Y);
+        g.b.ppx = io.ld(PZ_B_PREVIOUS_PREVIOUS_X);
+        g.b.ppy = io.ld(PZ_B_PREVIOUS_PREVIOUS_Y);
+        g.b.rot = io.ld(PZ_B_FINE_ROTATION);
+        if (kKeepsEx) g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);
+        g.b.punch = io.ld(PZ_B_PUNCH_EFFECT_X);
+        load_player(ROLE == 0 ? g.p1 : g.p2, io, kOwn);
         Player& other = ROLE == 0 ? g.p2 : g.p1;
-        const u32x4 ea = io.ld4(kGroupEnvA), eb = io.ld4(kGroupEnvB);
-        const u32x4 ba = io.ld4(kGroupBallA), bt = io.ld4(kGroupBallTrail), bc = io.ld4(kGroupBallC);
-        const u32x4 pa = io.ld4(kOwnGroups + kGroupPlayerA), pb = io.ld4(kOwnGroups + kGroupPlayerB),
-                    pc = io.ld4(kOwnGroups + kGroupPlayerC);
-        const u32x4 oc = io.ld4(kOtherGroups + kGroupPlayerC);
-        player_from_groups(own, pa, pb, pc);
-        other.dive = (int)oc.x, other.lying = (int)oc.y, other.coll = (int)oc.z, other.bold = (int)oc.w;
-        // the decision reads the other player's x -- player 2's after player 1's move, recomputed from x, state and
-        // diving direction when player 1 is human (step_games_pair)
-        if (kOwnAI && (ROLE == 0 || !AI1)) other.x = (int)io.ld4(kOtherGroups + kGroupPlayerA).x;
-        if (kOwnAI && ROLE == 1 && !AI1) other.state = (int)io.ld4(kOtherGroups + kGroupPlayerB).z;
-        ball_from_groups(g.b, ba, bt, bc);
-        env_from_groups(g, ea, eb);
+        other.coll = io.ld(kOther + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED);
+        if (kOwnAI && ROLE == 0) other.x = io.ld(kOther + PZ_P_X);  // the decision reads the other player's x
+        if (kOwnAI && ROLE == 1 && !AI1) {  // ... player 2's after player 1's move: recomputed from these
+            other.x = io.ld(kOther + PZ_P_X);
+            other.state = io.ld(kOther + PZ_P_STATE);
+            other.dive = io.ld(kOther + PZ_P_DIVING_DIRECTION);
+        }
         if (with_stats) sio.load(st);
     }
-    const Game loaded = g;  // what the groups held before the frame
+    const Game loaded = g;  // what the columns held before the frame
     const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     bool frozen = false;
     PZ_DRAIN_VMEM();
@@ -821,31 +864,49 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
     PZ_PAIR_STAMP(ROLE, 2);
 
-    const Player& own = ROLE == 0 ? g.p1 : g.p2;
-    const Player& own_before = ROLE == 0 ? loaded.p1 : loaded.p2;
-    // groups that are finished behind the other stores: the own player's group C when its boldness is still to be
-    // drawn, ball group C when the landing point after a ball-player collision is still in flight
-    const bool ball_c_late = kKeepsEx && after_hit.wanted;
-
     // the two halves of the write-back; their order is a compile-time choice (below)
     auto store_state = [&]() {
+#ifdef PZ_ABLATE
+        if (live && (a.cfg.reserved & 4096) != 0 && a.episode_stats != nullptr) {
+            // timing-only: what the always-written part of the state would cost as 16-byte column groups: three groups
+            // per wave into a scratch buffer handed in through the (unused) statistics pointer
+            const Rsrc scratch = make_rsrc(a.episode_stats, (uint32_t)(a.stride * 96));
+            const Player& p = ROLE == 0 ? g.p1 : g.p2;
+            const u32x4 w0 = {(uint32_t)p.x, (uint32_t)p.y, (uint32_t)p.yv, (uint32_t)p.frame};
+            const u32x4 w1 = {(uint32_t)p.delay, (uint32_t)p.hitprev, (uint32_t)p.state, (uint32_t)p.arm};
+            const u32x4 w2 = ROLE == 0 ? u32x4{(uint32_t)g.b.x, (uint32_t)g.b.y, (uint32_t)g.b.yv, (uint32_t)g.b.rot}
+                                       : u32x4{(uint32_t)g.b.px, (uint32_t)g.b.py, (uint32_t)g.b.ppx, (uint32_t)g.b.ppy};
+            const uint32_t pitch = (uint32_t)a.stride * 16u;
+            __builtin_amdgcn_raw_buffer_store_b128(w0, scratch, (uint32_t)i * 16u, (uint32_t)(ROLE * 3 + 0) * pitch, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(w1, scratch, (uint32_t)i * 16u, (uint32_t)(ROLE * 3 + 1) * pitch, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(w2, scratch, (uint32_t)i * 16u, (uint32_t)(ROLE * 3 + 2) * pitch, 0);
+        }
+#endif
         if (!live || PZ_SKIP_STATE_STORES) return;
-        // changed-only write-back of the rarely changing groups, as in store_game_changed
-        io.st4(kOwnGroups + kGroupPlayerA, player_group_a(own));
-        io.st4(kOwnGroups + kGroupPlayerB, player_group_b(own));
-        if (!bold_pending && differs(player_group_c(own), player_group_c(own_before)))
-            io.st4(kOwnGroups + kGroupPlayerC, player_group_c(own));
+        // changed-only write-back of the rarely changing columns, as in store_game_changed
+        store_player_changed(ROLE == 0 ? g.p1 : g.p2, ROLE == 0 ? loaded.p1 : loaded.p2, io, kOwn);
         if (ROLE == 0) {
-            io.st4(kGroupBallA, ball_group_a(g.b));
-            if (differs(env_group_a(g), env_group_a(loaded))) io.st4(kGroupEnvA, env_group_a(g));
-            if (differs(env_group_b(g), env_group_b(loaded))) io.st4(kGroupEnvB, env_group_b(g));
+            io.st(PZ_B_X, g.b.x);
+            io.st(PZ_B_Y, g.b.y);
+            io.st(PZ_B_Y_VELOCITY, g.b.yv);
+            if (g.b.xv != loaded.b.xv) io.st(PZ_B_X_VELOCITY, g.b.xv);
+            if (g.b.power != loaded.b.power) io.st(PZ_B_IS_POWER_HIT, g.b.power);
+            if (g.b.punch != loaded.b.punch) io.st(PZ_B_PUNCH_EFFECT_X, g.b.punch);
+            if (g.e.s1 != loaded.e.s1) io.st(PZ_E_SCORE_P1, g.e.s1);
+            if (g.e.s2 != loaded.e.s2) io.st(PZ_E_SCORE_P2, g.e.s2);
+            if (g.e.p2serve != loaded.e.p2serve) io.st(PZ_E_IS_PLAYER2_SERVE, g.e.p2serve);
+            if (g.e.round_ended != loaded.e.round_ended) io.st(PZ_E_ROUND_ENDED, g.e.round_ended);
+            if (g.e.game_ended != loaded.e.game_ended) io.st(PZ_E_GAME_ENDED, g.e.game_ended);
+            if (g.e.rng != loaded.e.rng) io.st(PZ_E_RNG_DRAW_COUNTER, (int32_t)g.e.rng);
             if (with_stats) sio.store(st);
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, make_rsrc(a.terminated, n32),
                                                  (uint32_t)i, 0, 0);
         } else {
-            io.st4(kGroupBallTrail, ball_group_trail(g.b));
-            // (without a computer player expected_landing_point_x never changes: the loaded value is written back)
-            if (!ball_c_late && differs(ball_group_c(g.b), ball_group_c(loaded.b))) io.st4(kGroupBallC, ball_group_c(g.b));
+            io.st(PZ_B_PREVIOUS_X, g.b.px);
+            io.st(PZ_B_PREVIOUS_Y, g.b.py);
+            io.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
+            io.st(PZ_B_PREVIOUS_PREVIOUS_Y, g.b.ppy);
+            io.st(PZ_B_FINE_ROTATION, g.b.rot);
         }
         const Rsrc rew = make_rsrc(ROLE == 0 ? a.rew_p1 : a.rew_p2, n32 * 4u);
         const unsigned int bits = as_float ? __float_as_uint(ROLE == 0 ? rw.f1 : rw.f2)
@@ -885,14 +946,12 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     PZ_PAIR_STAMP(ROLE, 6);
     if (bold_pending) {  // draw number loaded.rng + ROLE of the env stream: player 1's, then player 2's (physics.py:218)
         uint32_t counter = loaded.e.rng + (uint32_t)ROLE;
-        u32x4 c = player_group_c(own);
-        c.w = (uint32_t)rng_integers(id, counter, 5u);
-        io.st4(kOwnGroups + kGroupPlayerC, c);
+        io.st(kOwn + PZ_P_COMPUTER_BOLDNESS, rng_integers(id, counter, 5u));
     }
-    // last: after a ball-player collision the landing point comes from a table gather issued at the end of the frame
-    if (ball_c_late) {
-        g.b.ex = lut.landing_finish(after_hit, g.b.x, g.b.y, g.b.xv, g.b.yv, g.b.ex);
-        io.st4(kGroupBallC, ball_group_c(g.b));
+    // last: after a ball-player collision the value comes from a table gather issued at the end of the frame
+    if (kKeepsEx) {
+        const int ex = lut.landing_finish(after_hit, g.b.x, g.b.y, g.b.xv, g.b.yv, g.b.ex);
+        if (live && ex != loaded.b.ex) io.st(PZ_B_EXPECTED_LANDING_POINT_X, ex);
     }
 }
 

@@ -58,23 +58,15 @@ constexpr int kNetTopTopY = 176;
 constexpr int kNetTopBottomY = 192;
 constexpr int kLoopLimit = 1000;
 
-// (members in the order of the state's 16-byte groups, include/pikazoo_hip.h: a group is four adjacent members, which
-// lets the compiler keep the structs in registers across the vector loads / stores)
 struct Player {
-    int x, y, yv, frame;              // group A
-    int delay, hitprev, state, arm;   // group B
-    int dive, lying, coll, bold;      // group C
-    int standby;                      // (env group B)
+    int x, y, yv, state, frame, arm, delay, dive, lying, coll, bold, standby, hitprev;
 };
 struct Ball {
-    int x, y, yv, rot;        // group A
-    int px, py, ppx, ppy;     // trail
-    int xv, power, ex, punch; // group C
+    int x, y, xv, yv, power, px, py, ppx, ppy, rot, ex, punch;
 };
 struct Env {
-    int s1, s2, p2serve;
+    int s1, s2, p2serve, round_ended, game_ended;
     uint32_t rng;  // env-stream draw counter
-    int round_ended, game_ended;
 };
 struct Game {
     Player p1, p2;
@@ -1138,14 +1130,13 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
 //   * the decided (x_direction, y_direction) travel with the player too: the ball-player collision takes
 //     the power hit's direction from them (physics.py:329 passes the mutated user_input).
 // The flight predictions come from `lut` (tables or, outside their domain, the computed form); the wave
-// of player 2 keeps ball.expected_landing_point_x whenever a computer plays (kKeepsEx: it owns ball group C) and hands
-// the look-up of its value after a ball-player collision back to the caller (`after_hit`, finished behind the caller's
-// stores).
+// that owns the (last) computer player keeps ball.expected_landing_point_x (kKeepsEx) and hands the look-up of its
+// value after a ball-player collision back to the caller (`after_hit`, finished behind the caller's stores).
 // xchg: two regions of LDS, `xchg_region` words apart; a wave writes into the PARTNER's region and reads
 // from its own, so a wave may reuse its own region afterwards without asking (the pair kernel aliases them
 // with the observation staging rows).  One __syncthreads(), two when both players are computers.
 // ---------------------------------------------------------------------------------------
-constexpr int kXchgPitch = 64;      // exchange word k of lane l lives at [k * 64 + l] (9 player words, decision, stand-by)
+constexpr int kXchgPitch = 64;      // exchange word k of lane l lives at [k * 64 + l] (10 words: 9 player + decision)
 constexpr int kEarlyPostAt = 1024;  // word offset of the early post {x, draws} inside a region (2 x 64 words)
 
 template <int ROLE, bool AI1, bool AI2>
@@ -1155,7 +1146,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
 {
     constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
     constexpr bool kOtherAI = ROLE == 0 ? AI2 : AI1;
-    constexpr bool kKeepsEx = (AI1 || AI2) && ROLE == 1;  // player 2's wave owns ball group C (landing point included)
+    constexpr bool kKeepsEx = (AI1 || AI2) && (ROLE == 1 ? AI2 : !AI2);
     Player& own = ROLE == 0 ? g.p1 : g.p2;
     Player& other = ROLE == 0 ? g.p2 : g.p1;
     frozen = live && g.e.game_ended && !cfg.auto_reset;
@@ -1259,7 +1250,6 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
                 draws_own = computer_decide_predrawn<ROLE == 1>(own, g.b, other.x, pre, scan, ex, in_own);
         }
     }
-    if (!kOwnAI && kKeepsEx && active) g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);  // (only player 1 is a computer)
     if (active) player_move<ROLE == 1>(own, in_own);
     PZ_FRAME_STAMP(4);
     if (ROLE == 0 && AI1 && AI2) {
@@ -1285,7 +1275,6 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
         mine[7 * kXchgPitch] = own.lying;
         mine[8 * kXchgPitch] = own.hitprev;
         if (kOwnAI) mine[9 * kXchgPitch] = (in_own.xd + 1) | ((in_own.yd + 1) << 2) | (int32_t)(draws_own << 4);
-        if (kOwnAI && ROLE == 1) mine[10 * kXchgPitch] = own.standby;  // env group B is player 1's wave's to store
     }
     __syncthreads();
     if (live) {
@@ -1299,7 +1288,6 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
         other.dive = theirs[6 * kXchgPitch];
         other.lying = theirs[7 * kXchgPitch];
         other.hitprev = theirs[8 * kXchgPitch];
-        if (kOtherAI && ROLE == 0) other.standby = theirs[10 * kXchgPitch];
         if (kOtherAI) {
             const int32_t w = theirs[9 * kXchgPitch];
             if (active) {
