@@ -132,7 +132,7 @@ def run_gpu(env, acts, warmup, steps, launch, min_time):
     raw = env.unwrapped
     lib = _native.load()
     n = raw.num_envs
-    st, cfg = raw.state_ptr, raw._cfg_ref
+    st, cfg = raw.state.data_ptr(), raw._cfg_ref
     o1, o2 = raw._obs[0].data_ptr(), raw._obs[1].data_ptr()
     r1, r2, tm = raw._rew_raw[0].data_ptr(), raw._rew_raw[1].data_ptr(), raw._term_u8.data_ptr()
     tables = raw._tables_ref

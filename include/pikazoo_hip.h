@@ -14,13 +14,8 @@
  *    distinct state buffers are thread-safe;
  *  - all calls are asynchronous on `stream`;
  *  - return value: 0 = ok, negative = PZ_E_* argument error, positive = hipError_t;
- *  - state is 44 int32 words per game, stored as PZ_STATE_GROUPS = 11 arrays of 16-byte groups:
- *    int32[11][stride][4].  Game i (one GPU lane) owns element i of every array; `n` games are live,
- *    stride >= n.  Which word sits where: pz_state_slot[] below (the enums name the 44 words in their logical
- *    order -- the order of the [44, n] view the Python host exposes -- and PZ_STATE_OFFSET(word, stride, i)
- *    gives a word's position in the buffer).  A wave reads / writes one group of its 64 games with ONE 16-byte
- *    vector-memory instruction (1 KiB, fully coalesced); words that change every frame share groups, words that
- *    rarely change share others, so that a frame writes back only the groups that changed;
+ *  - state is int32[PZ_STATE_WORDS][stride], field-major (structure of arrays): lane i
+ *    (one independent game) owns column i; `n` lanes are live, stride >= n;
  *  - observations are int32[n][35] row-major per agent (pikazoo_env.py:576-624);
  *  - out-of-range actions are undefined behaviour here (the reference raises IndexError at
  *    pikazoo_env.py:182); the Python host validates them unless told not to.
@@ -34,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PZ_ABI_VERSION 5
+#define PZ_ABI_VERSION 4
 #define PZ_STATE_WORDS 44
 #define PZ_OBS_DIM 35
 
@@ -59,32 +54,6 @@ enum pz_env_field {
     PZ_E_SCORE_P1 = 38, PZ_E_SCORE_P2, PZ_E_IS_PLAYER2_SERVE, PZ_E_ROUND_ENDED,
     PZ_E_GAME_ENDED, PZ_E_RNG_DRAW_COUNTER
 };
-
-/* ---- physical layout of the state: 11 groups x 4 words ------------------------------------
- *  group  0 / 3   player 1 / 2: x, y, y_velocity, frame_number                  (change every frame)
- *  group  1 / 4   player 1 / 2: delay_before_next_frame, power_hit_key_is_down_previous, state, arm_swing_direction
- *  group  2 / 5   player 1 / 2: diving_direction, lying_down_duration_left, is_collision_with_ball_happened,
- *                               computer_boldness                                (rarely change)
- *  group  6       ball: x, y, y_velocity, fine_rotation                          (every frame)
- *  group  7       ball: previous_x, previous_y, previous_previous_x, previous_previous_y   (every frame)
- *  group  8       ball: x_velocity, is_power_hit, expected_landing_point_x, punch_effect_x  (rarely)
- *  group  9       env: score 1, score 2, is_player2_serve, rng_draw_counter      (rarely)
- *  group 10       env: round_ended, game_ended; computer_where_to_stand_by of player 1, of player 2 (rarely)
- * pz_state_slot[w] = 4 * group + position of logical word w (w = the enum values above). */
-#define PZ_STATE_GROUPS 11
-#define PZ_STATE_SLOT_LIST                                                                                  \
-    /* player 1: x y yv state frame arm delay dive lying coll bold standby hitprev */                       \
-    0, 1, 2, 6, 3, 7, 4, 8, 9, 10, 11, 42, 5,                                                               \
-    /* player 2 */                                                                                          \
-    12, 13, 14, 18, 15, 19, 16, 20, 21, 22, 23, 43, 17,                                                     \
-    /* ball: x y xv yv power px py ppx ppy rot ex punch */                                                  \
-    24, 25, 32, 26, 33, 28, 29, 30, 31, 27, 34, 35,                                                         \
-    /* env: s1 s2 p2serve round_ended game_ended rng */                                                     \
-    36, 37, 38, 40, 41, 39
-static const unsigned char pz_state_slot[PZ_STATE_WORDS] = {PZ_STATE_SLOT_LIST};
-/* int32 index of logical word `w` of game `i` in a state buffer of pitch `stride` */
-#define PZ_STATE_OFFSET(w, stride, i) \
-    ((int64_t)(pz_state_slot[w] >> 2) * (stride) * 4 + (int64_t)(i) * 4 + (pz_state_slot[w] & 3))
 
 enum pz_serve_mode { PZ_SERVE_WINNER = 0, PZ_SERVE_ALTERNATE = 1, PZ_SERVE_RANDOM = 2 };
 

@@ -47,45 +47,20 @@ __device__ __forceinline__ Rsrc make_rsrc(const void* p, uint32_t bytes)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
 }
 
-// One game's state accessor (layout: include/pikazoo_hip.h -- int32[11 groups][stride][4]): wave-uniform descriptor
-// + group pitch, per-lane byte offset.  A group of the wave's 64 games is ONE 16-byte-per-lane instruction (1 KiB,
-// contiguous); single words stay addressable (a dword at 16-byte lane stride) for the rare paths.
-constexpr unsigned char kSlot[PZ_STATE_WORDS] = {PZ_STATE_SLOT_LIST};  // word -> 4 * group + position
-// groups (see the header): players' A / B / C at 0..2 and 3..5, ball 6..8, env 9..10
-enum StateGroup { kGroupPlayerA = 0, kGroupPlayerB = 1, kGroupPlayerC = 2, kGroupBallA = 6, kGroupBallTrail = 7,
-                  kGroupBallC = 8, kGroupEnvA = 9, kGroupEnvB = 10 };
-
+// One game's column accessor: wave-uniform descriptor + column pitch, per-lane byte offset.
 struct StateIO {
     Rsrc rsrc;
-    uint32_t pitch;  // bytes between groups = stride * 16 (uniform)
-    uint32_t voff;   // this lane's byte offset inside a group array = game index * 16
-    uint32_t lane4;  // game index * 4: the lane's offset in the plain per-game arrays (actions, rewards)
-    __device__ __forceinline__ int ld(int word) const
+    uint32_t pitch;  // bytes between columns = stride * 4 (uniform)
+    uint32_t voff;   // this lane's byte offset inside a column = lane index * 4
+    __device__ __forceinline__ int ld(int col) const
     {
-        const uint32_t slot = kSlot[word];
-        return (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + (slot & 3u) * 4u, (slot >> 2) * pitch, 0);
+        return (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (uint32_t)col * pitch, 0);
     }
-    __device__ __forceinline__ void st(int word, int v) const
+    __device__ __forceinline__ void st(int col, int v) const
     {
-        const uint32_t slot = kSlot[word];
-        __builtin_amdgcn_raw_buffer_store_b32((unsigned int)v, rsrc, voff + (slot & 3u) * 4u, (slot >> 2) * pitch,
-                                              PZ_STATE_AUX);
-    }
-    __device__ __forceinline__ u32x4 ld4(int group) const
-    {
-        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (uint32_t)group * pitch, 0);
-    }
-    __device__ __forceinline__ void st4(int group, const u32x4& v) const
-    {
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, (uint32_t)group * pitch, PZ_STATE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned int)v, rsrc, voff, (uint32_t)col * pitch, PZ_STATE_AUX);
     }
 };
-
-__device__ __forceinline__ StateIO make_state_io(const void* state, int64_t stride, int64_t game)
-{
-    return StateIO{make_rsrc(state, (uint32_t)(stride * (PZ_STATE_WORDS * 4))), (uint32_t)stride * 16u,
-                   (uint32_t)game * 16u, (uint32_t)game * 4u};
-}
 
 // What the first loads of a wave depend on.  The step kernels take these five as leading scalar kernel
 // arguments (and everything, again, in StepArgs): the build preloads the first 10 argument dwords into
@@ -572,7 +547,8 @@ __device__ __forceinline__ void scout_candidates(const HotArgs a, int32_t* __res
                                                  int32_t* __restrict__ scratch, int lane)
 {
     const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
-    const StateIO io = make_state_io(a.state, a.stride, i);
+    const StateIO io{make_rsrc(a.state, (uint32_t)(a.stride * (PZ_STATE_WORDS * 4))), (uint32_t)a.stride * 4u,
+                     (uint32_t)i * 4u};
     Ball b{};
     Player p1{}, p2{};
     bool need = false;
@@ -611,7 +587,8 @@ __device__ __forceinline__ void scout_candidates(const HotArgs a, int32_t* __res
 __device__ __forceinline__ void scout_landing_after_hits(const StepArgs& a, const int32_t* __restrict__ hits, int lane)
 {
     const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
-    const StateIO io = make_state_io(a.state, a.stride, i);
+    const StateIO io{make_rsrc(a.state, (uint32_t)(a.stride * (PZ_STATE_WORDS * 4))), (uint32_t)a.stride * 4u,
+                     (uint32_t)i * 4u};
     const int32_t* slot = hits + lane * kHitPitch;
     if (slot[0] != 0)  // only ever set for lanes inside the batch
         io.st(PZ_B_EXPECTED_LANDING_POINT_X, predict_landing_x<true>(slot[1], slot[2], slot[3], slot[4]));
@@ -682,7 +659,8 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
     const uint32_t n32 = (uint32_t)hot.n;
 
     // descriptors are built from kernel arguments only, so they are provably wave-uniform
-    const StateIO io = make_state_io(hot.state, hot.stride, i);
+    const StateIO io{make_rsrc(hot.state, (uint32_t)(hot.stride * (PZ_STATE_WORDS * 4))), (uint32_t)hot.stride * 4u,
+                     (uint32_t)i * 4u};
     const bool as_float = a.cfg.ballpos_reward != 0 || a.cfg.normal_state_mode != 0;
     const bool with_stats = a.episode_stats != nullptr && a.cfg.episode_stats_mode != 0;  // uniform
     const StatsIO sio = make_stats_io(a.episode_stats, with_stats, a.stride, i);
@@ -700,8 +678,8 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
     PZ_STAMP(0);
     int a1 = 0, a2 = 0;
     if (MODE == kActions) {  // rows past n read as 0 through the range check
-        a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.lane4, 0, 0);
-        a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.lane4, 0, 0);
+        a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.voff, 0, 0);
+        a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.voff, 0, 0);
     }
     EpisodeStats st{0.0, 0.0, 0};
     if (live) {
@@ -728,9 +706,9 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
                     for (int f = 0; f < frames; ++f) {  // rows past n read as 0 through the range check
                         const Rsrc tape = make_rsrc(a.act_p1 + (int64_t)(s + f) * 2 * a.n, n32 * 8u);
                         tape_lds[(f * 2 + 0) * kLanes + lane] =
-                            (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.lane4, 0, 0);
+                            (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, 0, 0);
                         tape_lds[(f * 2 + 1) * kLanes + lane] =
-                            (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.lane4, n32 * 4u, 0);
+                            (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, n32 * 4u, 0);
                     }
                     wave_lds_handover<SCOUT == kNoScout>();  // every lane reads back its own words only
                 }
@@ -753,8 +731,8 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
             if (MODE == kRollout || MODE == kTape) {
                 if (MODE == kRollout && a.act_out != nullptr) {
                     const Rsrc ao = make_rsrc(a.act_out + (int64_t)s * 2 * a.n, n32 * 8u);
-                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a1, ao, io.lane4, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, io.lane4, n32 * 4u, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a1, ao, io.voff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, io.voff, n32 * 4u, 0);
                 }
                 emit_outputs(a, g, rw, as_float, live, i, lane, s, lds_obs, false);
             }
@@ -803,7 +781,8 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
     const bool live = i < hot.n;
     const uint32_t n32 = (uint32_t)hot.n;
-    const StateIO io = make_state_io(hot.state, hot.stride, i);
+    const StateIO io{make_rsrc(hot.state, (uint32_t)(hot.stride * (PZ_STATE_WORDS * 4))), (uint32_t)hot.stride * 4u,
+                     (uint32_t)i * 4u};
     const bool as_float = a.cfg.ballpos_reward != 0 || a.cfg.normal_state_mode != 0;
     const bool with_stats = ROLE == 0 && a.episode_stats != nullptr && a.cfg.episode_stats_mode != 0;
     const StatsIO sio = make_stats_io(a.episode_stats, with_stats, a.stride, i);
@@ -813,8 +792,8 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     const RngId id = make_rng_id(a.cfg, live ? i : 0);
     const FlightLut lut = make_lut(a.tables);
     PZ_PAIR_STAMP(ROLE, 0);
-    const int a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.lane4, 0, 0);
-    const int a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.lane4, 0, 0);
+    const int a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.voff, 0, 0);
+    const int a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.voff, 0, 0);
     EpisodeStats st{0.0, 0.0, 0};
     if (live) {
         g.e.round_ended = io.ld(PZ_E_ROUND_ENDED);
@@ -911,7 +890,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         const Rsrc rew = make_rsrc(ROLE == 0 ? a.rew_p1 : a.rew_p2, n32 * 4u);
         const unsigned int bits = as_float ? __float_as_uint(ROLE == 0 ? rw.f1 : rw.f2)
                                            : (unsigned int)(ROLE == 0 ? rw.i1 : rw.i2);
-        __builtin_amdgcn_raw_buffer_store_b32(bits, rew, io.lane4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(bits, rew, io.voff, 0, 0);
         PZ_PAIR_STAMP(ROLE, 3);
     };
     auto store_observations = [&]() {
@@ -977,7 +956,8 @@ __global__ __launch_bounds__(kLanes) void init_kernel(int32_t* state, int64_t n,
 {
     const int64_t i = (int64_t)blockIdx.x * kLanes + threadIdx.x;
     if (i >= n) return;
-    const StateIO io = make_state_io(state, stride, i);
+    const StateIO io{make_rsrc(state, (uint32_t)(stride * (PZ_STATE_WORDS * 4))), (uint32_t)stride * 4u,
+                     (uint32_t)i * 4u};
     Game g;
     const RngId id = make_rng_id(cfg, i);
     construct_game(g, id);
@@ -991,7 +971,8 @@ __global__ __launch_bounds__(kLanes) void reset_kernel(int32_t* state, int64_t n
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     const int lane = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
-    const StateIO io = make_state_io(state, stride, i);
+    const StateIO io{make_rsrc(state, (uint32_t)(stride * (PZ_STATE_WORDS * 4))), (uint32_t)stride * 4u,
+                     (uint32_t)i * 4u};
     if (i < n) {
         Game g;
         load_game(g, io);
@@ -1015,7 +996,8 @@ __global__ __launch_bounds__(kLanes) void observe_kernel(const int32_t* state, i
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     const int lane = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
-    const StateIO io = make_state_io(state, stride, i);
+    const StateIO io{make_rsrc(state, (uint32_t)(stride * (PZ_STATE_WORDS * 4))), (uint32_t)stride * 4u,
+                     (uint32_t)i * 4u};
     if (i < n) {
         Game g;
         load_game(g, io);
@@ -1107,7 +1089,7 @@ __global__ __launch_bounds__(256) void render_kernel(const int32_t* __restrict__
     const int g = (int)(blockIdx.x * 256 + threadIdx.x);
     if (g >= kGroupsPerRow * PZ_FRAME_HEIGHT || game < 0 || game >= n) return;
     const int row = g / kGroupsPerRow, col = (g - row * kGroupsPerRow) * 4;
-    auto word = [&](int w) { return state[(int64_t)(kSlot[w] >> 2) * stride * 4 + game * 4 + (kSlot[w] & 3)]; };
+    auto word = [&](int f) { return state[(int64_t)f * stride + game]; };
 
     // the draw list, in the order of raw_env.draw (:250-255): twelve fixed slots (sprite < 0: not drawn), so that the
     // list stays in registers

@@ -11,15 +11,9 @@ from pathlib import Path
 PKG_ROOT = Path(__file__).resolve().parent.parent  # .../pika-zoo_amd
 LIB_PATH = PKG_ROOT / "lib" / "libpikazoo_hip.so"
 
-ABI_VERSION = 5
+ABI_VERSION = 4
 STATE_WORDS = 44
-STATE_GROUPS = 11
 OBS_DIM = 35
-# pz_state_slot of include/pikazoo_hip.h: logical word -> 4 * group + position inside the 16-byte group
-STATE_SLOT = (0, 1, 2, 6, 3, 7, 4, 8, 9, 10, 11, 42, 5,
-              12, 13, 14, 18, 15, 19, 16, 20, 21, 22, 23, 43, 17,
-              24, 25, 32, 26, 33, 28, 29, 30, 31, 27, 34, 35,
-              36, 37, 38, 40, 41, 39)
 SERVE_MODES = {"winner": 0, "alternate": 1, "random": 2}
 
 

@@ -6,8 +6,7 @@ Mirrors the PettingZoo *parallel* API of the reference's ``raw_env``
 truncations, infos)``, ``observation_space(agent)``, ``action_space(agent)`` -- but every dict
 value is a device tensor with a leading ``num_envs`` axis (one GPU lane per independent game).
 
-All game state lives in one int32 buffer in HBM -- 44 words per game, stored as 11 arrays of 16-byte groups
-(``include/pikazoo_hip.h``) and exposed as the logical ``int32[44, num_envs]`` tensor ``env.state``; a step is ONE
+All game state lives in one ``int32[44, num_envs]`` tensor in HBM (field-major); a step is ONE
 kernel launch through the C ABI in ``include/pikazoo_hip.h``.  PyTorch is used only for device
 memory and streams.  There is no CPU fallback: constructing the env without the HIP library or
 without a GPU raises.
@@ -168,10 +167,8 @@ class raw_env:
         # columns are padded to a multiple of 64 games so that every workgroup's 256-byte segment of a column is
         # aligned whatever num_envs is (a ragged pitch costs ~10 % per launch); `state` is the [44, n] view
         self._stride = (n + 63) // 64 * 64
-        # physical layout (include/pikazoo_hip.h): int32[11 groups][stride][4]; `state` is the logical [44, n] view
-        self._state_buf = torch.zeros((_native.STATE_GROUPS, self._stride, 4), dtype=torch.int32, device=dev)
-        self._slot = torch.tensor(_native.STATE_SLOT, dtype=torch.int64, device=dev)       # word -> packed row
-        self._slot_inv = torch.argsort(self._slot)                                           # packed row -> word
+        self._state_buf = torch.zeros((_native.STATE_WORDS, self._stride), dtype=torch.int32, device=dev)
+        self.state = self._state_buf[:, :n]
         self._obs = [torch.zeros((n, _native.OBS_DIM), dtype=torch.int32, device=dev) for _ in range(2)]
         # one 4-byte word per lane and agent; viewed as int32 or float32 (RewardByBallPosition)
         self._rew_raw = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
@@ -183,17 +180,16 @@ class raw_env:
         self._ep_returns = self._ep_lengths = None
         # raw pointers of the env-owned buffers (fixed for the env's lifetime) and the cached result tuple:
         # the dicts returned by step() hold views of those buffers, so they can be reused between steps
-        self._ptrs = (self._state_buf.data_ptr(), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
+        self._ptrs = (self.state.data_ptr(), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
                       self._rew_raw[0].data_ptr(), self._rew_raw[1].data_ptr(), self._term_u8.data_ptr())
         self._step_result = None
-        # scores are words 0, 1 of group 9: a live [n, 2] view of the state buffer
-        self._scores = self._state_buf[_native.STATE_SLOT[_E_SCORE_P1] // 4, :n, 0:2]
+        self._scores = self.state[_E_SCORE_P1:_E_SCORE_P1 + 2].t()  # live [n, 2] view of the state
         self.steps_done = 0  # frames stepped by this env (per lane)
 
         self.action_spaces = {a: Discrete(18) for a in self.possible_agents}
         self._spaces = {}
         with torch.cuda.device(self.device):
-            _native.check(self._lib.pz_init(self._state_buf.data_ptr(), n, self._stride, self._cfg_ref, self._stream()),
+            _native.check(self._lib.pz_init(self.state.data_ptr(), n, self._stride, self._cfg_ref, self._stream()),
                           "pz_init")
 
     # ------------------------------------------------------------------------------------------
@@ -204,34 +200,6 @@ class raw_env:
     @property
     def unwrapped(self):
         return self
-
-    # ---- the state tensor ---------------------------------------------------------------------------
-    @property
-    def state(self) -> torch.Tensor:
-        """The logical ``int32[44, num_envs]`` state (word order of ``include/pikazoo_hip.h``'s enums, one column per
-        game): a *copy* unpacked from the kernel's 16-byte-group layout.  Assign to it (``env.state = t``) or call
-        :meth:`set_state` to write a state back; ``state_ptr`` is the device pointer the C ABI takes."""
-        n = self.num_envs
-        packed = self._state_buf[:, :n, :].permute(0, 2, 1).reshape(_native.STATE_WORDS, n)  # row = 4 * group + position
-        return packed.index_select(0, self._slot)
-
-    @state.setter
-    def state(self, value):
-        self.set_state(value)
-
-    def set_state(self, value: torch.Tensor):
-        """Overwrite the state with a logical ``[44, num_envs]`` integer tensor (what :attr:`state` returns)."""
-        n = self.num_envs
-        value = torch.as_tensor(value, device=self.device).to(torch.int32)
-        if value.shape != (_native.STATE_WORDS, n):
-            raise ValueError(f"state must have shape ({_native.STATE_WORDS}, {n})")
-        packed = value.index_select(0, self._slot_inv)                                          # rows in packed order
-        self._state_buf[:, :n, :].copy_(packed.reshape(_native.STATE_GROUPS, 4, n).permute(0, 2, 1))
-
-    @property
-    def state_ptr(self) -> int:
-        """Device pointer of the state buffer (``int32[11][stride][4]``, see include/pikazoo_hip.h) for the C ABI."""
-        return self._state_buf.data_ptr()
 
     @property
     def num_agents(self):
@@ -406,7 +374,7 @@ class raw_env:
             if m.shape != (self.num_envs,):
                 raise ValueError(f"mask must have shape ({self.num_envs},)")
         with torch.cuda.device(self.device):
-            _native.check(self._lib.pz_reset(self._state_buf.data_ptr(), self.num_envs, self._stride, self._cfg_ref,
+            _native.check(self._lib.pz_reset(self.state.data_ptr(), self.num_envs, self._stride, self._cfg_ref,
                                              _ptr(m), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
                                              self._stats_ptr(), self._stream()), "pz_reset")
         if self.scalar_api:
@@ -479,7 +447,7 @@ class raw_env:
         if t0 is None:
             t0 = self.steps_done
         with torch.cuda.device(self.device):
-            _native.check(self._lib.pz_step_random(self._state_buf.data_ptr(), self.num_envs, self._stride,
+            _native.check(self._lib.pz_step_random(self.state.data_ptr(), self.num_envs, self._stride,
                                                    self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0),
                                                    int(k), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
                                                    self._rew_raw[0].data_ptr(), self._rew_raw[1].data_ptr(),
@@ -511,7 +479,7 @@ class raw_env:
                    "_term": torch.empty((k, n), dtype=torch.uint8, device=dev)}
         with torch.cuda.device(dev):
             _native.check(self._lib.pz_rollout_random(
-                self._state_buf.data_ptr(), n, self._stride, self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0), k,
+                self.state.data_ptr(), n, self._stride, self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0), k,
                 out["actions"].data_ptr(), out["_obs"][0].data_ptr(), out["_obs"][1].data_ptr(),
                 out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(), out["_term"].data_ptr(),
                 self._stats_ptr(), self._episodes.data_ptr(), self._tables_ref, self._stream()), "pz_rollout_random")
@@ -540,7 +508,7 @@ class raw_env:
         out["actions"] = actions
         with torch.cuda.device(dev):
             _native.check(self._lib.pz_step_many(
-                self._state_buf.data_ptr(), n, self._stride, self._cfg_ref, actions.data_ptr(), k, out["_obs"][0].data_ptr(),
+                self.state.data_ptr(), n, self._stride, self._cfg_ref, actions.data_ptr(), k, out["_obs"][0].data_ptr(),
                 out["_obs"][1].data_ptr(), out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(),
                 out["_term"].data_ptr(), self._stats_ptr(), self._episodes.data_ptr(), self._tables_ref,
                 self._stream()), "pz_step_many")
@@ -578,7 +546,7 @@ class raw_env:
         o1 = torch.empty_like(self._obs[0])
         o2 = torch.empty_like(self._obs[1])
         with torch.cuda.device(self.device):
-            _native.check(self._lib.pz_observe(self._state_buf.data_ptr(), self.num_envs, self._stride,
+            _native.check(self._lib.pz_observe(self.state.data_ptr(), self.num_envs, self._stride,
                                                int(self._cfg.normalize_obs), o1.data_ptr(), o2.data_ptr(),
                                                self._stream()), "pz_observe")
         odt = self.obs_dtype
@@ -597,7 +565,7 @@ class raw_env:
     def state_dict(self):
         """Everything a bit-exact continuation needs: the state tensor, the RecordEpisodeStatistics words, the
         counters, and the configuration (Philox key, game ids, fused wrappers) the trajectory depends on."""
-        return {"state": self.state, "steps_done": self.steps_done, "seed": self.seed,
+        return {"state": self.state.clone(), "steps_done": self.steps_done, "seed": self.seed,
                 "env_id_base": self.env_id_base, "config": self._cfg_dict(),
                 "episode_stats": None if self._stats is None else self._stats.clone(),
                 "episodes_done": self._episodes.clone()}
@@ -606,7 +574,7 @@ class raw_env:
         """Restore a :meth:`state_dict`.  Raises when it was taken from an env whose Philox key, game ids or
         (fused-wrapper) configuration differ from this one: the continuation would silently be another
         trajectory."""
-        if tuple(sd["state"].shape) != (_native.STATE_WORDS, self.num_envs):
+        if sd["state"].shape != self.state.shape:
             raise ValueError("state shape mismatch")
         cfg = sd.get("config")
         if cfg is not None:
@@ -619,7 +587,7 @@ class raw_env:
         stats = sd.get("episode_stats")
         if (stats is None) != (self._stats is None):
             raise ValueError("checkpoint and env disagree on RecordEpisodeStatistics")
-        self.set_state(sd["state"])
+        self.state.copy_(sd["state"])
         if stats is not None:
             self._stats.copy_(stats)
         if sd.get("episodes_done") is not None:
@@ -654,7 +622,7 @@ class raw_env:
         elif self.num_envs * _render.HEIGHT * _render.WIDTH * 3 > (1 << 30):
             raise ValueError(f"rendering all {self.num_envs} games needs more than 1 GiB: pass lanes=")
         with torch.cuda.device(self.device):
-            frames = _render.render(self._lib, self._state_buf, self.num_envs, self._stride, self._sprites, lane_t,
+            frames = _render.render(self._lib, self.state, self.num_envs, self._stride, self._sprites, lane_t,
                                     self._stream(), out)
         return frames[0].cpu().numpy() if self.scalar_api else frames
 

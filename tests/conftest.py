@@ -55,18 +55,6 @@ FULL_FIXTURES = [
 DIGEST_FIXTURES = ["digest_human_human", "digest_p2_computer", "digest_both_computer_random_serve"]
 
 
-def unpack_state(buf, n, stride):
-    """Logical int32 [44, n] view (a copy) of a raw C-ABI state buffer -- int32[11 groups][stride][4], see
-    include/pikazoo_hip.h -- and, second, the padding games n..stride of every group (must stay untouched)."""
-    from pikazoo_amd import _native
-
-    import torch
-    g = buf.reshape(_native.STATE_GROUPS, stride, 4)
-    packed = g[:, :n, :].permute(0, 2, 1).reshape(_native.STATE_WORDS, n)
-    slot = torch.tensor(_native.STATE_SLOT, dtype=torch.int64, device=buf.device)
-    return packed.index_select(0, slot), g[:, n:, :]
-
-
 def golden_state(d, t):
     """Full int32 [W, lanes] state after step t of a full fixture (rng counter kept as int32)."""
     st = d["states"][t].astype(np.int32)

@@ -15,8 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (DIGEST_FIXTURES, FULL_FIXTURES, golden_state, load_golden, oracle_config_from_meta,
-                      unpack_state)
+from conftest import DIGEST_FIXTURES, FULL_FIXTURES, golden_state, load_golden, oracle_config_from_meta
 
 pytestmark = pytest.mark.gpu
 
@@ -333,12 +332,11 @@ def test_stride_larger_than_n_and_error_codes(oracle):
                                   obs2.data_ptr(), rew1.data_ptr(), rew2.data_ptr(), term.data_ptr(), None, None,
                                   None, s) == 0
     torch.cuda.synchronize()
-    logical, padding = unpack_state(state, n, stride)
-    assert bool((padding == -7).all()), "games beyond n must not be touched"
+    assert bool((state[:, n:] == -7).all()), "columns beyond n must not be touched"
     ref = oracle.OracleEnv(n, oracle.make_config(winning_score=2, is_player2_computer=True, seed=77, env_id_base=9))
     ref.reset()
     ref.rollout_random(11, 0, 100)
-    assert np.array_equal(cpu(logical), ref.state)
+    assert np.array_equal(cpu(state[:, :n]), ref.state)
     assert np.array_equal(cpu(obs1), ref.obs[0])
     # argument errors are reported, not launched
     assert lib.pz_init(None, n, stride, C.byref(cfg), s) == -1
@@ -699,9 +697,8 @@ def test_randomized_config_sweep_vs_oracle(oracle):
                     t += kk
             torch.cuda.synchronize()
             ctx = (trial, phase, mode, n, stride, tb is not None, k)
-            logical, padding = unpack_state(state, n, stride)
-            assert np.array_equal(cpu(logical), ref.state), ctx
-            assert bool((padding == -99).all()), ctx
+            assert np.array_equal(cpu(state[:, :n]), ref.state), ctx
+            assert bool((state[:, n:] == -99).all()), ctx
             assert np.array_equal(cpu(obs[0]), ref.obs[0].view(np.int32)) and np.array_equal(cpu(obs[1]),
                                                                                            ref.obs[1].view(np.int32)), ctx
             assert np.array_equal(cpu(rew[0]), ref.rew[0].view(np.int32)) and np.array_equal(cpu(rew[1]),
@@ -857,7 +854,7 @@ def test_ball_states_outside_the_tables_take_the_computed_path(oracle):
     st[1, ::2] = 200
     st[26, ::2] = st[0, ::2] + 10
     st[27, ::2] = 190
-    raw.set_state(st)
+    raw.state.copy_(st.to(raw.device))
     ref.state[:] = st.numpy()
     for t in range(40, 70):
         acts = raw.random_actions(5, t)

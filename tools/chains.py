@@ -45,7 +45,7 @@ def main():
             cfg = _native.PzConfig.from_buffer_copy(env._cfg)
             cfg.env_id_base = env.env_id_base + lo
             cfgs.append(cfg)
-            rc = lib.pz_step(env.state_ptr + 16 * lo, sub, env._stride, C.byref(cfg),
+            rc = lib.pz_step(env.state.data_ptr() + 4 * lo, sub, env._stride, C.byref(cfg),
                              acts[t, 0].data_ptr() + 4 * lo, acts[t, 1].data_ptr() + 4 * lo,
                              env._obs[0].data_ptr() + 140 * lo, env._obs[1].data_ptr() + 140 * lo,
                              env._rew_raw[0].data_ptr() + 4 * lo, env._rew_raw[1].data_ptr() + 4 * lo,
