@@ -53,6 +53,7 @@ import torch  # noqa: E402
 from pikazoo_amd import _native, dist, pikazoo_v0  # noqa: E402
 
 BYTES_PER_ENV_STEP = 8 * 44 + 297  # rd+wr state, 2 actions, 2x35 obs, 2 rewards, 1 flag
+BYTES_PER_ENV_STEP_PACKED = 2 * 36 + 297  # the same with the packed state format (36 bytes per game)
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 INFINITY_CACHE_BYTES = 256 << 20
 ACTION_SEED = 1
@@ -77,6 +78,9 @@ def parse_args():
     ap.add_argument("--wrappers", action="store_true", help="config 5: fused SimplifyAction+RewardByBallPosition")
     ap.add_argument("--no-flight-tables", action="store_true",
                     help="computer player: run the flight predictors in the kernel instead of the HBM look-up tables")
+    ap.add_argument("--state-format", choices=["int32", "packed"], default="int32",
+                    help="headline run: state as int32[44, N] columns (BASELINE's contract, default) or in the packed "
+                         "36-byte format (SURVEY 8(f)-3)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on CPU baseline threads")
     ap.add_argument("--check-lanes", type=int, default=2048, help="lanes replayed on the CPU oracle for parity")
@@ -90,13 +94,15 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_env(shard, device, *, num_envs, p1_computer=False, p2_computer=False, wrappers=False, flight_tables=True):
+def make_env(shard, device, *, num_envs, p1_computer=False, p2_computer=False, wrappers=False, flight_tables=True,
+             state_format="int32"):
     from pikazoo_amd.wrappers import RewardByBallPosition, SimplifyAction
 
     env = pikazoo_v0.env(winning_score=15, serve="winner", is_player2_computer=p2_computer,
                          is_player1_computer=p1_computer,
                          num_envs=num_envs, device=device, seed=0, env_id_base=shard.env_id_base,
-                         auto_reset=True, validate_actions=False, flight_tables=flight_tables)
+                         auto_reset=True, validate_actions=False, flight_tables=flight_tables,
+                         state_format=state_format)
     if wrappers:
         env = SimplifyAction(env)
         env = RewardByBallPosition(env, WRAPPER_TABLE, 216, 176)
@@ -132,7 +138,7 @@ def run_gpu(env, acts, warmup, steps, launch, min_time):
     raw = env.unwrapped
     lib = _native.load()
     n = raw.num_envs
-    st, cfg = raw.state.data_ptr(), raw._cfg_ref
+    st, cfg = raw._state_ptr, raw._cfg_ref
     o1, o2 = raw._obs[0].data_ptr(), raw._obs[1].data_ptr()
     r1, r2, tm = raw._rew_raw[0].data_ptr(), raw._rew_raw[1].data_ptr(), raw._term_u8.data_ptr()
     tables = raw._tables_ref
@@ -293,7 +299,7 @@ def cpu_baseline(args, raw_gpu, p2_computer, wrappers):
 
 
 def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=False, launch=None, steps=None,
-            warmup=None, burn=None, min_time=None, check_lanes=0, flight_tables=True):
+            warmup=None, burn=None, min_time=None, check_lanes=0, flight_tables=True, state_format="int32"):
     num_envs = args.num_envs if num_envs is None else num_envs
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
@@ -301,7 +307,7 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     min_time = args.min_time if min_time is None else min_time
     launch = args.launch if launch is None else launch
     env = make_env(shard, device, num_envs=num_envs, p1_computer=args.p1_computer, p2_computer=p2_computer,
-                   wrappers=wrappers, flight_tables=flight_tables)
+                   wrappers=wrappers, flight_tables=flight_tables, state_format=state_format)
     raw = env.unwrapped
     env.reset()
     burn_in(raw, burn)
@@ -312,13 +318,13 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     wall = dist.all_reduce_max(run["wall"], device=cdev)
     n_total, = dist.all_reduce_sum([raw.num_envs], device=cdev)
     launch_us = run["event_ms"] * 1e3 / run["timed_steps"]
-    alg = BYTES_PER_ENV_STEP * num_envs
+    alg = (BYTES_PER_ENV_STEP_PACKED if state_format == "packed" else BYTES_PER_ENV_STEP) * num_envs
     res = {
         "wall_s": wall, "event_ms": run["event_ms"], "n_total": n_total, "timed_steps": run["timed_steps"],
         "replays": run["replays"], "launches_per_replay": run["launches_per_replay"],
         "value": n_total * run["timed_steps"] / wall,
         "launch_us": launch_us, "wall_us_per_step": wall * 1e6 / run["timed_steps"],
-        "achieved_GBps": alg / (launch_us * 1e-6) / 1e9,
+        "achieved_GBps": alg / (launch_us * 1e-6) / 1e9, "algorithmic_bytes_per_launch": alg,
         "raw": raw,
     }
     res["frac"] = res["achieved_GBps"] / HBM_PEAK_GBPS
@@ -388,7 +394,10 @@ def ensure_built():
     mod.build()
 
 
-def kernel_name(num_envs, ai, tables):
+def kernel_name(num_envs, ai, tables, packed=False):
+    if packed:
+        return ("pz::step_kernel<AI1,AI2,kActions,false,kNoScout,PACKED> via pz_step" if num_envs >= 393216 or (ai and not tables)
+                else "pz::step_pair_kernel<AI1,AI2,PACKED> via pz_step")
     if num_envs >= 393216:
         return "pz::step_kernel<AI1,AI2,kActions,true> via pz_step"
     if ai and not tables:
@@ -441,7 +450,8 @@ def main():
         return
 
     main_res = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers,
-                       check_lanes=args.check_lanes if single else 0, flight_tables=tables)
+                       check_lanes=args.check_lanes if single else 0, flight_tables=tables,
+                       state_format=args.state_format)
     raw_main = main_res.pop("raw")
     cpu = None
     if single and not args.no_cpu:
@@ -462,6 +472,16 @@ def main():
                              dict(num_envs=65536, p2_computer=True, flight_tables=False)),
             "cfg5": ("65 536 games, fused SimplifyAction + RewardByBallPosition",
                      dict(num_envs=65536, wrappers=True)),
+            # the same workloads on the packed state format (36 instead of 176 bytes of state per game;
+            # `frac` of these entries is computed on their own 369 algorithmic bytes per game-step)
+            "packed_headline": ("65 536 games, random/random, packed state format",
+                                dict(num_envs=65536, state_format="packed")),
+            "packed_cfg3": ("65 536 games, player 2 = rule-based computer (tables), packed state format",
+                            dict(num_envs=65536, p2_computer=True, state_format="packed")),
+            "packed_524288": ("524 288 games on one GPU, random/random, packed state format",
+                              dict(num_envs=524288, state_format="packed", steps=300, warmup=50, burn=512)),
+            "int32_524288": ("524 288 games on one GPU, random/random, int32 state (config 4's batch on one GPU)",
+                             dict(num_envs=524288, steps=300, warmup=50, burn=512)),
         }
         # the flight tables are built once per device, outside every timed region: say what that costs
         from pikazoo_amd import env as _env
@@ -476,6 +496,7 @@ def main():
             r = measure(args, dist.weak_shard(kw["num_envs"], rank, world), device, **{**sub, **kw})
             r.pop("raw")
             configs[key] = config_entry(r, wl, kw["num_envs"])
+            configs[key]["algorithmic_bytes_per_launch"] = r["algorithmic_bytes_per_launch"]
         configs["cfg3"]["flight_tables"] = table_info
 
     extra = {}
@@ -499,11 +520,13 @@ def main():
             extra[f"launch_{mode}"] = {"value": r["value"], "launch_us": r["launch_us"]}
 
     if rank == 0:
-        alg_bytes = BYTES_PER_ENV_STEP * args.num_envs
+        alg_bytes = main_res["algorithmic_bytes_per_launch"]
         wl = (("cfg3" if tables else "cfg3_compute") if args.p2_computer
               else ("cfg5" if args.wrappers else "random_random"))
         if args.num_envs != 65536 and wl == "random_random":
             wl = f"random_random_{args.num_envs}"
+        if args.state_format == "packed":
+            wl = "packed_" + wl
         traffic = load_traffic(wl, args.num_envs)
         launch_s = main_res["launch_us"] * 1e-6
         out = {
@@ -511,6 +534,7 @@ def main():
             "value": main_res["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": main_res["wall_us_per_step"] * 1e-3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+            "state_format": args.state_format,
             "data": "synthetic",
             "timed_steps": main_res["timed_steps"], "replays": main_res["replays"],
             "launches_per_replay": main_res["launches_per_replay"], "timed_seconds": main_res["wall_s"],
@@ -524,7 +548,8 @@ def main():
                             f"fused_wrappers={args.wrappers}",
                 "num_envs_per_gpu": args.num_envs, "num_envs_total": main_res["n_total"],
                 "launch": args.launch,
-                "kernel": kernel_name(args.num_envs, args.p2_computer or args.p1_computer, tables),
+                "kernel": kernel_name(args.num_envs, args.p2_computer or args.p1_computer, tables,
+                                      args.state_format == "packed"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": main_res["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",

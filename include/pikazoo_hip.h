@@ -15,7 +15,8 @@
  *  - all calls are asynchronous on `stream`;
  *  - return value: 0 = ok, negative = PZ_E_* argument error, positive = hipError_t;
  *  - state is int32[PZ_STATE_WORDS][stride], field-major (structure of arrays): lane i
- *    (one independent game) owns column i; `n` lanes are live, stride >= n;
+ *    (one independent game) owns column i; `n` lanes are live, stride >= n -- or, with
+ *    cfg->packed_state, the bit-packed format below (36 bytes per game instead of 176);
  *  - observations are int32[n][35] row-major per agent (pikazoo_env.py:576-624);
  *  - out-of-range actions are undefined behaviour here (the reference raises IndexError at
  *    pikazoo_env.py:182); the Python host validates them unless told not to.
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PZ_ABI_VERSION 4
+#define PZ_ABI_VERSION 5
 #define PZ_STATE_WORDS 44
 #define PZ_OBS_DIM 35
 
@@ -62,7 +63,7 @@ enum pz_error {
     PZ_E_NULL = -1,       /* a required pointer is NULL */
     PZ_E_SIZE = -2,       /* n < 0, stride < n, k < 1 ... */
     PZ_E_CONFIG = -3,     /* config field out of range */
-    PZ_E_ALIGN = -4       /* buffer not 16-byte aligned */
+    PZ_E_ALIGN = -4       /* buffer not 16-byte aligned (observations, packed state, power_hit table) */
 };
 
 /* Constructor kwargs of pikazoo_v0.env (pikazoo_env.py:79-86) + the fused wrappers
@@ -90,7 +91,7 @@ typedef struct pz_config {
     int32_t y_line;               /* RewardByBallPosition y_line (default 176) */
     float   additional_reward[8]; /* [0..3] player_1 zones, [4..7] player_2 zones */
     int32_t auto_reset;           /* 1: a finished game is reset() in place before its next frame */
-    int32_t reserved;
+    int32_t packed_state;         /* 0: `state` is int32[PZ_STATE_WORDS][stride]; 1: the packed format (below) */
     int32_t normal_state_mode;    /* RewardInNormalState (reward_in_normal_state.py:10-15): 0 off,
                                      1 applied before additional_reward, 2 after it */
     float   normal_state_reward;  /* its constant (reward_in_normal_state.py:8) */
@@ -101,6 +102,37 @@ typedef struct pz_config {
     uint64_t seed;                /* Philox4x32-10 key of the env RNG stream */
     int64_t env_id_base;          /* global id of lane 0 (shards of one job use disjoint ranges) */
 } pz_config;
+
+/* ---- the packed state format (cfg->packed_state = 1) -----------------------------------------------
+ * SURVEY section 8(f)-3 "int16 / bit-packed state".  The same 44 values in 36 bytes per game, three columns
+ * (structure of arrays, game i at element i of each):
+ *   group A  uint32[4][..] at byte 0            player 1, env block, ball.punch_effect_x
+ *   group B  uint32[4][..] at byte 16 * stride  player 2, the ball
+ *   tail     uint32[..]    at byte 32 * stride  expected_landing_point_x (uint16) | computer_boldness of player 1,
+ *                                               player 2 (uint8 each)
+ * i.e. a buffer of pz_packed_state_bytes(stride) = 36 * stride bytes, 16-byte aligned.  Field layout:
+ *   A0 / B0  x 9 | y 8 <<9 | y_velocity+32 6 <<17 | state 3 <<23 | frame_number 3 <<26 | delay_before_next_frame 3 <<29
+ *   A1 / B1  bits 0-8: arm_swing_direction==1 | diving_direction+1 2 <<1 | lying_down_duration_left+2 3 <<3 |
+ *            is_collision_with_ball_happened <<6 | computer_where_to_stand_by <<7 | power_hit_key_is_down_previous <<8
+ *   A1       | punch_effect_x 9 <<9 | is_player2_serve <<18 | round_ended <<19 | game_ended <<20 | misfit flag <<31
+ *   A2       score_p1 16 | score_p2 16 <<16          A3   rng draw counter
+ *   B1       | is_power_hit <<9 | x_velocity+32 6 <<10 | y_velocity 13 signed <<16 | misfit flag <<31
+ *   B2       x 9 | previous_x 9 <<9 | previous_previous_x 9 <<18
+ *   B3       y 8 | previous_y 8 <<8 | previous_previous_y 8 <<16 | fine_rotation 6 <<24
+ * Every entry point that takes a pz_config reads / writes `state` in the format the config names (so winning_score
+ * must be <= 65535 then); pz_observe takes the format as an argument; pz_render reads int32 columns only.  The
+ * results are the same bit for bit: pz_unpack_state of a packed run equals the int32 run.  The field widths hold
+ * every value play can produce; pz_pack_state counts the games of a caller-supplied state that
+ * do not fit, and a step kernel that ever met a ball y velocity outside +-4095 would raise the game's misfit flag
+ * (sticky; counted by pz_unpack_state). */
+#define PZ_PACKED_BYTES_PER_GAME 36
+int64_t pz_packed_state_bytes(int64_t stride);
+/* int32 columns -> packed; *misfits (int64, device, may be NULL) += games with a value outside its field */
+int pz_pack_state(const int32_t *state, int64_t n, int64_t stride, void *packed, int64_t packed_stride,
+                  int64_t *misfits, void *stream);
+/* packed -> int32 columns; *flagged (int64, device, may be NULL) += games whose misfit flag is set */
+int pz_unpack_state(const void *packed, int64_t n, int64_t packed_stride, int32_t *state, int64_t stride,
+                    int64_t *flagged, void *stream);
 
 /* ---- flight look-up tables of the computer player (optional; caller-owned device memory) -----
  * The two flight predictors of the rule-based computer player are pure functions of a few small
@@ -148,7 +180,7 @@ int pz_reset(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
              void *stream);
 
 /* ---- raw_env._get_obs : pikazoo_env.py:576-624 (normalize != 0: NormalizeObservation on top) */
-int pz_observe(const int32_t *state, int64_t n, int64_t stride, int32_t normalize,
+int pz_observe(const int32_t *state, int64_t n, int64_t stride, int32_t normalize, int32_t packed,
                int32_t *obs_p1, int32_t *obs_p2, void *stream);
 
 /* ---- raw_env.step : pikazoo_env.py:175-240 (one frame of every game, one launch) ---------

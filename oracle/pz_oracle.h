@@ -58,7 +58,7 @@ typedef struct pzo_config {
     int32_t y_line;              /* reward_by_ball_position.py:12 */
     float   additional_reward[8];/* reward_by_ball_position.py:10 */
     int32_t auto_reset;          /* batched-env addition: reset() in place before the next step */
-    int32_t reserved;
+    int32_t packed_state;         /* product-side storage format flag; the oracle always holds int32 columns */
     int32_t normal_state_mode;   /* wrappers/reward_in_normal_state.py:10-15 fused: 0 off, 1 applied
                                     before additional_reward (wrapper inside RewardByBallPosition),
                                     2 applied after it (wrapper outside) */

@@ -60,7 +60,7 @@ class Config(C.Structure):
         ("y_line", C.c_int32),
         ("additional_reward", C.c_float * 8),
         ("auto_reset", C.c_int32),
-        ("reserved", C.c_int32),
+        ("packed_state", C.c_int32),  # storage format of the product; ignored here
         ("normal_state_mode", C.c_int32),
         ("normal_state_reward", C.c_float),
         ("normalize_obs", C.c_int32),

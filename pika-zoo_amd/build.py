@@ -21,7 +21,7 @@ INCLUDE = REPO / "include"
 LIB_DIR = PKG_ROOT / "lib"
 LIB = LIB_DIR / "libpikazoo_hip.so"
 SOURCES = [CSRC / "pz_kernels.hip"]
-DEPS = SOURCES + [CSRC / "pz_physics.hpp", INCLUDE / "pikazoo_hip.h"]
+DEPS = SOURCES + [CSRC / "pz_physics.hpp", CSRC / "pz_packed.hpp", INCLUDE / "pikazoo_hip.h"]
 ARCH = "gfx950"
 # the step kernels' five leading arguments (10 dwords) are preloaded into SGPRs at wave launch (pz_kernels.hip: HotArgs)
 FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-mllvm", "-amdgpu-kernarg-preload-count=10"]

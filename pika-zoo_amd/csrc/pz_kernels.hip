@@ -22,6 +22,7 @@
 
 #include "pikazoo_hip.h"
 #include "pz_physics.hpp"
+#include "pz_packed.hpp"
 
 namespace pz {
 
@@ -61,6 +62,35 @@ struct StateIO {
         __builtin_amdgcn_raw_buffer_store_b32((unsigned int)v, rsrc, voff, (uint32_t)col * pitch, PZ_STATE_AUX);
     }
 };
+
+// The packed format (pz_packed.hpp): group A, group B and the tail are three columns, each behind its own descriptor
+// -- the 16-byte stores then carry no SGPR offset (see flush_rows for why that matters).
+struct PackedIO {
+    Rsrc a, b, tail;
+    uint32_t v16, v4;  // this lane's byte offset inside a 16-byte / 4-byte column
+    __device__ __forceinline__ pk_u32x4 ld_a() const { return __builtin_amdgcn_raw_buffer_load_b128(a, v16, 0, 0); }
+    __device__ __forceinline__ pk_u32x4 ld_b() const { return __builtin_amdgcn_raw_buffer_load_b128(b, v16, 0, 0); }
+    __device__ __forceinline__ uint32_t ld_tail() const { return __builtin_amdgcn_raw_buffer_load_b32(tail, v4, 0, 0); }
+    __device__ __forceinline__ void st_a(pk_u32x4 w) const { __builtin_amdgcn_raw_buffer_store_b128(w, a, v16, 0, PZ_STATE_AUX); }
+    __device__ __forceinline__ void st_b(pk_u32x4 w) const { __builtin_amdgcn_raw_buffer_store_b128(w, b, v16, 0, PZ_STATE_AUX); }
+    __device__ __forceinline__ void st_tail(uint32_t w) const { __builtin_amdgcn_raw_buffer_store_b32(w, tail, v4, 0, PZ_STATE_AUX); }
+    __device__ __forceinline__ void st_ex(int ex) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ex, tail, v4, 0, PZ_STATE_AUX);
+    }
+    __device__ __forceinline__ void st_bold(int player, int bold) const  // player 0 / 1
+    {
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bold, tail, v4 + 2u + (uint32_t)player, 0, PZ_STATE_AUX);
+    }
+};
+
+__device__ __forceinline__ PackedIO make_packed_io(const void* packed, int64_t stride, int64_t lane_index)
+{
+    const char* base = static_cast<const char*>(packed);
+    const uint32_t group = (uint32_t)stride * 16u;
+    return PackedIO{make_rsrc(base, group), make_rsrc(base + stride * 16, group), make_rsrc(base + stride * 32, (uint32_t)stride * 4u),
+                    (uint32_t)lane_index * 16u, (uint32_t)lane_index * 4u};
+}
 
 // What the first loads of a wave depend on.  The step kernels take these five as leading scalar kernel
 // arguments (and everything, again, in StepArgs): the build preloads the first 10 argument dwords into
@@ -236,6 +266,30 @@ __device__ __forceinline__ void store_game_changed(const Game& g, const Game& o,
     if (g.e.rng != o.e.rng) io.st(PZ_E_RNG_DRAW_COUNTER, (int32_t)g.e.rng);
 }
 
+// whole games in either format (constructor / reset / observe kernels, the single-wave step kernel)
+struct PackedWords {
+    pk_u32x4 a, b;
+    uint32_t tail;
+};
+
+__device__ __forceinline__ PackedWords load_game_packed(Game& g, const PackedIO& pio, bool with_tail)
+{
+    PackedWords w{pio.ld_a(), pio.ld_b(), with_tail ? pio.ld_tail() : 0u};
+    unpack_group_a(g, w.a);
+    unpack_group_b(g, w.b);
+    unpack_tail(g, w.tail);
+    return w;
+}
+
+// `was`: what the lane loaded (its sticky overflow flags are kept; the tail is stored only when it changed)
+__device__ __forceinline__ void store_game_packed(const Game& g, const PackedIO& pio, const PackedWords& was, bool with_tail)
+{
+    pio.st_a(pack_group_a(g, was.a.y & kPackedOverflowBit));
+    pio.st_b(pack_group_b(g, was.b.y & kPackedOverflowBit));
+    const uint32_t tail = pack_tail(g);
+    if (with_tail && tail != was.tail) pio.st_tail(tail);
+}
+
 __device__ __forceinline__ RngId make_rng_id(const pz_config& cfg, int64_t lane_index)
 {
     const uint64_t gid = (uint64_t)(cfg.env_id_base + lane_index);
@@ -390,15 +444,15 @@ __device__ unsigned long long g_pz_stamps[8192 * 8];
 #endif
 
 #ifdef PZ_ABLATE
-// timing-only build (tools/ablate.py): cfg.reserved bits skip parts of the kernel; results are
+// timing-only build (tools/ablate.py): cfg.packed_state bits 3.. skip parts of the kernel; results are
 // wrong by construction.  bit3: no game logic; bit4: no observation staging / flush;
 // bits 5,6,7: skip the landing predictor before the players / the power-hit candidates / the
 // landing predictor after a collision (pz_physics.hpp); pair kernel also bit 8: no pre-drawn Philox
 // blocks, bit 9: no computer decision at all.
-#define PZ_SKIP_FRAME ((a.cfg.reserved & 8) != 0)
-#define PZ_SKIP_OBS ((a.cfg.reserved & 16) != 0)
-#define PZ_SKIP_STATE_STORES ((a.cfg.reserved & 1024) != 0)  // pair kernel: no state / reward / flag stores
-#define PZ_SKIP_OBS_STORES ((a.cfg.reserved & 2048) != 0)    // pair kernel: observations staged but not stored
+#define PZ_SKIP_FRAME ((a.cfg.packed_state & 8) != 0)
+#define PZ_SKIP_OBS ((a.cfg.packed_state & 16) != 0)
+#define PZ_SKIP_STATE_STORES ((a.cfg.packed_state & 1024) != 0)  // pair kernel: no state / reward / flag stores
+#define PZ_SKIP_OBS_STORES ((a.cfg.packed_state & 2048) != 0)    // pair kernel: observations staged but not stored
 #else
 #define PZ_SKIP_FRAME false
 #define PZ_SKIP_OBS false
@@ -618,10 +672,12 @@ __device__ __forceinline__ void scout_candidates_posted(const int32_t* __restric
 // second wave for the flight predictions that can run beside the frame -- kScoutLoads for the single
 // frame of pz_step (scout_candidates, scout_landing_after_hits), kScoutPosted for the k-frame modes
 // (scout_candidates_posted).  The scout executes exactly the workgroup barriers of the main wave.
-template <bool AI1, bool AI2, int MODE, bool SPARSE, int SCOUT = kNoScout>
+// PACKED: the state buffer holds the packed format (pz_packed.hpp); the whole groups are written back (no scout wave).
+template <bool AI1, bool AI2, int MODE, bool SPARSE, int SCOUT = kNoScout, bool PACKED = false>
 __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
 {
     const HotArgs hot{state, n, stride, act_p1, act_p2};
+    static_assert(!PACKED || (SCOUT == kNoScout && !SPARSE), "the packed format has no scout and no changed-only variant");
     static_assert(SCOUT == kNoScout || ((AI1 || AI2) && (MODE == kActions) == (SCOUT == kScoutLoads)),
                   "kScoutLoads serves the single-frame AI launch, kScoutPosted the k-frame ones");
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
@@ -659,8 +715,9 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
     const uint32_t n32 = (uint32_t)hot.n;
 
     // descriptors are built from kernel arguments only, so they are provably wave-uniform
-    const StateIO io{make_rsrc(hot.state, (uint32_t)(hot.stride * (PZ_STATE_WORDS * 4))), (uint32_t)hot.stride * 4u,
-                     (uint32_t)i * 4u};
+    const StateIO io{make_rsrc(hot.state, PACKED ? 0u : (uint32_t)(hot.stride * (PZ_STATE_WORDS * 4))),
+                     (uint32_t)hot.stride * 4u, (uint32_t)i * 4u};
+    const PackedIO pio = make_packed_io(hot.state, PACKED ? hot.stride : 0, i);
     const bool as_float = a.cfg.ballpos_reward != 0 || a.cfg.normal_state_mode != 0;
     const bool with_stats = a.episode_stats != nullptr && a.cfg.episode_stats_mode != 0;  // uniform
     const StatsIO sio = make_stats_io(a.episode_stats, with_stats, a.stride, i);
@@ -673,7 +730,7 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
     bool ex_pending = false;  // SCOUT: the scout wave stores this lane's expected_landing_point_x
     unsigned int finished = 0;
 #ifdef PZ_ABLATE
-    g_pz_ablate_bits = a.cfg.reserved;  // every lane stores the same value; read by the predictor hooks
+    g_pz_ablate_bits = a.cfg.packed_state;  // every lane stores the same value; read by the predictor hooks
 #endif
     PZ_STAMP(0);
     int a1 = 0, a2 = 0;
@@ -682,8 +739,12 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
         a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.voff, 0, 0);
     }
     EpisodeStats st{0.0, 0.0, 0};
+    PackedWords was{};
     if (live) {
-        load_game(g, io);
+        if constexpr (PACKED)
+            was = load_game_packed(g, pio, true);
+        else
+            load_game(g, io);
         if (with_stats) sio.load(st);
     }
     const Game loaded = g;  // SPARSE: what the columns held before the frame
@@ -747,7 +808,9 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
     }
     PZ_STAMP(2);
     if (live) {
-        if (SPARSE)
+        if constexpr (PACKED)
+            store_game_packed(g, pio, was, true);
+        else if (SPARSE)
             store_game_changed(g, loaded, io, ex_pending);
         else
             store_game(g, io, ex_pending);
@@ -772,7 +835,10 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
 // player's 13 columns, its half of the ball columns (both waves load all 12), player 1's wave also the 6
 // env columns, the episode statistics and `terminated`; each wave writes its own agent's reward and
 // observation tensor; the wave of the (last) computer player keeps ball.expected_landing_point_x.
-template <int ROLE, bool AI1, bool AI2>
+// PACKED (pz_packed.hpp): both waves load groups A and B (16 bytes per lane each), a computer player's wave also the
+// tail; player 1's wave writes group A, player 2's group B, and the tail's three fields are stored byte-wise by their
+// owners behind everything else: a new round's boldness, and the landing point by the wave that keeps it.
+template <int ROLE, bool AI1, bool AI2, bool PACKED>
 __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, int32_t (*lds_obs)[kLanes * PZ_OBS_DIM],
                                           int32_t* __restrict__ xchg, int lane)
 {
@@ -781,8 +847,9 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
     const bool live = i < hot.n;
     const uint32_t n32 = (uint32_t)hot.n;
-    const StateIO io{make_rsrc(hot.state, (uint32_t)(hot.stride * (PZ_STATE_WORDS * 4))), (uint32_t)hot.stride * 4u,
-                     (uint32_t)i * 4u};
+    const StateIO io{make_rsrc(hot.state, PACKED ? 0u : (uint32_t)(hot.stride * (PZ_STATE_WORDS * 4))),
+                     (uint32_t)hot.stride * 4u, (uint32_t)i * 4u};
+    const PackedIO pio = make_packed_io(hot.state, PACKED ? hot.stride : 0, i);
     const bool as_float = a.cfg.ballpos_reward != 0 || a.cfg.normal_state_mode != 0;
     const bool with_stats = ROLE == 0 && a.episode_stats != nullptr && a.cfg.episode_stats_mode != 0;
     const StatsIO sio = make_stats_io(a.episode_stats, with_stats, a.stride, i);
@@ -795,7 +862,17 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     const int a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.voff, 0, 0);
     const int a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.voff, 0, 0);
     EpisodeStats st{0.0, 0.0, 0};
-    if (live) {
+    uint32_t sticky = 0;  // PACKED: the own group's overflow flag, kept
+    if (PACKED && live) {
+        const pk_u32x4 ga = pio.ld_a(), gb = pio.ld_b();
+        const uint32_t tail = kOwnAI ? pio.ld_tail() : 0u;  // computer_boldness is read by the decision only
+        unpack_group_a(g, ga);
+        unpack_group_b(g, gb);
+        unpack_tail(g, tail);
+        sticky = (ROLE == 0 ? ga.y : gb.y) & kPackedOverflowBit;
+        if (with_stats) sio.load(st);
+    }
+    if (!PACKED && live) {
         g.e.round_ended = io.ld(PZ_E_ROUND_ENDED);
         g.e.game_ended = io.ld(PZ_E_GAME_ENDED);
         g.e.rng = (uint32_t)io.ld(PZ_E_RNG_DRAW_COUNTER);
@@ -833,7 +910,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
 #ifdef PZ_ABLATE
     // read by the hooks in pz_physics.hpp; one lane of the launch writes it (131 072 same-address stores would be the
     // slowest thing in the kernel), the launches of one variant run back to back with the same bits
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_pz_ablate_bits = a.cfg.reserved;
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_pz_ablate_bits = a.cfg.packed_state;
 #endif
     LandingProbe after_hit{false, false, 0u};
     bool bold_pending = false;  // a human player's new-round boldness draw, made behind the stores
@@ -846,7 +923,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     // the two halves of the write-back; their order is a compile-time choice (below)
     auto store_state = [&]() {
 #ifdef PZ_ABLATE
-        if (live && (a.cfg.reserved & 4096) != 0 && a.episode_stats != nullptr) {
+        if (live && (a.cfg.packed_state & 4096) != 0 && a.episode_stats != nullptr) {
             // timing-only: what the always-written part of the state would cost as 16-byte column groups: three groups
             // per wave into a scratch buffer handed in through the (unused) statistics pointer
             const Rsrc scratch = make_rsrc(a.episode_stats, (uint32_t)(a.stride * 96));
@@ -862,6 +939,22 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         }
 #endif
         if (!live || PZ_SKIP_STATE_STORES) return;
+        if constexpr (PACKED) {
+            if (ROLE == 0) {
+                pio.st_a(pack_group_a(g, sticky));
+                if (with_stats) sio.store(st);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, make_rsrc(a.terminated, n32),
+                                                     (uint32_t)i, 0, 0);
+            } else {
+                pio.st_b(pack_group_b(g, sticky));
+            }
+            const Rsrc rew = make_rsrc(ROLE == 0 ? a.rew_p1 : a.rew_p2, n32 * 4u);
+            const unsigned int bits = as_float ? __float_as_uint(ROLE == 0 ? rw.f1 : rw.f2)
+                                               : (unsigned int)(ROLE == 0 ? rw.i1 : rw.i2);
+            __builtin_amdgcn_raw_buffer_store_b32(bits, rew, io.voff, 0, 0);
+            PZ_PAIR_STAMP(ROLE, 3);
+            return;
+        }
         // changed-only write-back of the rarely changing columns, as in store_game_changed
         store_player_changed(ROLE == 0 ? g.p1 : g.p2, ROLE == 0 ? loaded.p1 : loaded.p2, io, kOwn);
         if (ROLE == 0) {
@@ -925,16 +1018,30 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     PZ_PAIR_STAMP(ROLE, 6);
     if (bold_pending) {  // draw number loaded.rng + ROLE of the env stream: player 1's, then player 2's (physics.py:218)
         uint32_t counter = loaded.e.rng + (uint32_t)ROLE;
-        io.st(kOwn + PZ_P_COMPUTER_BOLDNESS, rng_integers(id, counter, 5u));
+        const int bold = rng_integers(id, counter, 5u);
+        if constexpr (PACKED)
+            pio.st_bold(ROLE, bold);
+        else
+            io.st(kOwn + PZ_P_COMPUTER_BOLDNESS, bold);
+    }
+    if (PACKED && (AI1 || AI2)) {
+        // the boldness drawn inside the frame (player_new_round): a round started iff the game was live and between rounds
+        const bool started = live && loaded.e.round_ended != 0 && !(loaded.e.game_ended != 0 && a.cfg.auto_reset == 0);
+        if (started) pio.st_bold(ROLE, (ROLE == 0 ? g.p1 : g.p2).bold);
     }
     // last: after a ball-player collision the value comes from a table gather issued at the end of the frame
     if (kKeepsEx) {
         const int ex = lut.landing_finish(after_hit, g.b.x, g.b.y, g.b.xv, g.b.yv, g.b.ex);
-        if (live && ex != loaded.b.ex) io.st(PZ_B_EXPECTED_LANDING_POINT_X, ex);
+        if (live && ex != loaded.b.ex) {
+            if constexpr (PACKED)
+                pio.st_ex(ex);
+            else
+                io.st(PZ_B_EXPECTED_LANDING_POINT_X, ex);
+        }
     }
 }
 
-template <bool AI1, bool AI2>
+template <bool AI1, bool AI2, bool PACKED = false>
 __global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(PZ_HOT_PARAMS, const StepArgs a)
 {
     const HotArgs hot{state, n, stride, act_p1, act_p2};
@@ -946,24 +1053,53 @@ __global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(PZ_HOT_PARAMS, co
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (kLanes - 1);
     if (role == 0)
-        pair_body<0, AI1, AI2>(a, hot, lds_obs, xchg, lane);
+        pair_body<0, AI1, AI2, PACKED>(a, hot, lds_obs, xchg, lane);
     else
-        pair_body<1, AI1, AI2>(a, hot, lds_obs, xchg, lane);
+        pair_body<1, AI1, AI2, PACKED>(a, hot, lds_obs, xchg, lane);
 }
 
 // ---- constructor / reset / observe / policy kernels --------------------------------------------
+// One game in either format, for the kernels outside the step path.
+template <bool PACKED>
+struct AnyIO {
+    StateIO io;
+    PackedIO pio;
+    __device__ __forceinline__ AnyIO(const void* state, int64_t stride, int64_t i)
+        : io{make_rsrc(state, PACKED ? 0u : (uint32_t)(stride * (PZ_STATE_WORDS * 4))), (uint32_t)stride * 4u, (uint32_t)i * 4u},
+          pio(make_packed_io(state, PACKED ? stride : 0, i))
+    {
+    }
+    __device__ __forceinline__ PackedWords load(Game& g) const
+    {
+        if constexpr (PACKED) return load_game_packed(g, pio, true);
+        load_game(g, io);
+        return PackedWords{};
+    }
+    __device__ __forceinline__ void store(const Game& g, const PackedWords& was) const
+    {
+        if constexpr (PACKED) {
+            pio.st_a(pack_group_a(g, was.a.y & kPackedOverflowBit));
+            pio.st_b(pack_group_b(g, was.b.y & kPackedOverflowBit));
+            pio.st_tail(pack_tail(g));
+        } else {
+            store_game(g, io);
+        }
+    }
+};
+
+template <bool PACKED>
 __global__ __launch_bounds__(kLanes) void init_kernel(int32_t* state, int64_t n, int64_t stride, const pz_config cfg)
 {
     const int64_t i = (int64_t)blockIdx.x * kLanes + threadIdx.x;
     if (i >= n) return;
-    const StateIO io{make_rsrc(state, (uint32_t)(stride * (PZ_STATE_WORDS * 4))), (uint32_t)stride * 4u,
-                     (uint32_t)i * 4u};
+    const AnyIO<PACKED> io(state, stride, i);
     Game g;
     const RngId id = make_rng_id(cfg, i);
     construct_game(g, id);
-    store_game(g, io);
+    io.store(g, PackedWords{});
 }
 
+template <bool PACKED>
 __global__ __launch_bounds__(kLanes) void reset_kernel(int32_t* state, int64_t n, int64_t stride, const pz_config cfg,
                                                        const uint8_t* mask, int32_t* obs_p1, int32_t* obs_p2,
                                                        void* episode_stats)
@@ -971,15 +1107,14 @@ __global__ __launch_bounds__(kLanes) void reset_kernel(int32_t* state, int64_t n
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     const int lane = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
-    const StateIO io{make_rsrc(state, (uint32_t)(stride * (PZ_STATE_WORDS * 4))), (uint32_t)stride * 4u,
-                     (uint32_t)i * 4u};
+    const AnyIO<PACKED> io(state, stride, i);
     if (i < n) {
         Game g;
-        load_game(g, io);
+        const PackedWords was = io.load(g);
         if (mask == nullptr || mask[i] != 0) {
             const RngId id = make_rng_id(cfg, i);
             reset_game(g, cfg, id);
-            store_game(g, io);
+            io.store(g, was);
             if (episode_stats != nullptr)  // RecordEpisodeStatistics.reset (:23-25)
                 make_stats_io(episode_stats, true, stride, i).store(EpisodeStats{0.0, 0.0, 0});
         }
@@ -990,17 +1125,17 @@ __global__ __launch_bounds__(kLanes) void reset_kernel(int32_t* state, int64_t n
     if (obs_p2 != nullptr) flush_rows(lds_obs[1], obs_p2, (uint32_t)n * kRowBytes, lane);
 }
 
+template <bool PACKED>
 __global__ __launch_bounds__(kLanes) void observe_kernel(const int32_t* state, int64_t n, int64_t stride,
                                                          int normalize, int32_t* obs_p1, int32_t* obs_p2)
 {
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     const int lane = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
-    const StateIO io{make_rsrc(state, (uint32_t)(stride * (PZ_STATE_WORDS * 4))), (uint32_t)stride * 4u,
-                     (uint32_t)i * 4u};
+    const AnyIO<PACKED> io(state, stride, i);
     if (i < n) {
         Game g;
-        load_game(g, io);
+        io.load(g);
         stage_obs(g, lds_obs[0], lds_obs[1], lane, normalize != 0);
     }
     __syncthreads();
@@ -1019,6 +1154,32 @@ __global__ __launch_bounds__(256) void random_actions_kernel(int32_t* act_p1, in
     policy_actions((uint32_t)gid, (uint32_t)(gid >> 32), action_seed, t, n_actions, a1, a2);
     act_p1[i] = a1;
     act_p2[i] = a2;
+}
+
+// ---- int32 columns <-> packed format (pz_pack_state / pz_unpack_state) ----------------------------------------
+__global__ __launch_bounds__(kLanes) void pack_state_kernel(const int32_t* state, int64_t n, int64_t stride, void* packed,
+                                                            int64_t packed_stride, unsigned long long* misfits)
+{
+    const int64_t i = (int64_t)blockIdx.x * kLanes + threadIdx.x;
+    if (i >= n) return;
+    Game g;
+    AnyIO<false>(state, stride, i).load(g);
+    const bool fits = game_fits(g);
+    if (!fits && misfits != nullptr) atomicAdd(misfits, 1ull);
+    PackedWords flagged{};
+    flagged.a.y = fits ? 0u : kPackedOverflowBit;  // a misfit stays visible in the packed state
+    AnyIO<true>(packed, packed_stride, i).store(g, flagged);
+}
+
+__global__ __launch_bounds__(kLanes) void unpack_state_kernel(const void* packed, int64_t n, int64_t packed_stride,
+                                                              int32_t* state, int64_t stride, unsigned long long* flagged)
+{
+    const int64_t i = (int64_t)blockIdx.x * kLanes + threadIdx.x;
+    if (i >= n) return;
+    Game g;
+    const PackedWords w = AnyIO<true>(packed, packed_stride, i).load(g);
+    if (((w.a.y | w.b.y) & kPackedOverflowBit) != 0 && flagged != nullptr) atomicAdd(flagged, 1ull);
+    AnyIO<false>(state, stride, i).store(g, PackedWords{});
 }
 
 // ---- flight tables (pz_build_flight_tables) -----------------------------------------------------
@@ -1180,6 +1341,9 @@ constexpr int64_t kMaxLanesPerLaunch = (int64_t)0xFFFFFFFFu / (PZ_STATE_WORDS * 
 //   and is used by every launch that writes the state back after ONE frame; a trajectory launch writes it once
 //   per k frames, where the plain write-back is always right.
 
+static inline bool is_packed(const pz_config& cfg) { return (cfg.packed_state & 1) != 0; }
+static inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
 static int check_common(const void* state, int64_t n, int64_t stride, const pz_config* cfg)
 {
     if (state == nullptr || cfg == nullptr) return PZ_E_NULL;
@@ -1187,34 +1351,42 @@ static int check_common(const void* state, int64_t n, int64_t stride, const pz_c
     if (cfg->winning_score < 1 || cfg->serve_mode < 0 || cfg->serve_mode > 2 || cfg->normal_state_mode < 0 ||
         cfg->normal_state_mode > 2 || cfg->episode_stats_mode < 0 || cfg->episode_stats_mode > 2)
         return PZ_E_CONFIG;
+#ifndef PZ_ABLATE  // the timing-only build passes its switches in the upper bits of this field
+    if (cfg->packed_state != 0 && cfg->packed_state != 1) return PZ_E_CONFIG;
+#endif
+    if (is_packed(*cfg)) {
+        if (cfg->winning_score > 65535) return PZ_E_CONFIG;  // the scores are 16-bit fields
+        if (misaligned16(state)) return PZ_E_ALIGN;
+    }
     return PZ_OK;
 }
 
-static inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
-
 static inline unsigned int blocks_for(int64_t n, int per) { return (unsigned int)((n + per - 1) / per); }
 
-template <int MODE, bool SPARSE>
+template <int MODE, bool SPARSE, bool PACKED = false>
 static int launch_step_ai(const StepArgs& a, hipStream_t stream)
 {
     const dim3 grid(blocks_for(a.n, kLanes)), block(kLanes);
     const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
     if (ai1 && ai2)
-        hipLaunchKernelGGL((step_kernel<true, true, MODE, SPARSE>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+        hipLaunchKernelGGL((step_kernel<true, true, MODE, SPARSE, kNoScout, PACKED>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
     else if (ai1)
-        hipLaunchKernelGGL((step_kernel<true, false, MODE, SPARSE>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+        hipLaunchKernelGGL((step_kernel<true, false, MODE, SPARSE, kNoScout, PACKED>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
     else if (ai2)
-        hipLaunchKernelGGL((step_kernel<false, true, MODE, SPARSE>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+        hipLaunchKernelGGL((step_kernel<false, true, MODE, SPARSE, kNoScout, PACKED>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
     else
-        hipLaunchKernelGGL((step_kernel<false, false, MODE, SPARSE>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+        hipLaunchKernelGGL((step_kernel<false, false, MODE, SPARSE, kNoScout, PACKED>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
     return (int)hipGetLastError();
 }
 
 template <bool AI1, bool AI2>
 static int launch_pair(const StepArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL((step_pair_kernel<AI1, AI2>), dim3(blocks_for(a.n, kLanes)), dim3(2 * kLanes), 0, stream,
-                       PZ_HOT_ARGS(a), a);
+    const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
+    if (is_packed(a.cfg))
+        hipLaunchKernelGGL((step_pair_kernel<AI1, AI2, true>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+    else
+        hipLaunchKernelGGL((step_pair_kernel<AI1, AI2, false>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
     return (int)hipGetLastError();
 }
 
@@ -1232,6 +1404,9 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
         return launch_pair<false, false>(a, stream);
     }
 #endif
+    // the packed format: pair kernel above, else one wave per workgroup (a computer player without tables computes its
+    // flights in that wave: no scout)
+    if (is_packed(a.cfg)) return launch_step_ai<MODE, false, true>(a, stream);
 #if !defined(PZ_NO_SCOUT_WAVE) && !defined(PZ_ABLATE) && !defined(PZ_STAMPS)
     if (a.n < PZ_TWO_WAVE_MAX_LANES && !tables) {  // a computer player is present (else: pair kernel above)
         constexpr int kScout = MODE == kActions ? kScoutLoads : kScoutPosted;
@@ -1297,7 +1472,7 @@ const char* pz_error_string(int code)
         case PZ_E_NULL: return "required pointer is NULL";
         case PZ_E_SIZE: return "bad size (n < 0, stride < n, k < 1, or more than 24 403 223 games in one launch)";
         case PZ_E_CONFIG: return "pz_config field out of range";
-        case PZ_E_ALIGN: return "observation buffer is not 16-byte aligned";
+        case PZ_E_ALIGN: return "buffer is not 16-byte aligned (observations, packed state, power_hit table)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown pikazoo error";
     }
 }
@@ -1306,8 +1481,12 @@ int pz_init(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, voi
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (n == 0) return PZ_OK;
-    hipLaunchKernelGGL(init_kernel, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, state, n, stride,
-                       *cfg);
+    if (is_packed(*cfg))
+        hipLaunchKernelGGL(init_kernel<true>, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, state, n,
+                           stride, *cfg);
+    else
+        hipLaunchKernelGGL(init_kernel<false>, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, state, n,
+                           stride, *cfg);
     return (int)hipGetLastError();
 }
 
@@ -1317,20 +1496,56 @@ int pz_reset(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, co
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
-    hipLaunchKernelGGL(reset_kernel, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, state, n,
-                       stride, *cfg, mask, obs_p1, obs_p2, episode_stats);
+    if (is_packed(*cfg))
+        hipLaunchKernelGGL(reset_kernel<true>, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, state, n,
+                           stride, *cfg, mask, obs_p1, obs_p2, episode_stats);
+    else
+        hipLaunchKernelGGL(reset_kernel<false>, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, state, n,
+                           stride, *cfg, mask, obs_p1, obs_p2, episode_stats);
     return (int)hipGetLastError();
 }
 
-int pz_observe(const int32_t* state, int64_t n, int64_t stride, int32_t normalize, int32_t* obs_p1, int32_t* obs_p2,
-               void* stream)
+int pz_observe(const int32_t* state, int64_t n, int64_t stride, int32_t normalize, int32_t packed, int32_t* obs_p1,
+               int32_t* obs_p2, void* stream)
 {
     if (state == nullptr) return PZ_E_NULL;
     if (n < 0 || stride < n || stride > kMaxLanesPerLaunch) return PZ_E_SIZE;
-    if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
+    if (misaligned16(obs_p1) || misaligned16(obs_p2) || (packed != 0 && misaligned16(state))) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
-    hipLaunchKernelGGL(observe_kernel, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, state, n,
-                       stride, (int)normalize, obs_p1, obs_p2);
+    if (packed != 0)
+        hipLaunchKernelGGL(observe_kernel<true>, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, state,
+                           n, stride, (int)normalize, obs_p1, obs_p2);
+    else
+        hipLaunchKernelGGL(observe_kernel<false>, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, state,
+                           n, stride, (int)normalize, obs_p1, obs_p2);
+    return (int)hipGetLastError();
+}
+
+int64_t pz_packed_state_bytes(int64_t stride) { return stride < 0 ? 0 : stride * PZ_PACKED_BYTES_PER_GAME; }
+
+int pz_pack_state(const int32_t* state, int64_t n, int64_t stride, void* packed, int64_t packed_stride, int64_t* misfits,
+                  void* stream)
+{
+    if (state == nullptr || packed == nullptr) return PZ_E_NULL;
+    if (n < 0 || stride < n || packed_stride < n || stride > kMaxLanesPerLaunch || packed_stride > kMaxLanesPerLaunch)
+        return PZ_E_SIZE;
+    if (misaligned16(packed)) return PZ_E_ALIGN;
+    if (n == 0) return PZ_OK;
+    hipLaunchKernelGGL(pack_state_kernel, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, state, n,
+                       stride, packed, packed_stride, reinterpret_cast<unsigned long long*>(misfits));
+    return (int)hipGetLastError();
+}
+
+int pz_unpack_state(const void* packed, int64_t n, int64_t packed_stride, int32_t* state, int64_t stride, int64_t* flagged,
+                    void* stream)
+{
+    if (state == nullptr || packed == nullptr) return PZ_E_NULL;
+    if (n < 0 || stride < n || packed_stride < n || stride > kMaxLanesPerLaunch || packed_stride > kMaxLanesPerLaunch)
+        return PZ_E_SIZE;
+    if (misaligned16(packed)) return PZ_E_ALIGN;
+    if (n == 0) return PZ_OK;
+    hipLaunchKernelGGL(unpack_state_kernel, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, packed, n,
+                       packed_stride, state, stride, reinterpret_cast<unsigned long long*>(flagged));
     return (int)hipGetLastError();
 }
 

@@ -11,7 +11,8 @@ from pathlib import Path
 PKG_ROOT = Path(__file__).resolve().parent.parent  # .../pika-zoo_amd
 LIB_PATH = PKG_ROOT / "lib" / "libpikazoo_hip.so"
 
-ABI_VERSION = 4
+ABI_VERSION = 5
+PACKED_BYTES_PER_GAME = 36
 STATE_WORDS = 44
 OBS_DIM = 35
 SERVE_MODES = {"winner": 0, "alternate": 1, "random": 2}
@@ -32,7 +33,7 @@ class PzConfig(C.Structure):
         ("y_line", C.c_int32),
         ("additional_reward", C.c_float * 8),
         ("auto_reset", C.c_int32),
-        ("reserved", C.c_int32),
+        ("packed_state", C.c_int32),
         ("normal_state_mode", C.c_int32),
         ("normal_state_reward", C.c_float),
         ("normalize_obs", C.c_int32),
@@ -65,7 +66,10 @@ _SIGNATURES = {
     "pz_build_flight_tables": (C.c_int, [_P, _P, _P]),
     "pz_init": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P]),
     "pz_reset": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, _P, _P, _P, _P]),
-    "pz_observe": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, _P, _P, _P]),
+    "pz_observe": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
+    "pz_packed_state_bytes": (C.c_int64, [C.c_int64]),
+    "pz_pack_state": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P]),
+    "pz_unpack_state": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P]),
     # (the argument before the stream is `const pz_flight_tables*`: a byref(PzFlightTables) or None)
     "pz_step": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pz_step_random": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), C.c_uint64, C.c_uint64,

@@ -96,7 +96,11 @@ class raw_env:
     scalars and empty ``agents`` on termination, i.e. the reference's exact return types;
     ``auto_reset`` then defaults to False, so that ``while env.agents:`` loops end like they do around
     the reference); ``flight_tables`` (computer players only: look the flight predictions up in the
-    per-device HBM tables instead of iterating them in the kernel; results are identical).
+    per-device HBM tables instead of iterating them in the kernel; results are identical);
+    ``state_format`` ("int32": the state lives in HBM as the ``int32[44, num_envs]`` tensor :attr:`state`,
+    live and writable; "packed": as 36 bytes per game instead of 176 -- the bit-packed format of
+    ``include/pikazoo_hip.h`` -- which makes large batches about a third faster; every result is identical,
+    :attr:`state` then returns an unpacked copy, and checkpoints are interchangeable between the two).
 
     Returned tensors are views of env-owned buffers that the next ``step`` overwrites;
     ``clone()`` what must outlive it.
@@ -108,7 +112,7 @@ class raw_env:
                  is_player2_computer: bool = False, render_mode=None, *, num_envs: int = 1,
                  device="cuda", seed: int = 0, env_id_base: int = 0, auto_reset: Optional[bool] = None,
                  validate_actions: bool = True, scalar_api: bool = False, flight_tables: bool = True,
-                 sprite_dir=None, sprites=None):
+                 sprite_dir=None, sprites=None, state_format: str = "int32"):
         assert serve in ("winner", "alternate", "random")  # pikazoo_env.py:104
         if render_mode not in (None, "rgb_array"):
             raise NotImplementedError('render_mode must be None or "rgb_array" (no "human" window on a GPU batch)')
@@ -116,6 +120,10 @@ class raw_env:
             raise ValueError("winning_score must be >= 1")
         if int(num_envs) < 1:
             raise ValueError("num_envs must be >= 1")
+        if state_format not in ("int32", "packed"):
+            raise ValueError('state_format must be "int32" or "packed"')
+        if state_format == "packed" and int(winning_score) > 32767:
+            raise ValueError("the packed state format holds scores up to 32767")
         self._lib = _native.load()  # raises when the HIP library has not been built
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -143,6 +151,7 @@ class raw_env:
         self.scalar_api = bool(scalar_api)
         self.seed = int(seed)
         self.env_id_base = int(env_id_base)
+        self.state_format = state_format
 
         cfg = _native.PzConfig()
         cfg.winning_score = self.winning_score
@@ -153,6 +162,7 @@ class raw_env:
         cfg.ballpos_reward = 0
         cfg.x_line, cfg.y_line = 216, 176
         cfg.auto_reset = int(self.auto_reset)
+        cfg.packed_state = int(state_format == "packed")
         cfg.seed = self.seed & 0xFFFFFFFFFFFFFFFF
         cfg.env_id_base = self.env_id_base
         self._cfg = cfg
@@ -167,8 +177,17 @@ class raw_env:
         # columns are padded to a multiple of 64 games so that every workgroup's 256-byte segment of a column is
         # aligned whatever num_envs is (a ragged pitch costs ~10 % per launch); `state` is the [44, n] view
         self._stride = (n + 63) // 64 * 64
-        self._state_buf = torch.zeros((_native.STATE_WORDS, self._stride), dtype=torch.int32, device=dev)
-        self.state = self._state_buf[:, :n]
+        if cfg.packed_state:
+            # group A [stride][4] dwords, group B [stride][4] dwords, tail [stride] dwords (include/pikazoo_hip.h)
+            self._state_buf = torch.zeros(_native.PACKED_BYTES_PER_GAME * self._stride, dtype=torch.uint8, device=dev)
+            self._state_view = None
+            # the two scores are the halves of group A's third dword: a live int16 [n, 2] view
+            self._scores = self._state_buf[:16 * self._stride].view(torch.int16).view(self._stride, 8)[:n, 4:6]
+        else:
+            self._state_buf = torch.zeros((_native.STATE_WORDS, self._stride), dtype=torch.int32, device=dev)
+            self._state_view = self._state_buf[:, :n]
+            self._scores = self._state_view[_E_SCORE_P1:_E_SCORE_P1 + 2].t()  # live [n, 2] view of the state
+        self._state_ptr = self._state_buf.data_ptr()
         self._obs = [torch.zeros((n, _native.OBS_DIM), dtype=torch.int32, device=dev) for _ in range(2)]
         # one 4-byte word per lane and agent; viewed as int32 or float32 (RewardByBallPosition)
         self._rew_raw = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
@@ -180,16 +199,15 @@ class raw_env:
         self._ep_returns = self._ep_lengths = None
         # raw pointers of the env-owned buffers (fixed for the env's lifetime) and the cached result tuple:
         # the dicts returned by step() hold views of those buffers, so they can be reused between steps
-        self._ptrs = (self.state.data_ptr(), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
+        self._ptrs = (self._state_ptr, self._obs[0].data_ptr(), self._obs[1].data_ptr(),
                       self._rew_raw[0].data_ptr(), self._rew_raw[1].data_ptr(), self._term_u8.data_ptr())
         self._step_result = None
-        self._scores = self.state[_E_SCORE_P1:_E_SCORE_P1 + 2].t()  # live [n, 2] view of the state
         self.steps_done = 0  # frames stepped by this env (per lane)
 
         self.action_spaces = {a: Discrete(18) for a in self.possible_agents}
         self._spaces = {}
         with torch.cuda.device(self.device):
-            _native.check(self._lib.pz_init(self.state.data_ptr(), n, self._stride, self._cfg_ref, self._stream()),
+            _native.check(self._lib.pz_init(self._state_ptr, n, self._stride, self._cfg_ref, self._stream()),
                           "pz_init")
 
     # ------------------------------------------------------------------------------------------
@@ -211,8 +229,48 @@ class raw_env:
 
     @property
     def scores(self) -> torch.Tensor:
-        """``int32[num_envs, 2]`` live view (the reference's ``scores`` list, pikazoo_env.py:100)."""
+        """``[num_envs, 2]`` live view (the reference's ``scores`` list, pikazoo_env.py:100): int32, or int16 with
+        the packed state format."""
         return self._scores
+
+    @property
+    def state(self) -> torch.Tensor:
+        """The game state as ``int32[44, num_envs]`` (rows: ``pz_player_field`` x 2, ``pz_ball_field``,
+        ``pz_env_field`` of include/pikazoo_hip.h).  With ``state_format="int32"`` this is the live tensor the
+        kernels step (writable); with "packed" it is an unpacked copy -- write through :meth:`set_state`."""
+        if self._state_view is not None:
+            return self._state_view
+        return self._unpacked()[0][:, :self.num_envs]
+
+    def _unpacked(self):
+        """(int32[44, stride] copy of the packed state, its stride)"""
+        out = torch.empty((_native.STATE_WORDS, self._stride), dtype=torch.int32, device=self.device)
+        flagged = torch.zeros(1, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.pz_unpack_state(self._state_ptr, self.num_envs, self._stride, out.data_ptr(),
+                                                    self._stride, flagged.data_ptr(), self._stream()), "pz_unpack_state")
+        if int(flagged.item()):
+            raise _native.PikazooNativeError(
+                f"{int(flagged.item())} games carry the packed format's misfit flag: a value left its field")
+        return out, self._stride
+
+    def set_state(self, state: torch.Tensor):
+        """Overwrite the state of every game with ``int32[44, num_envs]`` columns (either format)."""
+        state = torch.as_tensor(state, device=self.device)
+        if state.shape != (_native.STATE_WORDS, self.num_envs) or state.dtype != torch.int32:
+            raise ValueError(f"state must be int32[{_native.STATE_WORDS}, {self.num_envs}]")
+        if self._state_view is not None:
+            self._state_view.copy_(state)
+            return
+        src = state.contiguous()
+        misfits = torch.zeros(1, dtype=torch.int64, device=self.device)
+        staged = torch.empty_like(self._state_buf)
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.pz_pack_state(src.data_ptr(), self.num_envs, self.num_envs, staged.data_ptr(),
+                                                  self._stride, misfits.data_ptr(), self._stream()), "pz_pack_state")
+        if int(misfits.item()):
+            raise ValueError(f"{int(misfits.item())} games hold values outside the packed format's fields")
+        self._state_buf.copy_(staged)
 
     @property
     def episodes_done(self) -> int:
@@ -374,7 +432,7 @@ class raw_env:
             if m.shape != (self.num_envs,):
                 raise ValueError(f"mask must have shape ({self.num_envs},)")
         with torch.cuda.device(self.device):
-            _native.check(self._lib.pz_reset(self.state.data_ptr(), self.num_envs, self._stride, self._cfg_ref,
+            _native.check(self._lib.pz_reset(self._state_ptr, self.num_envs, self._stride, self._cfg_ref,
                                              _ptr(m), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
                                              self._stats_ptr(), self._stream()), "pz_reset")
         if self.scalar_api:
@@ -447,7 +505,7 @@ class raw_env:
         if t0 is None:
             t0 = self.steps_done
         with torch.cuda.device(self.device):
-            _native.check(self._lib.pz_step_random(self.state.data_ptr(), self.num_envs, self._stride,
+            _native.check(self._lib.pz_step_random(self._state_ptr, self.num_envs, self._stride,
                                                    self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0),
                                                    int(k), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
                                                    self._rew_raw[0].data_ptr(), self._rew_raw[1].data_ptr(),
@@ -479,7 +537,7 @@ class raw_env:
                    "_term": torch.empty((k, n), dtype=torch.uint8, device=dev)}
         with torch.cuda.device(dev):
             _native.check(self._lib.pz_rollout_random(
-                self.state.data_ptr(), n, self._stride, self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0), k,
+                self._state_ptr, n, self._stride, self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0), k,
                 out["actions"].data_ptr(), out["_obs"][0].data_ptr(), out["_obs"][1].data_ptr(),
                 out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(), out["_term"].data_ptr(),
                 self._stats_ptr(), self._episodes.data_ptr(), self._tables_ref, self._stream()), "pz_rollout_random")
@@ -508,7 +566,7 @@ class raw_env:
         out["actions"] = actions
         with torch.cuda.device(dev):
             _native.check(self._lib.pz_step_many(
-                self.state.data_ptr(), n, self._stride, self._cfg_ref, actions.data_ptr(), k, out["_obs"][0].data_ptr(),
+                self._state_ptr, n, self._stride, self._cfg_ref, actions.data_ptr(), k, out["_obs"][0].data_ptr(),
                 out["_obs"][1].data_ptr(), out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(),
                 out["_term"].data_ptr(), self._stats_ptr(), self._episodes.data_ptr(), self._tables_ref,
                 self._stream()), "pz_step_many")
@@ -546,9 +604,9 @@ class raw_env:
         o1 = torch.empty_like(self._obs[0])
         o2 = torch.empty_like(self._obs[1])
         with torch.cuda.device(self.device):
-            _native.check(self._lib.pz_observe(self.state.data_ptr(), self.num_envs, self._stride,
-                                               int(self._cfg.normalize_obs), o1.data_ptr(), o2.data_ptr(),
-                                               self._stream()), "pz_observe")
+            _native.check(self._lib.pz_observe(self._state_ptr, self.num_envs, self._stride,
+                                               int(self._cfg.normalize_obs), int(self._cfg.packed_state),
+                                               o1.data_ptr(), o2.data_ptr(), self._stream()), "pz_observe")
         odt = self.obs_dtype
         return {self.possible_agents[0]: o1.view(odt), self.possible_agents[1]: o2.view(odt)}
 
@@ -574,7 +632,7 @@ class raw_env:
         """Restore a :meth:`state_dict`.  Raises when it was taken from an env whose Philox key, game ids or
         (fused-wrapper) configuration differ from this one: the continuation would silently be another
         trajectory."""
-        if sd["state"].shape != self.state.shape:
+        if tuple(sd["state"].shape) != (_native.STATE_WORDS, self.num_envs):
             raise ValueError("state shape mismatch")
         cfg = sd.get("config")
         if cfg is not None:
@@ -587,7 +645,7 @@ class raw_env:
         stats = sd.get("episode_stats")
         if (stats is None) != (self._stats is None):
             raise ValueError("checkpoint and env disagree on RecordEpisodeStatistics")
-        self.state.copy_(sd["state"])
+        self.set_state(sd["state"])
         if stats is not None:
             self._stats.copy_(stats)
         if sd.get("episodes_done") is not None:
@@ -622,7 +680,8 @@ class raw_env:
         elif self.num_envs * _render.HEIGHT * _render.WIDTH * 3 > (1 << 30):
             raise ValueError(f"rendering all {self.num_envs} games needs more than 1 GiB: pass lanes=")
         with torch.cuda.device(self.device):
-            frames = _render.render(self._lib, self.state, self.num_envs, self._stride, self._sprites, lane_t,
+            state = self._state_buf if self._state_view is not None else self._unpacked()[0]  # pz_render reads int32 columns
+            frames = _render.render(self._lib, state, self.num_envs, self._stride, self._sprites, lane_t,
                                     self._stream(), out)
         return frames[0].cpu().numpy() if self.scalar_api else frames
 

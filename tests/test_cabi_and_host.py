@@ -43,7 +43,7 @@ def test_binding_matches_library_layout(built_lib):
     from pikazoo_amd import _native
 
     lib = _native.load()
-    assert lib.pz_abi_version() == 4 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
+    assert lib.pz_abi_version() == 5 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
     assert lib.pz_config_bytes() == C.sizeof(_native.PzConfig) == 104
     assert lib.pz_error_string(0) == b"ok" and b"NULL" in lib.pz_error_string(-1)
     assert C.sizeof(_native.PzFlightTables) == 16
@@ -185,7 +185,7 @@ def test_argument_validation_without_a_gpu(built_lib):
     assert lib.pz_step(fake, 0, 0, C.byref(cfg), None, fake, fake, fake, fake, fake, fake, None, None, None) == -1
     assert lib.pz_step_random(fake, 0, 0, C.byref(cfg), 1, 0, 0, fake, fake, fake, fake, fake, None, None, None,
                               None) == -2
-    assert lib.pz_observe(fake, 0, 0, 0, C.c_void_p(4100), fake, None) == -4   # PZ_E_ALIGN
+    assert lib.pz_observe(fake, 0, 0, 0, 0, C.c_void_p(4100), fake, None) == -4   # PZ_E_ALIGN
     assert lib.pz_step(fake, 0, 0, C.byref(cfg), fake, fake, fake, fake, fake, fake, fake, None, None, None) == 0
     bad = _native.PzFlightTables(None, 4104)  # power-hit table not 16-byte aligned
     assert lib.pz_step(fake, 8, 8, C.byref(cfg), fake, fake, fake, fake, fake, fake, fake, None, C.byref(bad),
@@ -220,7 +220,12 @@ def test_no_vmem_store_data_hazard_in_device_code(built_lib, tmp_path):
             continue
         stores += 1
         lo, hi = int(m.group(1)), int(m.group(2))
-        for nxt in ins[k + 1:k + 3]:  # two issue slots cover the one (gfx90a: two) required wait states
+        states = 0  # wait states since the store: the hazard needs one (gfx90a: two); `s_nop N` supplies N + 1
+        for nxt in ins[k + 1:k + 3]:
+            if states >= 2:
+                break
+            nop = re.match(r"s_nop (\d+)", nxt)
+            states += int(nop.group(1)) + 1 if nop else 1
             w = re.match(r"v_(?!cmp|nop|readfirstlane|readlane)\w+ (?:v\[(\d+):(\d+)\]|v(\d+))", nxt)
             if w:
                 a, b = (int(w.group(1)), int(w.group(2))) if w.group(1) else (int(w.group(3)),) * 2

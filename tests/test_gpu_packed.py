@@ -1,0 +1,305 @@
+"""GPU tests of the packed state format (``cfg->packed_state`` / ``state_format="packed"``, 36 bytes per game):
+what is specific to the format.  The trajectory and oracle parity tests of test_gpu_parity.py run in both formats
+(their ``fmt`` parameter); here: pack / unpack round trips and misfit detection through the C ABI, the k-frame
+launches, masked resets and frozen games, both sides of the kernel switch, the headline size on every lane, and
+checkpoints moving between the two formats.  Bar: bit-exact, as everywhere.
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import cpu, make_env
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from pikazoo_amd import _native
+
+    return _native.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _pack(state, n, stride, pstride):
+    lib = _lib()
+    packed = torch.zeros(lib.pz_packed_state_bytes(pstride), dtype=torch.uint8, device=state.device)
+    misfits = torch.zeros(1, dtype=torch.int64, device=state.device)
+    assert lib.pz_pack_state(state.data_ptr(), n, stride, packed.data_ptr(), pstride, misfits.data_ptr(), _stream()) == 0
+    return packed, int(misfits.item())
+
+
+def _unpack(packed, n, pstride, stride):
+    lib = _lib()
+    out = torch.full((44, stride), -77, dtype=torch.int32, device=packed.device)
+    flagged = torch.zeros(1, dtype=torch.int64, device=packed.device)
+    assert lib.pz_unpack_state(packed.data_ptr(), n, pstride, out.data_ptr(), stride, flagged.data_ptr(), _stream()) == 0
+    return out, int(flagged.item())
+
+
+# field ranges of the packed format (include/pikazoo_hip.h), per state row: (low, high) inclusive
+_PLAYER_RANGES = [(0, 511), (0, 255), (-32, 31), (0, 7), (0, 7), None, (0, 7), (-1, 1), (-2, 5), (0, 1), (0, 255), (0, 1),
+                  (0, 1)]
+_BALL_RANGES = [(0, 511), (0, 255), (-32, 31), (-4096, 4095), (0, 1), (0, 511), (0, 255), (0, 511), (0, 255), (0, 63),
+                (0, 65535), (0, 511)]
+_ENV_RANGES = [(0, 65535), (0, 65535), (0, 1), (0, 1), (0, 1), None]
+
+
+def _random_state(n, gen):
+    rows = []
+    for rng in _PLAYER_RANGES + _PLAYER_RANGES + _BALL_RANGES + _ENV_RANGES:
+        if rng is None:
+            rows.append(None)
+        else:
+            rows.append(torch.randint(rng[0], rng[1] + 1, (n,), generator=gen, dtype=torch.int64).to(torch.int32))
+    for c in (5, 18):  # arm_swing_direction is +-1
+        rows[c] = (torch.randint(0, 2, (n,), generator=gen, dtype=torch.int64) * 2 - 1).to(torch.int32)
+    rows[43] = torch.randint(-2 ** 31, 2 ** 31, (n,), generator=gen, dtype=torch.int64).to(torch.int32)  # rng counter
+    return torch.stack(rows)
+
+
+def test_pack_unpack_round_trip_over_the_whole_field_ranges():
+    """Every field at random over its whole packed range (far beyond what play produces), odd sizes, strides larger
+    than n on both sides, and the extremes of every field on a few lanes."""
+    gen = torch.Generator().manual_seed(5)
+    n, stride, pstride = 10_000 + 37, 10_112, 10_240
+    st = _random_state(n, gen)
+    ranges = _PLAYER_RANGES + _PLAYER_RANGES + _BALL_RANGES + _ENV_RANGES
+    for c, rng in enumerate(ranges):  # lanes 0 / 1: all minima / all maxima
+        if rng is not None:
+            st[c, 0], st[c, 1] = rng[0], rng[1]
+    st[5, 0] = st[18, 0] = -1
+    st[5, 1] = st[18, 1] = 1
+    st[43, 0], st[43, 1] = -2 ** 31, 2 ** 31 - 1
+    dev = torch.device("cuda:0")
+    state = torch.zeros((44, stride), dtype=torch.int32, device=dev)
+    state[:, :n] = st.to(dev)
+    packed, misfits = _pack(state, n, stride, pstride)
+    assert misfits == 0
+    back, flagged = _unpack(packed, n, pstride, stride)
+    assert flagged == 0
+    assert torch.equal(back[:, :n], state[:, :n])
+    assert bool((back[:, n:] == -77).all())  # lanes past n are not written
+
+
+def test_pack_counts_states_that_do_not_fit_and_the_flag_survives():
+    dev = torch.device("cuda:0")
+    env = make_env(num_envs=256, seed=1)
+    env.reset()
+    env.step_random(3, k=40)
+    state = env.unwrapped.state.contiguous().clone()
+    packed, misfits = _pack(state, 256, 256, 256)
+    assert misfits == 0
+    bad = state.clone()
+    bad[29, 7] = 5000      # ball y velocity beyond the 13-bit field
+    bad[0, 9] = -3         # player 1 x negative
+    bad[38, 100] = 70000   # score beyond 16 bits
+    bad[5, 11] = 0         # arm_swing_direction is +-1
+    packed, misfits = _pack(bad, 256, 256, 256)
+    assert misfits == 4
+    back, flagged = _unpack(packed, 256, 256, 256)
+    assert flagged == 4
+    good = torch.ones(256, dtype=torch.bool, device=dev)
+    good[[7, 9, 100, 11]] = False
+    assert torch.equal(back[:, good], state[:, good])
+    # the Python host refuses both directions
+    penv = make_env(num_envs=256, seed=1, state_format="packed")
+    with pytest.raises(ValueError, match="outside the packed format"):
+        penv.unwrapped.set_state(bad)
+    penv.unwrapped._state_buf.copy_(packed)
+    with pytest.raises(RuntimeError, match="misfit flag"):
+        penv.unwrapped.state
+    lib = _lib()
+    assert lib.pz_packed_state_bytes(1000) == 36000
+    assert lib.pz_pack_state(state.data_ptr(), 256, 256, packed.data_ptr() + 4, 256, None, _stream()) == -4  # PZ_E_ALIGN
+    assert lib.pz_pack_state(state.data_ptr(), 256, 128, packed.data_ptr(), 256, None, _stream()) == -2      # PZ_E_SIZE
+    assert lib.pz_unpack_state(None, 256, 256, state.data_ptr(), 256, None, _stream()) == -1                 # PZ_E_NULL
+
+
+def test_packed_config_limits():
+    from pikazoo_amd import _native
+
+    with pytest.raises(ValueError, match="32767"):
+        make_env(num_envs=4, winning_score=40000, state_format="packed")
+    env = make_env(num_envs=64, state_format="packed")
+    raw = env.unwrapped
+    raw._cfg.winning_score = 70000  # the C ABI's own limit: 16-bit score fields
+    with pytest.raises(_native.PikazooNativeError):
+        env.reset()
+    raw._cfg.winning_score = 15
+    raw._cfg.packed_state = 2
+    with pytest.raises(_native.PikazooNativeError):
+        env.reset()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(is_player2_computer=True),
+                                dict(is_player1_computer=True, is_player2_computer=True, flight_tables=False)])
+def test_packed_equals_int32_in_every_launch_mode(kw, oracle):
+    """pz_step, pz_step_random (k = 1 and k = 23), pz_rollout_random and pz_step_many in both formats from the same
+    start: identical states, outputs and trajectories; the end state against the oracle."""
+    n, aseed = 4096 + 64, 77
+    base = dict(num_envs=n, seed=21, env_id_base=1 << 20, winning_score=2, serve="random")
+    a = make_env(state_format="int32", **base, **kw)
+    b = make_env(state_format="packed", **base, **kw)
+    ra, rb = a.unwrapped, b.unwrapped
+    assert torch.equal(ra.state, rb.state)
+    oa, ob = a.reset()[0], b.reset()[0]
+    assert torch.equal(oa["player_1"], ob["player_1"]) and torch.equal(ra.state, rb.state)
+    t = 0
+    for _ in range(60):
+        acts = ra.random_actions(aseed, t)
+        xa, xb = a.step(acts), b.step(acts)
+        t += 1
+    for e in (xa, xb):
+        assert e[0]["player_1"].dtype == torch.int32
+    for i in range(3):
+        for ag in ("player_1", "player_2"):
+            assert torch.equal(xa[i][ag], xb[i][ag])
+    assert torch.equal(ra.state, rb.state)
+    assert np.array_equal(cpu(xa[4]["player_1"]["score"]), cpu(xb[4]["player_1"]["score"]))
+    for k in (1, 23):
+        xa, xb = ra.step_random(aseed, t0=t, k=k), rb.step_random(aseed, t0=t, k=k)
+        t += k
+        assert torch.equal(ra.state, rb.state), k
+        assert torch.equal(xa[0]["player_2"], xb[0]["player_2"]) and torch.equal(xa[1]["player_1"], xb[1]["player_1"])
+    ta, tb = ra.rollout_random(aseed, 31, t0=t), rb.rollout_random(aseed, 31, t0=t)
+    t += 31
+    assert torch.equal(ta["actions"], tb["actions"]) and torch.equal(ta["terminations"], tb["terminations"])
+    for ag in ("player_1", "player_2"):
+        assert torch.equal(ta["obs"][ag], tb["obs"][ag]) and torch.equal(ta["rewards"][ag], tb["rewards"][ag])
+    assert torch.equal(ra.state, rb.state)
+    tape = torch.stack([torch.stack(list(ra.random_actions(aseed, t + j).values())) for j in range(19)])
+    ta, tb = ra.step_many(tape), rb.step_many(tape)
+    t += 19
+    assert torch.equal(ta["obs"]["player_1"], tb["obs"]["player_1"]) and torch.equal(ra.state, rb.state)
+    assert ra.episodes_done == rb.episodes_done
+    okw = {k: v for k, v in kw.items() if k != "flight_tables"}
+    ref = oracle.OracleEnv(n, oracle.make_config(winning_score=2, serve="random", seed=21, env_id_base=1 << 20, **okw),
+                           nthreads=8)
+    ref.reset()
+    ref.rollout_random(aseed, 0, t)
+    assert np.array_equal(cpu(rb.state), ref.state)
+
+
+def test_packed_masked_reset_frozen_games_and_statistics(oracle):
+    n = 320
+    wr = dict(stack=[["RecordEpisodeStatistics", {}]])
+    env = make_env(num_envs=n, seed=3, winning_score=1, auto_reset=False, state_format="packed", wrappers=wr,
+                   is_player2_computer=True)
+    raw = env.unwrapped
+    ref = oracle.OracleEnv(n, oracle.make_config(winning_score=1, seed=3, auto_reset=False, is_player2_computer=True,
+                                                 episode_stats=1))
+    env.reset(), ref.reset()
+    for t in range(500):
+        acts = raw.random_actions(8, t)
+        obs, rew, term, _, infos = env.step(acts)
+        ref.step(cpu(acts["player_1"]), cpu(acts["player_2"]))
+    assert bool(term["player_1"].all()) and np.array_equal(cpu(raw.state), ref.state)
+    assert np.array_equal(cpu(raw.episode_returns), ref.episode_returns)
+    assert np.array_equal(cpu(raw.episode_lengths), ref.episode_lengths)
+    frozen = raw.state
+    obs, rew, term, _, _ = env.step(acts)
+    assert torch.equal(raw.state, frozen) and bool((rew["player_1"] == 0).all()) and bool(term["player_1"].all())
+    mask = (torch.arange(n, device=raw.device) % 3 == 0)
+    obs, _ = env.reset(mask=mask)
+    r1, r2 = ref.reset(cpu(mask).astype(np.uint8))
+    assert np.array_equal(cpu(raw.state), ref.state)
+    assert np.array_equal(cpu(obs["player_1"]), r1) and np.array_equal(cpu(obs["player_2"]), r2)
+    fresh = raw.observe()
+    assert torch.equal(fresh["player_1"], obs["player_1"]) and torch.equal(fresh["player_2"], obs["player_2"])
+    assert np.array_equal(cpu(raw.scores), ref.state[38:40].T) and raw.scores.dtype == torch.int16
+
+
+@pytest.mark.parametrize("kw,steps", [(dict(), 60), (dict(is_player2_computer=True), 40)])
+def test_packed_both_sides_of_the_kernel_switch(kw, steps, oracle):
+    """Below 393 216 games the packed state is stepped by the pair kernel, from there on by one wave per 64 games."""
+    switch = 393216
+    for n in (switch - 64, switch):
+        env = make_env(num_envs=n, seed=44, env_id_base=7, state_format="packed", **kw)
+        env.reset()
+        for t in range(steps):
+            obs, rew, term, _, _ = env.step(env.unwrapped.random_actions(21, t))
+        state = env.unwrapped.state
+        for lo in (0, n - 1024):
+            ref = oracle.OracleEnv(1024, oracle.make_config(seed=44, env_id_base=7 + lo, **kw), nthreads=4)
+            ref.reset()
+            for t in range(steps):
+                a1, a2 = oracle.random_actions(1024, 7 + lo, 21, t)
+                robs, rrew, rterm = ref.step(a1, a2)
+            assert np.array_equal(cpu(state[:, lo:lo + 1024]), ref.state), (n, lo)
+            assert np.array_equal(cpu(obs["player_1"][lo:lo + 1024]), robs[0]), (n, lo)
+            assert np.array_equal(cpu(rew["player_2"][lo:lo + 1024]), rrew[1]), (n, lo)
+            assert np.array_equal(cpu(term["player_1"][lo:lo + 1024]).astype(np.uint8), rterm), (n, lo)
+
+
+@pytest.mark.parametrize("name,kw,wr", [
+    ("random_random", dict(), {}),
+    ("cfg3_p2_computer_tables", dict(is_player2_computer=True), {}),
+    ("cfg5_fused_wrappers", dict(), dict(simplify_action=True,
+                                         additional_reward=(0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01))),
+])
+def test_packed_headline_size_every_lane_vs_oracle(name, kw, wr, oracle):
+    """65 536 games x 320 frames through pz_step on the packed state, all lanes against the oracle."""
+    from oracle.ref_capture import fused_options
+
+    n, steps, seed, base, aseed = 65536, 320, 11, 1 << 33, 99
+    env = make_env(num_envs=n, seed=seed, env_id_base=base, winning_score=2, wrappers=wr, state_format="packed", **kw)
+    raw = env.unwrapped
+    ref = oracle.OracleEnv(n, oracle.make_config(winning_score=2, seed=seed, env_id_base=base, **kw,
+                                                 **fused_options(wr)), nthreads=16)
+    env.reset(), ref.reset()
+    for t in range(steps):
+        acts = raw.random_actions(aseed, t)
+        obs, rew, term, _, _ = env.step(acts)
+        if (t + 1) % 40 == 0:
+            ref.rollout_random(aseed, t + 1 - 40, 40)
+            hs = cpu(raw.state)
+            if not np.array_equal(hs, ref.state):
+                f, l = np.argwhere(hs != ref.state)[0]
+                pytest.fail(f"{name}: frame {t} lane {l} word {oracle.FIELD_NAMES[f]}: hip {hs[f, l]} != "
+                            f"oracle {ref.state[f, l]}")
+    assert np.array_equal(cpu(obs["player_1"]), ref.obs[0]) and np.array_equal(cpu(obs["player_2"]), ref.obs[1])
+    assert np.array_equal(cpu(rew["player_1"]), ref.rew[0]) and np.array_equal(cpu(rew["player_2"]), ref.rew[1])
+    assert np.array_equal(cpu(term["player_1"]).astype(np.uint8), ref.term)
+
+
+def test_checkpoints_move_between_the_formats():
+    kw = dict(num_envs=1000, seed=8, is_player2_computer=True, winning_score=3)
+    a = make_env(state_format="int32", **kw)
+    a.reset()
+    a.step_random(1, k=100)
+    sd = a.unwrapped.state_dict()
+    a.step_random(1, k=50)
+    b = make_env(state_format="packed", **kw)
+    b.unwrapped.load_state_dict(sd)
+    b.step_random(1, k=50)
+    assert torch.equal(b.unwrapped.state, a.unwrapped.state)
+    sd2 = b.unwrapped.state_dict()
+    assert sd2["state"].dtype == torch.int32 and tuple(sd2["state"].shape) == (44, 1000)
+    c = make_env(state_format="int32", **kw)
+    c.unwrapped.load_state_dict(sd2)
+    b.step_random(1, k=30)
+    c.step_random(1, k=30)
+    assert torch.equal(b.unwrapped.state, c.unwrapped.state)
+
+
+def test_packed_render_and_scalar_api():
+    from pikazoo_amd import render as R
+
+    sprites = R.synthetic_sprites(3, torch.device("cuda:0"))
+    kw = dict(num_envs=8, seed=5, render_mode="rgb_array", sprites=sprites)
+    a, b = make_env(state_format="int32", **kw), make_env(state_format="packed", **kw)
+    for e in (a, b):
+        e.reset()
+        e.step_random(9, k=77)
+    assert torch.equal(a.render(), b.render())
+    env = make_env(num_envs=1, scalar_api=True, winning_score=1, state_format="packed", validate_actions=True)
+    obs, infos = env.reset()
+    assert isinstance(obs["player_1"], np.ndarray) and infos["player_1"]["score"] == [0, 0]
+    steps = 0
+    while env.agents:
+        obs, rew, term, trunc, infos = env.step({a: env.action_space(a).sample() for a in env.agents})
+        steps += 1
+    assert term["player_1"] is True and sorted(infos["player_1"]["score"]) == [0, 1] and steps > 10

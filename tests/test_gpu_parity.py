@@ -46,13 +46,17 @@ def cpu(t):
 AI_FIXTURES = ["cfg3_p2_computer", "p1_computer", "both_computer", "full_wrapper_stack"]
 
 
-@pytest.mark.parametrize("name,tables", [(n, True) for n in FULL_FIXTURES] + [(n, False) for n in AI_FIXTURES])
-def test_hip_matches_reference_trajectory(name, tables):
+@pytest.mark.parametrize("name,tables,fmt", [(n, True, "int32") for n in FULL_FIXTURES] +
+                         [(n, False, "int32") for n in AI_FIXTURES] + [(n, True, "packed") for n in FULL_FIXTURES] +
+                         [(n, False, "packed") for n in AI_FIXTURES])
+def test_hip_matches_reference_trajectory(name, tables, fmt):
     """`tables`: the computer player's flight predictions come from the HBM look-up tables (default) or are
-    iterated in the kernel (the scout-wave launch); fixtures without a computer player never use them."""
+    iterated in the kernel (the scout-wave launch); fixtures without a computer player never use them.
+    `fmt`: the state lives in HBM as int32 columns or in the packed format (36 bytes per game); `raw.state` is the
+    same int32[44, lanes] either way."""
     d = load_golden(name)
     meta = d["meta"]
-    env = make_env(meta, flight_tables=tables)
+    env = make_env(meta, flight_tables=tables, state_format=fmt)
     raw = env.unwrapped
     T, L = meta["steps"], meta["lanes"]
     assert np.array_equal(cpu(raw.state), d["state_ctor"])
@@ -159,13 +163,15 @@ def _has_computer(kw):
     return bool(kw.get("is_player1_computer") or kw.get("is_player2_computer"))
 
 
-@pytest.mark.parametrize("case,tables", [(c, True) for c in CASES] +
-                         [(c, False) for c in CASES if _has_computer(CASES[c]["kw"])])
-def test_hip_matches_oracle_random_batches(case, tables, oracle):
+@pytest.mark.parametrize("case,tables,fmt", [(c, True, "int32") for c in CASES] +
+                         [(c, False, "int32") for c in CASES if _has_computer(CASES[c]["kw"])] +
+                         [(c, True, "packed") for c in CASES] +
+                         [(c, False, "packed") for c in ("cfg3_p2_computer", "both_computer_random_serve_ws2")])
+def test_hip_matches_oracle_random_batches(case, tables, fmt, oracle):
     c = CASES[case]
     n, steps, kw, wr = c["n"], c["steps"], dict(c["kw"]), c.get("wr", {})
     seed, base, aseed = 99, 12345, 4242
-    env = make_env(num_envs=n, seed=seed, env_id_base=base, wrappers=wr, flight_tables=tables, **kw)
+    env = make_env(num_envs=n, seed=seed, env_id_base=base, wrappers=wr, flight_tables=tables, state_format=fmt, **kw)
     assert (env.unwrapped._tables_ref is not None) == (tables and _has_computer(kw))
     raw = env.unwrapped
     from oracle.ref_capture import fused_options
@@ -346,7 +352,7 @@ def test_stride_larger_than_n_and_error_codes(oracle):
     cfg.winning_score = 2
     assert lib.pz_step_random(state.data_ptr(), n, stride, C.byref(cfg), 11, 0, 0, obs1.data_ptr(), obs2.data_ptr(),
                               rew1.data_ptr(), rew2.data_ptr(), term.data_ptr(), None, None, None, s) == -2
-    assert lib.pz_observe(state.data_ptr(), n, stride, 0, obs1.data_ptr() + 4, obs2.data_ptr(), s) == -4
+    assert lib.pz_observe(state.data_ptr(), n, stride, 0, 0, obs1.data_ptr() + 4, obs2.data_ptr(), s) == -4
     cfg.normal_state_mode = 3
     assert lib.pz_init(state.data_ptr(), n, stride, C.byref(cfg), s) == -3
     cfg.normal_state_mode = 0
