@@ -53,7 +53,10 @@ import torch  # noqa: E402
 from pikazoo_amd import _native, dist, pikazoo_v0  # noqa: E402
 
 BYTES_PER_ENV_STEP = 8 * 44 + 297  # rd+wr state, 2 actions, 2x35 obs, 2 rewards, 1 flag
-BYTES_PER_ENV_STEP_PACKED = 2 * 36 + 297  # the same with the packed state format (36 bytes per game)
+# the same with the packed state format: groups A and B (32 bytes) read and written; the 4-byte tail only moves with a
+# computer player (its boldness is read, the landing point written)
+BYTES_PER_ENV_STEP_PACKED = 2 * 32 + 297
+BYTES_PER_ENV_STEP_PACKED_AI = 2 * 36 + 297
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 INFINITY_CACHE_BYTES = 256 << 20
 ACTION_SEED = 1
@@ -318,7 +321,10 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     wall = dist.all_reduce_max(run["wall"], device=cdev)
     n_total, = dist.all_reduce_sum([raw.num_envs], device=cdev)
     launch_us = run["event_ms"] * 1e3 / run["timed_steps"]
-    alg = (BYTES_PER_ENV_STEP_PACKED if state_format == "packed" else BYTES_PER_ENV_STEP) * num_envs
+    per_step = BYTES_PER_ENV_STEP
+    if state_format == "packed":
+        per_step = BYTES_PER_ENV_STEP_PACKED_AI if (p2_computer or args.p1_computer) else BYTES_PER_ENV_STEP_PACKED
+    alg = per_step * num_envs
     res = {
         "wall_s": wall, "event_ms": run["event_ms"], "n_total": n_total, "timed_steps": run["timed_steps"],
         "replays": run["replays"], "launches_per_replay": run["launches_per_replay"],
@@ -396,7 +402,7 @@ def ensure_built():
 
 def kernel_name(num_envs, ai, tables, packed=False):
     if packed:
-        return ("pz::step_kernel<AI1,AI2,kActions,false,kNoScout,PACKED> via pz_step" if num_envs >= 393216 or (ai and not tables)
+        return ("pz::step_kernel<AI1,AI2,kActions,false,kNoScout,PACKED> via pz_step" if (ai and not tables)
                 else "pz::step_pair_kernel<AI1,AI2,PACKED> via pz_step")
     if num_envs >= 393216:
         return "pz::step_kernel<AI1,AI2,kActions,true> via pz_step"
@@ -473,7 +479,7 @@ def main():
             "cfg5": ("65 536 games, fused SimplifyAction + RewardByBallPosition",
                      dict(num_envs=65536, wrappers=True)),
             # the same workloads on the packed state format (36 instead of 176 bytes of state per game;
-            # `frac` of these entries is computed on their own 369 algorithmic bytes per game-step)
+            # `frac` of these entries is computed on their own 361 / 369 algorithmic bytes per game-step)
             "packed_headline": ("65 536 games, random/random, packed state format",
                                 dict(num_envs=65536, state_format="packed")),
             "packed_cfg3": ("65 536 games, player 2 = rule-based computer (tables), packed state format",

@@ -192,10 +192,12 @@ def test_packed_masked_reset_frozen_games_and_statistics(oracle):
     ref = oracle.OracleEnv(n, oracle.make_config(winning_score=1, seed=3, auto_reset=False, is_player2_computer=True,
                                                  episode_stats=1))
     env.reset(), ref.reset()
-    for t in range(500):
+    for t in range(4000):
         acts = raw.random_actions(8, t)
         obs, rew, term, _, infos = env.step(acts)
         ref.step(cpu(acts["player_1"]), cpu(acts["player_2"]))
+        if t % 100 == 99 and bool(term["player_1"].all()):
+            break
     assert bool(term["player_1"].all()) and np.array_equal(cpu(raw.state), ref.state)
     assert np.array_equal(cpu(raw.episode_returns), ref.episode_returns)
     assert np.array_equal(cpu(raw.episode_lengths), ref.episode_lengths)
@@ -214,7 +216,8 @@ def test_packed_masked_reset_frozen_games_and_statistics(oracle):
 
 @pytest.mark.parametrize("kw,steps", [(dict(), 60), (dict(is_player2_computer=True), 40)])
 def test_packed_both_sides_of_the_kernel_switch(kw, steps, oracle):
-    """Below 393 216 games the packed state is stepped by the pair kernel, from there on by one wave per 64 games."""
+    """The packed state is stepped by the pair kernel at every size (the int32 columns switch to one wave per 64 games
+    at 393 216): both sides of that size."""
     switch = 393216
     for n in (switch - 64, switch):
         env = make_env(num_envs=n, seed=44, env_id_base=7, state_format="packed", **kw)

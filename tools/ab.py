@@ -5,8 +5,8 @@ rounds in ONE process, median and min reported).
     python tools/ab.py --build name1=-DFLAG1 name2="-DFLAG2 -DFLAG3" ...   # here: cross-compile variants
     python tools/ab.py [--ai] [--n 65536] [--rollout K] name1 name2 ...    # on the GPU box: time them
                                                                            # (--rollout: pz_rollout_random, K frames/launch)
-    a name with the suffix "+t" runs that library WITH the flight look-up tables (pz_flight_tables), e.g.
-    `python tools/ab.py --ai base base+t`
+    a name with the suffix "+t" runs that library WITH the flight look-up tables (pz_flight_tables), "+p" on the
+    packed state format, "+tp" both, e.g. `python tools/ab.py --ai base base+t base+tp`
 
 A variant named "base" is always built with no extra flags.  Libraries go to
 pika-zoo_amd/lib/ab_<name>.so (git-ignored, shipped by gpurun).
@@ -58,7 +58,7 @@ def main():
     libs = {}
     loaded = {}
     for nm in names:
-        file = nm[:-2] if nm.endswith("+t") else nm
+        file = nm.partition("+")[0]
         if file in loaded:
             libs[nm] = loaded[file]
             continue
@@ -78,8 +78,16 @@ def main():
         cfg.simplify_action, cfg.ballpos_reward, cfg.x_line, cfg.y_line = 1, 1, 216, 176
         for i, v in enumerate((0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01)):
             cfg.additional_reward[i] = v
+    def mods(nm):
+        return nm.partition("+")[2]
+
+    cfgs = {}
+    for nm in names:
+        c = cfgs[nm] = _native.PzConfig.from_buffer_copy(cfg)
+        c.packed_state = int("p" in mods(nm))
     # every variant owns its state buffer and initialises it itself: variants may differ in the state's layout
-    states = {nm: torch.zeros((44, n), dtype=torch.int32, device=dev) for nm in names}
+    states = {nm: (torch.zeros(36 * n, dtype=torch.uint8, device=dev) if "p" in mods(nm)
+                   else torch.zeros((44, n), dtype=torch.int32, device=dev)) for nm in names}
     obs = [torch.zeros((n, 35), dtype=torch.int32, device=dev) for _ in range(2)]
     rew = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
     term = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -87,14 +95,14 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     base = libs["base"]
     tables = None
-    if any(nm.endswith("+t") for nm in names):
+    if any("t" in mods(nm) for nm in names):
         t_land = torch.empty(base.pz_flight_table_bytes(0), dtype=torch.uint8, device=dev)
         t_hit = torch.empty(base.pz_flight_table_bytes(1), dtype=torch.uint8, device=dev)
         assert base.pz_build_flight_tables(t_land.data_ptr(), t_hit.data_ptr(), stream) == 0
         tables = _native.PzFlightTables(t_land.data_ptr(), t_hit.data_ptr())
     for nm in names:
-        assert libs[nm].pz_init(states[nm].data_ptr(), n, n, C.byref(cfg), stream) == 0
-        assert libs[nm].pz_reset(states[nm].data_ptr(), n, n, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(),
+        assert libs[nm].pz_init(states[nm].data_ptr(), n, n, C.byref(cfgs[nm]), stream) == 0
+        assert libs[nm].pz_reset(states[nm].data_ptr(), n, n, C.byref(cfgs[nm]), None, obs[0].data_ptr(), obs[1].data_ptr(),
                                  None, stream) == 0
 
     if rollout:
@@ -107,7 +115,8 @@ def main():
     def run(nm, steps):
         lib = libs[nm]
         state = states[nm]
-        tb = C.byref(tables) if nm.endswith("+t") else None
+        tb = C.byref(tables) if "t" in mods(nm) else None
+        cfg = cfgs[nm]
         if rollout:
             for j in range(max(1, steps // rollout)):
                 rc = lib.pz_rollout_random(state.data_ptr(), n, n, C.byref(cfg), 7, j * rollout, rollout,

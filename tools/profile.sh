@@ -7,6 +7,8 @@
 #   pmc_cfg3c the same passes on config 3 with the flight predictors computed in the kernel (scout-wave launch)
 #   pmc_big   FETCH_SIZE / WRITE_SIZE at 524 288 games (config 4's total size: past the Infinity Cache)
 #   kt_roll   --kernel-trace --stats of pz_rollout_random / pz_step_many (k = 32)
+#   pmc_pk    the four passes on the headline workload with the packed state format (65 536 games)
+#   pmc_pkbig FETCH_SIZE / WRITE_SIZE / kernel stats at 524 288 games with the packed state format
 #
 # Every PMC pass is its own rocprofv3 run with --kernel-trace only (MI355X_MICROARCH.md, rocprofv3 PMC slots:
 # FETCH_SIZE and WRITE_SIZE do not fit one pass; gpurun refuses --pmc together with the API trace domains).
@@ -14,7 +16,7 @@
 set -u
 TAG=${1:?tag}
 shift
-SECTIONS=${*:-kt pmc_hh pmc_cfg3 pmc_cfg3c pmc_big kt_roll}
+SECTIONS=${*:-kt pmc_hh pmc_cfg3 pmc_cfg3c pmc_big kt_roll pmc_pk pmc_pkbig}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -48,6 +50,12 @@ for s in $SECTIONS; do
         run big_fetch --kernel-trace --pmc FETCH_SIZE -- $PY bench.py --no-cpu --no-configs --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
         run big_write --kernel-trace --pmc WRITE_SIZE -- $PY bench.py --no-cpu --no-configs --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
         run big_kt --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --num-envs 524288 --steps 300 --warmup 50 --burn-in 256 --launch cabi || exit 1
+        ;;
+    pmc_pk) pmc_set pk --no-cpu --no-configs --state-format packed --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1 ;;
+    pmc_pkbig)
+        run pkbig_fetch --kernel-trace --pmc FETCH_SIZE -- $PY bench.py --no-cpu --no-configs --state-format packed --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
+        run pkbig_write --kernel-trace --pmc WRITE_SIZE -- $PY bench.py --no-cpu --no-configs --state-format packed --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
+        run pkbig_kt --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --state-format packed --num-envs 524288 --steps 300 --warmup 50 --burn-in 256 --launch cabi || exit 1
         ;;
     kt_roll) run roll --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --rollouts || exit 1 ;;
     *) echo "unknown section $s"; exit 2 ;;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-wave timeline of one step launch (diagnostic build with -DPZ_STAMPS; not product).
 
-    python tools/stamps.py --build ; python tools/stamps.py [--ai] [--n N]     (second on the GPU box)
+    python tools/stamps.py --build ; python tools/stamps.py [--ai [--tables]] [--packed] [--n N]     (second on the GPU box)
 
 Stamps (100 MHz s_memrealtime, 10 ns ticks), lane 0 of every workgroup:
  0 start | 1 state loaded (vmcnt(0)) | 2 frame computed | 3 state/reward stores issued |
@@ -47,7 +47,9 @@ def main():
     dev = torch.device("cuda:0")
     cfg = _native.PzConfig()
     cfg.winning_score, cfg.auto_reset, cfg.seed, cfg.p2_computer = 15, 1, 0, int(ai)
-    state = torch.zeros((44, n), dtype=torch.int32, device=dev)
+    packed = "--packed" in args  # the 36-byte state format (n must be a multiple of 4 here: stride = n)
+    cfg.packed_state = int(packed)
+    state = torch.zeros(36 * n, dtype=torch.uint8, device=dev) if packed else torch.zeros((44, n), dtype=torch.int32, device=dev)
     obs = [torch.zeros((n, 35), dtype=torch.int32, device=dev) for _ in range(2)]
     rew = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
     term = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -81,7 +83,7 @@ def main():
         st = buf.reshape(8192, 8)[:waves, :7].astype(np.int64)
         t0 = st[:, 0].min()
         rel = (st - t0) * 0.01  # microseconds
-        print(f"launch sample {rep}: n={n} ai={ai} waves={waves}; microseconds since the first wave started")
+        print(f"launch sample {rep}: n={n} ai={ai} packed={packed} waves={waves}; microseconds since the first wave started")
         for k, nm in enumerate(names):
             c = rel[:, k]
             print(f"  {nm:22s} min {c.min():6.2f}  median {np.median(c):6.2f}  p95 {np.percentile(c, 95):6.2f}  max {c.max():6.2f}")
