@@ -3,7 +3,11 @@
 launch (`pz_step`: the pair kernel / scout kernel, actions from HBM) for tens of thousands of frames per
 configuration, full state compared with the CPU oracle every `--every` frames on EVERY lane.
 
-    python tools/soak.py [--frames 20000] [--every 2000] [--n 65536]
+    python tools/soak.py [--frames 20000] [--every 2000] [--n 65536] [--packed]
+
+--packed: the same on the packed state format (36 bytes per game); its sticky misfit flags are checked with every unpack.
+Every run also tracks, frame by frame on the device, the extremes of the values the packed format stores in narrow
+fields (ball y velocity: 13 bits signed; player y velocity: 6 bits signed) -- printed per configuration.
 """
 import sys
 import time
@@ -28,6 +32,7 @@ def main():
     frames = int(args[args.index("--frames") + 1]) if "--frames" in args else 20000
     every = int(args[args.index("--every") + 1]) if "--every" in args else 2000
     n = int(args[args.index("--n") + 1]) if "--n" in args else 65536
+    fmt = "packed" if "--packed" in args else "int32"
     configs = [
         ("human_vs_human (pair kernel)", dict(), dict(), None),
         ("config 3: p2 computer, flight tables (pair kernel)", dict(is_player2_computer=True), dict(is_player2_computer=True), None),
@@ -40,7 +45,8 @@ def main():
     po.build()
     ok = True
     for name, kw, okw, wr in configs:
-        env = pikazoo_v0.env(num_envs=n, device="cuda:0", seed=123, env_id_base=1 << 34, validate_actions=False, **kw)
+        env = pikazoo_v0.env(num_envs=n, device="cuda:0", seed=123, env_id_base=1 << 34, validate_actions=False,
+                             state_format=fmt, **kw)
         ocfg_kw = dict(seed=123, env_id_base=1 << 34, **okw)
         if wr:
             env = RecordEpisodeStatistics(RewardInNormalState(RewardByBallPosition(SimplifyAction(env), TABLE), -0.001))
@@ -51,9 +57,14 @@ def main():
         env.reset(), ref.reset()
         t0 = time.perf_counter()
         eps = 0
+        # ball y velocity is observation word 33, the players' y velocities words 2 and 15 (raw observations only)
+        track = not raw._cfg.normalize_obs
+        ext = torch.zeros(2, dtype=torch.int32, device=raw.device)
         for start in range(0, frames, every):
             for t in range(start, start + every):
-                env.step(raw.random_actions(77, t))
+                obs = env.step(raw.random_actions(77, t))[0]["player_1"]
+                if track:
+                    ext = torch.maximum(ext, torch.stack((obs[:, 33].abs().max(), obs[:, [2, 15]].abs().max())))
             eps += ref.rollout_random(77, start, every)
             same = np.array_equal(raw.state.cpu().numpy(), ref.state)
             if wr:
@@ -64,7 +75,8 @@ def main():
                 print(f"MISMATCH {name}: after {start + every} frames", flush=True)
                 break
         print(f"{name}: {n} games x {start + every} frames = {n * (start + every) / 1e9:.2f} G game-steps bit-exact vs oracle "
-              f"on every lane: {same}; {eps} episodes finished; {time.perf_counter() - t0:.0f} s", flush=True)
+              f"on every lane: {same}; {eps} episodes finished; max |ball y velocity| {int(ext[0])}, max |player y velocity| "
+              f"{int(ext[1])} over every frame; state format {fmt}; {time.perf_counter() - t0:.0f} s", flush=True)
     print("SOAK", "PASSED" if ok else "FAILED")
     sys.exit(0 if ok else 1)
 
