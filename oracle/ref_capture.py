@@ -137,7 +137,7 @@ def install_stubs():
     pz_utils.env = pz_utils_env
     pz.utils = pz_utils
 
-    pygame = types.ModuleType("pygame")
+    pygame = _recording_pygame()
 
     sys.modules.update({
         "gymnasium": gym, "gymnasium.spaces": spaces, "gymnasium.utils": utils,
@@ -147,6 +147,73 @@ def install_stubs():
     })
     if str(REFERENCE_ROOT) not in sys.path:
         sys.path.insert(0, str(REFERENCE_ROOT))
+
+
+def _png_size(path):
+    """(width, height) from a PNG's IHDR chunk."""
+    with open(path, "rb") as f:
+        head = f.read(24)
+    assert head[:8] == b"\x89PNG\r\n\x1a\n" and head[12:16] == b"IHDR", path
+    return int.from_bytes(head[16:20], "big"), int.from_bytes(head[20:24], "big")
+
+
+def _recording_pygame():
+    """Stand-in for the uninstalled third-party ``pygame``: surfaces carry a description instead of pixels and a
+    surface that is blitted onto records (what, where).  With it the reference's own ``render()``
+    (pikazoo_env.py:250-384) runs unmodified and leaves its draw list -- which sprite, flipped / scaled how, at
+    which position -- on the screen surface, and its clouds / waves / punch effect advance exactly as they do under
+    the real library (they only depend on the env RNG).  No pixels are produced."""
+    pg = types.ModuleType("pygame")
+    pg.SRCALPHA = 0x00010000
+
+    class Surface:
+        def __init__(self, size, flags=0, desc=None):
+            self.size = (int(size[0]), int(size[1]))
+            self.desc = desc        # (file name, flip_x, scaled size or None) once it holds an image
+            self.blits = []         # [(desc, x, y, w, h)] in call order
+
+        def get_size(self):
+            return self.size
+
+        def get_width(self):
+            return self.size[0]
+
+        def get_height(self):
+            return self.size[1]
+
+        def blit(self, source, dest):
+            if self.desc is None and not self.blits and dest == (0, 0) and source.size == self.size and \
+                    source.desc is not None and source.desc[0].endswith(".png") and getattr(source, "is_file", False):
+                self.desc = source.desc   # get_image: a fresh SRCALPHA surface receives the loaded file
+                return
+            self.blits.append((source.desc, int(dest[0]), int(dest[1]), source.size[0], source.size[1]))
+
+    image = types.ModuleType("pygame.image")
+
+    def load(path):
+        sfc = Surface(_png_size(path), desc=(Path(path).name, False, None))
+        sfc.is_file = True
+        return sfc
+
+    image.load = load
+    transform = types.ModuleType("pygame.transform")
+
+    def flip(surface, flip_x, flip_y):
+        assert not flip_y
+        name, fx, scaled = surface.desc
+        return Surface(surface.size, desc=(name, fx != bool(flip_x), scaled))
+
+    def scale(surface, size):
+        name, fx, _ = surface.desc
+        return Surface(size, desc=(name, fx, (int(size[0]), int(size[1]))))
+
+    transform.flip, transform.scale = flip, scale
+    surfarray = types.ModuleType("pygame.surfarray")
+    surfarray.pixels3d = lambda surface: np.zeros((surface.size[0], surface.size[1], 3), np.uint8)
+    pg.Surface, pg.image, pg.transform, pg.surfarray = Surface, image, transform, surfarray
+    pg.init = lambda: None
+    pg.quit = lambda: None
+    return pg
 
 
 def wrapper_stack(wrappers):
@@ -392,6 +459,101 @@ def capture_single_agent(name: str, lanes: int, steps: int, seed: int, action_se
 TEST_TABLE = (0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01)
 INT_TABLE = (1, -2, 3, -4, 5, -6, 7, -8)
 
+# --------------------------------------------------------------------------------------
+# render(): the reference's draw list and what it does to the env RNG (render_mode="rgb_array")
+# --------------------------------------------------------------------------------------
+SCENERY_WORDS = 69  # 10 clouds x (x, y, x velocity, size_diff_turn_number), wave vertical_coord, its velocity, 27 y_coords
+# static part of a frame: draw_background (pikazoo_env.py:296-325), identical on every frame
+BACKGROUND_BLITS = 12 * 27 + 1 + 27 + 25 + 2 + 2 * 27 + 1 + 12
+
+
+def extract_scenery(raw) -> np.ndarray:
+    """cloud_array / wave_ of the reference (cloud_and_wave.py:12-50) as SCENERY_WORDS ints."""
+    out = np.zeros(SCENERY_WORDS, np.int32)
+    for i, c in enumerate(raw.cloud_array):
+        out[4 * i:4 * i + 4] = (c.top_left_point_x, c.top_left_point_y, c.top_left_point_x_velocity,
+                                c.size_diff_turn_number)
+    out[40], out[41] = raw.wave_.vertical_coord, raw.wave_.vertical_coord_velocity
+    out[42:69] = raw.wave_.y_coords
+    return out
+
+
+def capture_render(name: str, steps: int, periods, seed: int, action_seed: int, env_id_base: int, env_kwargs: dict) -> dict:
+    """One reference env per entry of `periods`, constructed with render_mode="rgb_array" (the constructor then draws
+    the ten clouds from the env RNG, pikazoo_env.py:475-477), stepped under the random policy; lane i calls the
+    reference's own ``render()`` after reset and after every periods[i]-th step.  Recorded per frame: the draw list the
+    reference issued (file, mirrored, x, y, width, height of every blit behind the static background), the clouds /
+    wave after it, and the 44 state words after it (render() advances the env RNG, so later steps differ from an
+    un-rendered run).  ``render()`` itself returns a blank array here: the stand-in pygame composes nothing."""
+    lanes = len(periods)
+    kw = dict(env_kwargs, render_mode="rgb_array")
+    envs = [make_reference_env(seed, env_id_base + i, None, **kw) for i in range(lanes)]
+    names: list = []
+    frames = []   # (lane, step (-1: after reset), entries)
+
+    def render(i, t):
+        env, raw, shim = envs[i]
+        if raw.screen is not None:
+            raw.screen.blits.clear()
+        out = raw.render()
+        assert out.shape == (304, 432, 3)
+        blits = raw.screen.blits
+        static, dynamic = blits[:BACKGROUND_BLITS], blits[BACKGROUND_BLITS:]
+        if not frames:
+            frames_static.extend(static)
+        assert static == frames_static, "draw_background changed between frames"
+        entries = []
+        for (file, flip, scaled), x, y, w, h in dynamic:
+            if file not in names:
+                names.append(file)
+            entries.append((names.index(file), int(flip), x, y, w, h))
+        frames.append((i, t, entries, extract_scenery(raw), extract_state(raw, shim)))
+
+    frames_static: list = []
+    state_ctor = np.stack([extract_state(raw, shim) for _, raw, shim in envs], axis=1)
+    scenery_ctor = np.stack([extract_scenery(raw) for _, raw, _ in envs], axis=1)
+    for i, (env, raw, shim) in enumerate(envs):
+        env.reset()
+    state0 = np.stack([extract_state(raw, shim) for _, raw, shim in envs], axis=1)
+    for i in range(lanes):
+        render(i, -1)
+    states = np.zeros((steps, po.W, lanes), np.int32)   # after step t (and before a render that follows it)
+    for t in range(steps):
+        a1, a2 = po.random_actions(lanes, env_id_base, action_seed, t, 18)
+        for i, (env, raw, shim) in enumerate(envs):
+            if not raw.agents:
+                env.reset()
+            env.step({"player_1": int(a1[i]), "player_2": int(a2[i])})
+            states[t, :, i] = extract_state(raw, shim)
+            if (t + 1) % periods[i] == 0:
+                render(i, t)
+    most = max(len(f[2]) for f in frames)
+    draw = np.full((len(frames), most, 6), -1, np.int16)
+    for k, f in enumerate(frames):
+        draw[k, :len(f[2])] = np.asarray(f[2], np.int16).reshape(-1, 6)
+    static = []
+    for (file, flip, scaled), x, y, w, h in frames_static:
+        assert not flip and scaled is None
+        if file not in names:
+            names.append(file)
+        static.append((names.index(file), x, y, w, h))
+    meta = dict(name=name, lanes=lanes, steps=steps, periods=list(periods), seed=seed, action_seed=action_seed,
+                env_id_base=env_id_base, env_kwargs=env_kwargs, files=names, fields=po.FIELD_NAMES)
+    return dict(
+        state_ctor=state_ctor.astype(np.int32), scenery_ctor=scenery_ctor, state0=state0.astype(np.int32), states=states,
+        frame_lane=np.asarray([f[0] for f in frames], np.int32), frame_step=np.asarray([f[1] for f in frames], np.int32),
+        frame_count=np.asarray([len(f[2]) for f in frames], np.int32), frame_draw=draw,
+        frame_scenery=np.stack([f[3] for f in frames]), frame_state=np.stack([f[4] for f in frames]).astype(np.int32),
+        background=np.asarray(static, np.int16), meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+
+
+RENDER_RUNS = [
+    # name, steps, render periods per lane, env kwargs
+    ("render_human_human", 1500, (1, 2, 3, 7, 25, 40), dict(winning_score=15)),
+    ("render_p2_computer", 1200, (1, 4, 30, 30), dict(winning_score=15, is_player2_computer=True, serve="alternate")),
+]
+
+
 FIXTURES = [
     # name, lanes, steps, env_kwargs, wrappers
     ("cfg2_human_human", 6, 3000, dict(winning_score=15, serve="winner"), None),
@@ -476,6 +638,14 @@ def main(argv=None):
                                     env_id_base=7000 + 10 * k, side=side, env_kwargs=kw)
         np.savez_compressed(GOLDEN / f"{name}.npz", **data)
         print(f"{name}: {lanes}x{steps} terminations={int(data['term'].sum())} "
+              f"{(GOLDEN / (name + '.npz')).stat().st_size / 1e3:.0f} kB")
+    for k, (name, steps, periods, kw) in enumerate(RENDER_RUNS):
+        if args.only and args.only != name:
+            continue
+        data = capture_render(name, steps, periods, seed=606 + k, action_seed=17 + k, env_id_base=9000 + 100 * k,
+                              env_kwargs=kw)
+        np.savez_compressed(GOLDEN / f"{name}.npz", **data)
+        print(f"{name}: {len(periods)} lanes x {steps} steps, {len(data['frame_lane'])} frames "
               f"{(GOLDEN / (name + '.npz')).stat().st_size / 1e3:.0f} kB")
     if not args.skip_digests:
         for k, (name, lanes, steps, kw, wr) in enumerate(DIGEST_RUNS):

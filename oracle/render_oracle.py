@@ -1,13 +1,18 @@
 """CPU restatement of the reference's ``rgb_array`` frame (TEST INFRASTRUCTURE, not product).
 
-``frame(state_column, sprites, background)`` draws one game the way ``raw_env.draw`` does
-(pikazoo/env/pikazoo_env.py:250-336) minus what is not a function of the game state (clouds and waves :338-353,
-punch effect :292-294), with numpy slices instead of pygame blits.
+``frame(state_column, sprites, background[, scenery])`` draws one game the way ``raw_env.draw`` does
+(pikazoo/env/pikazoo_env.py:250-353) minus the punch effect (:292-294: its radius and y are set by the physics in two
+ball attributes outside the 44 state words), with numpy slices instead of pygame blits; ``scenery_init`` /
+``scenery_tick`` restate the clouds and waves (cloud_and_wave.py), which live outside the 44 words and advance the env
+RNG on every render; ``draw_list`` is the list of blits a frame consists of.
 
-Parity note: pygame is not installed in the build container, so this oracle is **not pinned** against the
-reference's renderer; it restates the reference's draw order / coordinates from the source and pygame's published
-per-pixel-alpha blit rule (pygame ``surface.h``: ``ALPHA_BLEND_COMP(sC, dC, sA) = (((sC - dC) * sA + sC) >> 8) + dC``,
-pixels with ``sA == 0`` skipped).  The PNG reader of the product is cross-checked against Pillow on the reference's
+Parity: **the draw list, the clouds / waves and the RNG consumption are pinned** against the unmodified reference:
+``oracle/ref_capture.py`` runs the reference's own ``render()`` on a recording stand-in for pygame and commits what it
+drew (which file, mirrored, position, size of every blit), the cloud / wave state and the env state after every
+frame (tests/golden/render_*.npz; tests/test_render_cpu.py).  **The pixel arithmetic is not pinned** -- pygame is not
+installed in the build container: the per-pixel-alpha blit rule is restated from pygame ``surface.h``
+(``ALPHA_BLEND_COMP(sC, dC, sA) = (((sC - dC) * sA + sC) >> 8) + dC``, pixels with ``sA == 0`` skipped) and the
+nearest-neighbour walk of ``pygame.transform.scale`` (scaled clouds) from its ``transform.c``.  The PNG reader of the product is cross-checked against Pillow on the reference's
 own assets when both are present (tests/test_render_cpu.py).
 """
 import numpy as np
@@ -49,29 +54,132 @@ def sprite_index(state, frame):  # get_frame_number_for_player_animated_sprite :
     return 18 + 5 * (state - 5) + frame
 
 
-def frame(col, sprites, background):
-    """uint8 [304, 432, 3] for one game: `col` = its 44 state words, `sprites` = list of 46 RGBA arrays."""
-    screen = background.copy()
+# sprite ids of the product (include/pikazoo_hip.h: pz_sprite_id) and the reference's file behind each
+SPRITE_CLOUD, SPRITE_WAVE, SPRITE_COUNT = 46, 47, 48
+_PIKACHU_FRAMES = [(0, 5), (1, 5), (2, 5), (3, 2), (4, 1), (5, 5), (6, 5)]  # get_all_image :445-474
+
+
+def sprite_files():
+    files = [f"pikachu_{st}_{fr}.png" for st, count in _PIKACHU_FRAMES for fr in range(count)]
+    files += [f"ball_{k}.png" for k in range(5)] + ["ball_hyper.png", "ball_trail.png", "shadow.png"]
+    files += [f"number_{k}.png" for k in range(10)] + ["cloud.png", "wave.png"]
+    assert len(files) == SPRITE_COUNT
+    return files
+
+
+# ---- clouds and waves (cloud_and_wave.py): state outside the 44 words, driven by the env RNG ----------------------
+# scenery words: cloud i at 4i: top_left_point_x, top_left_point_y, top_left_point_x_velocity, size_diff_turn_number;
+# 40: wave.vertical_coord, 41: wave.vertical_coord_velocity, 42..68: wave.y_coords
+SCENERY_WORDS = 69
+
+
+def scenery_init(draw):
+    """get_all_image's ten Cloud(np_random) (:475-477, cloud_and_wave.py:15-19) + Wave() (:42-50); `draw(n)` is the
+    env stream's integers(0, n)."""
+    sc = np.zeros(SCENERY_WORDS, np.int32)
+    for i in range(10):
+        sc[4 * i] = -68 + draw(432 + 68)
+        sc[4 * i + 1] = draw(152)
+        sc[4 * i + 2] = 1 + draw(2)
+        sc[4 * i + 3] = draw(11)
+    sc[40], sc[41] = 0, 2
+    sc[42:69] = 314
+    return sc
+
+
+def scenery_tick(sc, draw):
+    """cloud_and_wave_engine (cloud_and_wave.py:53-78), in place."""
+    for i in range(10):
+        sc[4 * i] += sc[4 * i + 2]
+        if sc[4 * i] > 432:
+            sc[4 * i] = -68
+            sc[4 * i + 1] = draw(152)
+            sc[4 * i + 2] = 1 + draw(2)
+        sc[4 * i + 3] = (sc[4 * i + 3] + 1) % 11
+    sc[40] += sc[41]
+    if sc[40] > 32:
+        sc[40], sc[41] = 32, -1
+    elif sc[40] < 0 and sc[41] < 0:
+        sc[41] = 2
+        sc[40] = -draw(40)
+    for i in range(27):
+        sc[42 + i] = 314 - sc[40] + draw(3)
+
+
+def draw_list(col, sizes, scenery=None):
+    """The blits of raw_env.draw behind the static background, in the reference's order (:250-255), as
+    (sprite id, mirrored, x, y, width, height) with (x, y) the top-left corner; `sizes[id]` = (width, height) of the
+    sprite files.  The punch effect (:292-294) is not part of it."""
     col = [int(v) for v in col]
+    out = []
+
+    def centred(sid, x, y, flip=0):
+        w, h = sizes[sid]
+        out.append((sid, flip, x - w // 2, y - h // 2, w, h))
+
+    if scenery is not None:  # draw_clouds_and_wave :338-353 (after the engine ran)
+        for i in range(10):
+            x, y, _, turn = (int(v) for v in scenery[4 * i:4 * i + 4])
+            d = 5 - abs(turn - 5)
+            out.append((SPRITE_CLOUD, 0, x - d, y - d, 48 + 2 * d, 24 + 2 * d))
+        for i in range(27):
+            out.append((SPRITE_WAVE, 0, 16 * i, int(scenery[42 + i]), *sizes[SPRITE_WAVE]))
+    players = []
     for p in range(2):  # draw_player :257-275
         c0 = p * P_WORDS
         st, fr, dive = col[c0 + P_STATE], col[c0 + P_FRAME], col[c0 + P_DIVE]
-        spr = sprites[SPRITE_PIKACHU + sprite_index(st, fr)]
         diving = st in (3, 4)
         flip = (diving and dive == -1) if p == 0 else not (diving and dive == 1)
-        _blit_center(screen, spr[:, ::-1] if flip else spr, col[c0 + P_X], col[c0 + P_Y])
-    _blit_center(screen, sprites[SPRITE_SHADOW], col[P_X], 273)
-    _blit_center(screen, sprites[SPRITE_SHADOW], col[P_WORDS + P_X], 273)
-    _blit_center(screen, sprites[SPRITE_BALL + col[B_ROT] // 10], col[B_X], col[B_Y])  # draw_ball :280-290
-    _blit_center(screen, sprites[SPRITE_SHADOW], col[B_X], 273)
+        players.append((SPRITE_PIKACHU + sprite_index(st, fr), col[c0 + P_X], col[c0 + P_Y], int(flip)))
+    for sid, x, y, flip in players:
+        centred(sid, x, y, flip)
+    centred(SPRITE_SHADOW, col[P_X], 273)
+    centred(SPRITE_SHADOW, col[P_WORDS + P_X], 273)
+    centred(SPRITE_BALL + col[B_ROT] // 10, col[B_X], col[B_Y])  # draw_ball :280-290
+    centred(SPRITE_SHADOW, col[B_X], 273)
     if col[B_POWER]:
-        _blit_center(screen, sprites[SPRITE_HYPER], col[B_PX], col[B_PY])
-        _blit_center(screen, sprites[SPRITE_TRAIL], col[B_PPX], col[B_PPY])
+        centred(SPRITE_HYPER, col[B_PX], col[B_PY])
+        centred(SPRITE_TRAIL, col[B_PPX], col[B_PPY])
     s1, s2 = col[E_S1], col[E_S2]  # draw_scores_to_score_boards :327-336
     if s1 >= 10:
-        _blit(screen, sprites[SPRITE_NUMBER + 1], 14, 10)
-    _blit(screen, sprites[SPRITE_NUMBER + s1 % 10], 14 + 32, 10)
+        out.append((SPRITE_NUMBER + 1, 0, 14, 10, *sizes[SPRITE_NUMBER + 1]))
+    out.append((SPRITE_NUMBER + s1 % 10, 0, 14 + 32, 10, *sizes[SPRITE_NUMBER + s1 % 10]))
     if s2 >= 10:
-        _blit(screen, sprites[SPRITE_NUMBER + 1], 432 - 32 - 32 - 14, 10)
-    _blit(screen, sprites[SPRITE_NUMBER + s2 % 10], 432 - 32 - 32 - 14 + 32, 10)
+        out.append((SPRITE_NUMBER + 1, 0, 432 - 32 - 32 - 14, 10, *sizes[SPRITE_NUMBER + 1]))
+    out.append((SPRITE_NUMBER + s2 % 10, 0, 432 - 32 - 32 - 14 + 32, 10, *sizes[SPRITE_NUMBER + s2 % 10]))
+    return out
+
+
+def stretch_map(src, dst):
+    """Source index of every destination index under pygame.transform.scale, as pygame's transform.c `stretch` walks
+    it (an error-accumulating nearest-neighbour walk, restated from the library source; not checked against the
+    library, which is not installed here): for each destination pixel copy the current source pixel, then advance
+    the source while the error term is non-negative."""
+    out = np.zeros(dst, np.int32)
+    src2, dst2 = 2 * src, 2 * dst
+    err, s = src2 - dst2, 0
+    for d in range(dst):
+        out[d] = min(s, src - 1)
+        while err >= 0:
+            s += 1
+            err -= dst2
+        err += src2
+    return out
+
+
+def scaled(sprite, w, h):
+    hh, ww = sprite.shape[:2]
+    if (ww, hh) == (w, h):
+        return sprite
+    return sprite[stretch_map(hh, h)][:, stretch_map(ww, w)]
+
+
+def frame(col, sprites, background, scenery=None):
+    """uint8 [304, 432, 3] for one game: `col` = its 44 state words, `sprites` = list of the RGBA arrays (46, or 48 with
+    cloud and wave when `scenery` = the game's clouds / waves is given)."""
+    screen = background.copy()
+    sizes = [(s.shape[1], s.shape[0]) for s in sprites]
+    for sid, flip, x, y, w, h in draw_list(col, sizes, scenery):
+        spr = scaled(sprites[sid], w, h)
+        _blit(screen, spr[:, ::-1] if flip else spr, x, y)
     return screen

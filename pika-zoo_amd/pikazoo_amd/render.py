@@ -112,32 +112,36 @@ def blend_over(dst_rgb: np.ndarray, src_rgba: np.ndarray) -> np.ndarray:
     return np.where(a == 0, d, out).astype(np.uint8)
 
 
-def compose_background(tiles: Dict[str, np.ndarray]) -> np.ndarray:
-    """uint8 [304, 432, 3]: draw_background (pikazoo_env.py:296-325) onto a black screen."""
-    screen = np.zeros((HEIGHT, WIDTH, 3), np.uint8)
+def background_blits():
+    """draw_background (pikazoo_env.py:296-325) as the list of its blits (file, x, y), in the reference's order."""
+    out = []
+    for j in range(12):                       # sky :298-300
+        for i in range(432 // 16):
+            out.append(("sky_blue.png", 16 * i, 16 * j))
+    out.append(("mountain.png", 0, 188))      # :303
+    for i in range(432 // 16):                # ground_red :306-307
+        out.append(("ground_red.png", 16 * i, 248))
+    for i in range(1, 432 // 16 - 1):         # ground_line :310-313
+        out.append(("ground_line.png", 16 * i, 264))
+    out.append(("ground_line_leftmost.png", 0, 264))
+    out.append(("ground_line_rightmost.png", 432 - 16, 264))
+    for j in range(2):                        # ground_yellow :316-318
+        for i in range(432 // 16):
+            out.append(("ground_yellow.png", 16 * i, 280 + 16 * j))
+    out.append(("net_pillar_top.png", 213, 176))  # :321-324
+    for j in range(12):
+        out.append(("net_pillar.png", 213, 184 + 8 * j))
+    return out
 
-    def blit(name, x, y):
+
+def compose_background(tiles: Dict[str, np.ndarray]) -> np.ndarray:
+    """uint8 [304, 432, 3]: draw_background onto a black screen."""
+    screen = np.zeros((HEIGHT, WIDTH, 3), np.uint8)
+    for name, x, y in background_blits():
         t = tiles[name]
         h, w = t.shape[:2]
         y1, x1 = min(y + h, HEIGHT), min(x + w, WIDTH)
         screen[y:y1, x:x1] = blend_over(screen[y:y1, x:x1], t[:y1 - y, :x1 - x])
-
-    for j in range(12):                       # sky :298-300
-        for i in range(432 // 16):
-            blit("sky_blue.png", 16 * i, 16 * j)
-    blit("mountain.png", 0, 188)              # :303
-    for i in range(432 // 16):                # ground_red :306-307
-        blit("ground_red.png", 16 * i, 248)
-    for i in range(1, 432 // 16 - 1):         # ground_line :310-313
-        blit("ground_line.png", 16 * i, 264)
-    blit("ground_line_leftmost.png", 0, 264)
-    blit("ground_line_rightmost.png", 432 - 16, 264)
-    for j in range(2):                        # ground_yellow :316-318
-        for i in range(432 // 16):
-            blit("ground_yellow.png", 16 * i, 280 + 16 * j)
-    blit("net_pillar_top.png", 213, 176)      # :321-324
-    for j in range(12):
-        blit("net_pillar.png", 213, 184 + 8 * j)
     return screen
 
 

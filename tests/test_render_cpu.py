@@ -122,3 +122,109 @@ def test_frame_oracle_on_a_reference_state():
         assert f[10 + 5, 386 + 5, 0] == 10 + 36 + int(col[39]) % 10
         # player 1's shadow row is untouched at the far right end of the court
         assert f[273, 431].tolist() in ([0, 0, 0], [10 + 35, 200, 0])
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own render(), recorded (oracle/ref_capture.capture_render): draw lists, clouds / waves, env RNG
+# ------------------------------------------------------------------------------------------------
+RENDER_FIXTURES = ["render_human_human", "render_p2_computer"]
+
+
+def replay_render_fixture(d, on_frame):
+    """Step the C oracle through a render fixture -- construction, clouds, reset, the random policy, a scenery tick
+    wherever the reference rendered -- checking states / clouds / waves against the reference at every point, and call
+    `on_frame(k, lane, state_column, scenery)` for every recorded frame k."""
+    from oracle import pz_oracle as po
+    from oracle import render_oracle as ro
+
+    po.build()
+    meta = d["meta"]
+    lanes, steps, periods = meta["lanes"], meta["steps"], meta["periods"]
+    seed, base = meta["seed"], meta["env_id_base"]
+    kw = meta["env_kwargs"]
+    ref = po.OracleEnv(lanes, po.make_config(winning_score=kw.get("winning_score", 15), serve=kw.get("serve", "winner"),
+                                             is_player2_computer=kw.get("is_player2_computer", False), seed=seed,
+                                             env_id_base=base, auto_reset=True))
+
+    def stream(i):  # the env stream of lane i, continuing from the lane's draw counter
+        def draw(n):
+            v = po.env_draw(seed, base + i, int(ref.state[43, i]) & 0xFFFFFFFF, n)
+            ref.state[43, i] += 1
+            return v
+        return draw
+
+    # constructor: physics (draws 0, 1), then the ten clouds (get_all_image, pikazoo_env.py:475-477)
+    scenery = [ro.scenery_init(stream(i)) for i in range(lanes)]
+    assert np.array_equal(ref.state, d["state_ctor"])
+    assert np.array_equal(np.stack(scenery, axis=1), d["scenery_ctor"])
+    ref.reset()
+    assert np.array_equal(ref.state, d["state0"])
+    k = 0
+
+    def frame(i, t):
+        nonlocal k
+        assert (int(d["frame_lane"][k]), int(d["frame_step"][k])) == (i, t)
+        ro.scenery_tick(scenery[i], stream(i))
+        assert np.array_equal(scenery[i], d["frame_scenery"][k]), (k, i, t)
+        assert np.array_equal(ref.state[:, i], d["frame_state"][k]), (k, i, t)
+        on_frame(k, i, ref.state[:, i].copy(), scenery[i].copy())
+        k += 1
+
+    for i in range(lanes):
+        frame(i, -1)
+    for t in range(steps):
+        a1, a2 = po.random_actions(lanes, base, meta["action_seed"], t, 18)
+        ref.step(a1, a2)
+        assert np.array_equal(ref.state, d["states"][t]), t
+        for i in range(lanes):
+            if (t + 1) % periods[i] == 0:
+                frame(i, t)
+    assert k == len(d["frame_lane"])
+
+
+@pytest.mark.parametrize("name", RENDER_FIXTURES)
+def test_draw_list_clouds_waves_and_rng_match_the_reference_render(name):
+    """The reference's render() run unmodified on a recording stand-in for pygame: every blit it issued (file,
+    mirrored, position, size), its clouds and waves, and what rendering does to the env RNG -- against the oracle."""
+    from conftest import load_golden
+    from oracle import render_oracle as ro
+
+    d = load_golden(name)
+    files = d["meta"]["files"]
+    ours = ro.sprite_files()
+    fid = {f: ours.index(f) for f in files if f in ours}
+    punch = files.index("ball_punch.png")
+    # sprite sizes as the reference's surfaces report them
+    sizes = {}
+    for row in d["frame_draw"].reshape(-1, 6):
+        if row[0] >= 0 and files[row[0]] in fid and files[row[0]] != "cloud.png":
+            sizes.setdefault(fid[files[row[0]]], (int(row[4]), int(row[5])))
+    sizes[ro.SPRITE_CLOUD] = (48, 24)
+    size_list = [sizes.get(i, (0, 0)) for i in range(ro.SPRITE_COUNT)]
+    seen = set()
+
+    def on_frame(k, lane, col, scenery):
+        want = [tuple(int(v) for v in r) for r in d["frame_draw"][k][:d["frame_count"][k]] if r[0] != punch]
+        want = [(fid[files[r[0]]],) + r[1:] for r in want]
+        got = ro.draw_list(col, size_list, scenery)
+        assert got == want, (k, lane)
+        seen.update(r[0] for r in got)
+
+    replay_render_fixture(d, on_frame)
+    assert len(seen) >= 30  # players in most poses, all balls, hyper ball / trail, all digits, cloud, wave
+    # the static part of every frame: the product composes the same blits (file, position, size) in the same order
+    from pikazoo_amd import render as R
+
+    want = [(files[r[0]], int(r[1]), int(r[2]), int(r[3]), int(r[4])) for r in d["background"]]
+    got = [(f, x, y, *R.BACKGROUND_SHAPES[f]) for f, x, y in R.background_blits()]
+    assert got == want
+
+
+def test_stretch_map_is_a_monotone_cover():
+    from oracle import render_oracle as ro
+
+    for src, dst in [(48, 48), (48, 50), (48, 58), (24, 34), (40, 36), (40, 2), (7, 19)]:
+        m = ro.stretch_map(src, dst)
+        assert m[0] == 0 and (np.diff(m) >= 0).all() and m.max() <= src - 1
+        if dst >= src:
+            assert set(m) == set(range(src))  # enlarging drops no source pixel
