@@ -244,17 +244,30 @@ int pz_random_actions(int32_t *act_p1, int32_t *act_p2, int64_t n, int64_t env_i
                       uint64_t action_seed, uint64_t t, int32_t n_actions, void *stream);
 
 /* ---- raw_env.render, render_mode="rgb_array" : pikazoo_env.py:250-384 ------------------------
- * The frame of game lanes[j] (lanes == NULL: game j) for j < m, drawn from the state alone, in the order of
- * raw_env.draw (:250-255): background (draw_background :296-325, composed once by the host into `background`,
- * RGBA8 [304][432]) -> players and their shadows (draw_player :257-278: sprite
+ * The frame of game lanes[j] (lanes == NULL: game j) for j < m, in the order of raw_env.draw (:250-255): background
+ * (draw_background :296-325, composed once by the host into `background`, RGBA8 [304][432]) -> clouds and waves
+ * (draw_clouds_and_wave :338-353, only when `scenery` is given, see below) -> players and their shadows (draw_player :257-278: sprite
  * get_frame_number_for_player_animated_sprite(state, frame_number) :46-68, mirrored by the diving rules :263-264,
  * centred on (x, y); shadows centred on (x, 273)) -> ball (draw_ball :280-290: ball[rotation] with
  * rotation = fine_rotation // 10 physics.py:388, shadow, and on a power hit the hyper ball / trail at the two
  * previous positions) -> score boards (:327-336).  Sprites are RGBA8 (R | G<<8 | B<<16 | A<<24) in `atlas`,
  * described by `sprites[PZ_SPRITE_COUNT]` (device memory); blits use pygame's per-pixel-alpha rule
- * dC = (((sC - dC) * sA + sC) >> 8) + dC.  NOT drawn: clouds and waves (they animate from the env RNG and
- * state outside the 44 words, cloud_and_wave.py:53-78) and the punch effect (its radius is mutated by the
- * reference's render itself, :292-293).  frames: uint8 [m][304][432][3].  Nothing is written to `state`. */
+ * dC = (((sC - dC) * sA + sC) >> 8) + dC.  NOT drawn: the punch effect (:292-294; its radius and y live in two ball
+ * attributes outside the 44 state words, set by the physics and counted down by render itself).
+ * frames: uint8 [m][304][432][3].
+ *
+ * Clouds and waves (cloud_and_wave.py) are state OUTSIDE the 44 words, owned by the reference's renderer and driven by
+ * the env RNG: the constructor of an env with a render_mode draws the ten clouds (get_all_image :475-477: 40 draws right
+ * behind the two boldness draws), and EVERY render() call runs cloud_and_wave_engine (:53-78) first, which draws 27 wave
+ * heights and a few cloud respawns from the same stream -- so in the reference rendering changes the game's later
+ * random draws.  `scenery` reproduces exactly that: int32[PZ_SCENERY_WORDS][stride], field-major like the state
+ * (cloud i at words 4i..4i+3: top_left_point_x, top_left_point_y, top_left_point_x_velocity, size_diff_turn_number;
+ * 40 wave.vertical_coord, 41 its velocity, 42..68 wave.y_coords).  pz_scenery_init = the constructor's part (call it
+ * between pz_init and the first pz_reset); pz_render with scenery != NULL runs the engine for the rendered games
+ * (advancing their rng draw counter in `state`; `lanes` must then hold distinct games and cfg must be given) and draws
+ * the clouds -- scaled like pygame.transform.scale: source pixel = floor(k * source size / scaled size) -- and the
+ * waves.  With scenery == NULL nothing is written to `state` (cfg may be NULL) and no clouds / waves are drawn.
+ * Both calls take the int32 columns (a packed state is converted by the caller). */
 #define PZ_FRAME_WIDTH 432
 #define PZ_FRAME_HEIGHT 304
 enum pz_sprite_id {
@@ -264,15 +277,20 @@ enum pz_sprite_id {
     PZ_SPRITE_BALL_TRAIL = 34,
     PZ_SPRITE_SHADOW = 35,
     PZ_SPRITE_NUMBER = 36,        /* 10: number_0..9 */
-    PZ_SPRITE_COUNT = 46
+    PZ_SPRITE_CLOUD = 46,
+    PZ_SPRITE_WAVE = 47,
+    PZ_SPRITE_COUNT = 48
 };
+#define PZ_SCENERY_WORDS 69
 typedef struct pz_sprite {
     int32_t offset;   /* first pixel in the atlas */
     int32_t width, height;
 } pz_sprite;
-int pz_render(const int32_t *state, int64_t n, int64_t stride, const int32_t *lanes, int64_t m,
+int pz_scenery_init(int32_t *scenery, int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
+                    void *stream);
+int pz_render(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg, const int32_t *lanes, int64_t m,
               const uint32_t *atlas, const pz_sprite *sprites, const uint32_t *background,
-              uint8_t *frames, void *stream);
+              int32_t *scenery, uint8_t *frames, void *stream);
 
 /* ---- self-test hook ------------------------------------------------------------------------
  * The computer player's flight predictors (calculate_expected_landing_point_x_for

@@ -1240,10 +1240,68 @@ __device__ __forceinline__ uint32_t blend_over(uint32_t dst, uint32_t src)
     return out;
 }
 
+// ---- clouds and waves (cloud_and_wave.py): renderer-owned state outside the 44 words, driven by the env stream ----
+// get_all_image's `Cloud(self.np_random)` x 10 (pikazoo_env.py:475-477 -> cloud_and_wave.py:15-19) and Wave() (:42-50)
+__global__ __launch_bounds__(kLanes) void scenery_init_kernel(int32_t* scenery, int32_t* state, int64_t n, int64_t stride,
+                                                              const pz_config cfg)
+{
+    const int64_t i = (int64_t)blockIdx.x * kLanes + threadIdx.x;
+    if (i >= n) return;
+    const RngId id = make_rng_id(cfg, i);
+    uint32_t rng = (uint32_t)state[(int64_t)PZ_E_RNG_DRAW_COUNTER * stride + i];
+    auto word = [&](int w) -> int32_t& { return scenery[(int64_t)w * stride + i]; };
+    for (int c = 0; c < 10; ++c) {
+        word(4 * c + 0) = -68 + rng_integers(id, rng, 432u + 68u);
+        word(4 * c + 1) = rng_integers(id, rng, 152u);
+        word(4 * c + 2) = 1 + rng_integers(id, rng, 2u);
+        word(4 * c + 3) = rng_integers(id, rng, 11u);
+    }
+    word(40) = 0;
+    word(41) = 2;
+    for (int k = 0; k < 27; ++k) word(42 + k) = 314;
+    state[(int64_t)PZ_E_RNG_DRAW_COUNTER * stride + i] = (int32_t)rng;
+}
+
+// cloud_and_wave_engine (cloud_and_wave.py:53-78) for the games about to be drawn: one thread per frame
+__global__ __launch_bounds__(kLanes) void scenery_tick_kernel(int32_t* scenery, int32_t* state, int64_t n, int64_t stride,
+                                                              const pz_config cfg, const int32_t* lanes, int64_t m)
+{
+    const int64_t j = (int64_t)blockIdx.x * kLanes + threadIdx.x;
+    if (j >= m) return;
+    const int64_t i = lanes != nullptr ? (int64_t)lanes[j] : j;
+    if (i < 0 || i >= n) return;
+    const RngId id = make_rng_id(cfg, i);
+    uint32_t rng = (uint32_t)state[(int64_t)PZ_E_RNG_DRAW_COUNTER * stride + i];
+    auto word = [&](int w) -> int32_t& { return scenery[(int64_t)w * stride + i]; };
+    for (int c = 0; c < 10; ++c) {
+        int x = word(4 * c) + word(4 * c + 2);
+        if (x > 432) {
+            x = -68;
+            word(4 * c + 1) = rng_integers(id, rng, 152u);
+            word(4 * c + 2) = 1 + rng_integers(id, rng, 2u);
+        }
+        word(4 * c) = x;
+        const int turn = word(4 * c + 3) + 1;
+        word(4 * c + 3) = turn >= 11 ? turn - 11 : turn;
+    }
+    int vc = word(40) + word(41);
+    if (vc > 32) {
+        vc = 32;
+        word(41) = -1;
+    } else if (vc < 0 && word(41) < 0) {
+        word(41) = 2;
+        vc = -rng_integers(id, rng, 40u);
+    }
+    word(40) = vc;
+    for (int k = 0; k < 27; ++k) word(42 + k) = 314 - vc + rng_integers(id, rng, 3u);
+    state[(int64_t)PZ_E_RNG_DRAW_COUNTER * stride + i] = (int32_t)rng;
+}
+
 __global__ __launch_bounds__(256) void render_kernel(const int32_t* __restrict__ state, int64_t n, int64_t stride,
                                                      const int32_t* __restrict__ lanes, const uint32_t* __restrict__ atlas,
                                                      const pz_sprite* __restrict__ sprites,
-                                                     const uint32_t* __restrict__ background, uint8_t* __restrict__ frames)
+                                                     const uint32_t* __restrict__ background,
+                                                     const int32_t* __restrict__ scenery, uint8_t* __restrict__ frames)
 {
     constexpr int kGroupsPerRow = PZ_FRAME_WIDTH / 4;
     const int64_t game = lanes != nullptr ? (int64_t)lanes[blockIdx.y] : (int64_t)blockIdx.y;  // wave-uniform
@@ -1281,6 +1339,34 @@ __global__ __launch_bounds__(256) void render_kernel(const int32_t* __restrict__
     uint32_t px[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) px[k] = background[row * PZ_FRAME_WIDTH + col + k];
+    if (scenery != nullptr) {  // draw_clouds_and_wave :351-364, behind the players
+        auto sc = [&](int w) { return scenery[(int64_t)w * stride + game]; };
+        const pz_sprite cloud = sprites[PZ_SPRITE_CLOUD], wave = sprites[PZ_SPRITE_WAVE];
+        for (int c = 0; c < 10; ++c) {
+            const int turn = sc(4 * c + 3);
+            const int d = 5 - abs(turn - 5);                                    // Cloud.size_diff :22-23
+            const int x0 = sc(4 * c) - d, y0 = sc(4 * c + 1) - d;               // sprite_top_left_point :26-31
+            const int w = cloud.width + 2 * d, h = cloud.height + 2 * d;         // sprite_width / height :34-39
+            const int dy = row - y0;
+            if ((unsigned)dy >= (unsigned)h || col + 3 < x0 || col >= x0 + w) continue;
+            const int sy = dy * cloud.height / h;  // pygame.transform.scale: source = floor(k * source size / scaled size)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int dx = col + k - x0;
+                if ((unsigned)dx < (unsigned)w)
+                    px[k] = blend_over(px[k], atlas[cloud.offset + sy * cloud.width + dx * cloud.width / w]);
+            }
+        }
+        const int tile = col / wave.width;  // the four pixels of a thread share one 16-pixel wave tile
+        if (tile < 27) {
+            const int sy = row - sc(42 + tile);
+            if ((unsigned)sy < (unsigned)wave.height) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    px[k] = blend_over(px[k], atlas[wave.offset + sy * wave.width + (col + k - tile * wave.width)]);
+            }
+        }
+    }
 #pragma unroll
     for (int b = 0; b < 12; ++b) {
         if (list[b].sprite < 0) continue;
@@ -1623,16 +1709,30 @@ int pz_random_actions(int32_t* act_p1, int32_t* act_p2, int64_t n, int64_t env_i
     return (int)hipGetLastError();
 }
 
-int pz_render(const int32_t* state, int64_t n, int64_t stride, const int32_t* lanes, int64_t m, const uint32_t* atlas,
-              const pz_sprite* sprites, const uint32_t* background, uint8_t* frames, void* stream)
+int pz_scenery_init(int32_t* scenery, int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, void* stream)
 {
-    if (!state || !atlas || !sprites || !background || !frames) return PZ_E_NULL;
+    if (!scenery || !state || !cfg) return PZ_E_NULL;
+    if (n < 0 || stride < n || stride > kMaxLanesPerLaunch) return PZ_E_SIZE;
+    if (n == 0) return PZ_OK;
+    hipLaunchKernelGGL(scenery_init_kernel, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, scenery, state,
+                       n, stride, *cfg);
+    return (int)hipGetLastError();
+}
+
+int pz_render(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, const int32_t* lanes, int64_t m,
+              const uint32_t* atlas, const pz_sprite* sprites, const uint32_t* background, int32_t* scenery,
+              uint8_t* frames, void* stream)
+{
+    if (!state || !atlas || !sprites || !background || !frames || (scenery != nullptr && cfg == nullptr)) return PZ_E_NULL;
     if (n < 0 || stride < n || stride > kMaxLanesPerLaunch || m < 0 || m > 65535) return PZ_E_SIZE;
     if ((lanes == nullptr && m > n) || (reinterpret_cast<uintptr_t>(frames) & 3u) != 0) return lanes == nullptr && m > n ? PZ_E_SIZE : PZ_E_ALIGN;
     if (m == 0) return PZ_OK;
     const dim3 grid(blocks_for((int64_t)(PZ_FRAME_WIDTH / 4) * PZ_FRAME_HEIGHT, 256), (unsigned int)m);
+    if (scenery != nullptr)
+        hipLaunchKernelGGL(scenery_tick_kernel, dim3(blocks_for(m, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, scenery,
+                           state, n, stride, *cfg, lanes, m);
     hipLaunchKernelGGL(render_kernel, grid, dim3(256), 0, (hipStream_t)stream, state, n, stride, lanes, atlas, sprites,
-                       background, frames);
+                       background, scenery, frames);
     return (int)hipGetLastError();
 }
 

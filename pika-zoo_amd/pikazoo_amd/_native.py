@@ -80,7 +80,9 @@ _SIGNATURES = {
                                _P, _P, _P]),
     "pz_random_actions": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _P]),
     "pz_selftest_predictor": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
-    "pz_render": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, _P, _P, _P, _P, _P]),
+    "pz_scenery_init": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P]),
+    # (cfg may be None when no scenery is passed: ctypes passes NULL for None)
+    "pz_render": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

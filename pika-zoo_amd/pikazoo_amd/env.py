@@ -100,7 +100,11 @@ class raw_env:
     ``state_format`` ("int32": the state lives in HBM as the ``int32[44, num_envs]`` tensor :attr:`state`,
     live and writable; "packed": as 36 bytes per game instead of 176 -- the bit-packed format of
     ``include/pikazoo_hip.h`` -- which makes large batches about a third faster; every result is identical,
-    :attr:`state` then returns an unpacked copy, and checkpoints are interchangeable between the two).
+    :attr:`state` then returns an unpacked copy, and checkpoints are interchangeable between the two);
+    ``scenery`` (with ``render_mode="rgb_array"``: draw the reference's clouds and waves too.  They are renderer-owned
+    state driven by the env RNG, so -- exactly as in the reference, pikazoo_env.py:475-477, cloud_and_wave.py:53-78 --
+    the constructor then draws 40 values behind the two boldness draws and every ``render()`` advances the RNG of the
+    games it draws; off by default, which keeps ``render()`` free of side effects).
 
     Returned tensors are views of env-owned buffers that the next ``step`` overwrites;
     ``clone()`` what must outlive it.
@@ -112,7 +116,7 @@ class raw_env:
                  is_player2_computer: bool = False, render_mode=None, *, num_envs: int = 1,
                  device="cuda", seed: int = 0, env_id_base: int = 0, auto_reset: Optional[bool] = None,
                  validate_actions: bool = True, scalar_api: bool = False, flight_tables: bool = True,
-                 sprite_dir=None, sprites=None, state_format: str = "int32"):
+                 sprite_dir=None, sprites=None, state_format: str = "int32", scenery: bool = False):
         assert serve in ("winner", "alternate", "random")  # pikazoo_env.py:104
         if render_mode not in (None, "rgb_array"):
             raise NotImplementedError('render_mode must be None or "rgb_array" (no "human" window on a GPU batch)')
@@ -122,6 +126,8 @@ class raw_env:
             raise ValueError("num_envs must be >= 1")
         if state_format not in ("int32", "packed"):
             raise ValueError('state_format must be "int32" or "packed"')
+        if scenery and render_mode is None:
+            raise ValueError('scenery=True needs render_mode="rgb_array"')
         if state_format == "packed" and int(winning_score) > 32767:
             raise ValueError("the packed state format holds scores up to 32767")
         self._lib = _native.load()  # raises when the HIP library has not been built
@@ -209,6 +215,12 @@ class raw_env:
         with torch.cuda.device(self.device):
             _native.check(self._lib.pz_init(self._state_ptr, n, self._stride, self._cfg_ref, self._stream()),
                           "pz_init")
+        self._scenery = None
+        if scenery:  # get_all_image's ten clouds: 40 draws of the env stream per game, right behind the constructor's two
+            self._scenery = torch.zeros((69, self._stride), dtype=torch.int32, device=dev)
+            self._on_int32_state(lambda ptr: _native.check(
+                self._lib.pz_scenery_init(self._scenery.data_ptr(), ptr, n, self._stride, self._cfg_ref, self._stream()),
+                "pz_scenery_init"))
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -253,6 +265,18 @@ class raw_env:
             raise _native.PikazooNativeError(
                 f"{int(flagged.item())} games carry the packed format's misfit flag: a value left its field")
         return out, self._stride
+
+    def _on_int32_state(self, call):
+        """Run ``call(pointer to int32[44, stride] columns)`` for the entry points that take (and may write) int32
+        columns only; a packed state is unpacked for the call and packed again."""
+        with torch.cuda.device(self.device):
+            if self._state_view is not None:
+                return call(self._state_ptr)
+            cols, _ = self._unpacked()
+            out = call(cols.data_ptr())
+            _native.check(self._lib.pz_pack_state(cols.data_ptr(), self.num_envs, self._stride, self._state_ptr,
+                                                  self._stride, None, self._stream()), "pz_pack_state")
+            return out
 
     def set_state(self, state: torch.Tensor):
         """Overwrite the state of every game with ``int32[44, num_envs]`` columns (either format)."""
@@ -626,7 +650,8 @@ class raw_env:
         return {"state": self.state.clone(), "steps_done": self.steps_done, "seed": self.seed,
                 "env_id_base": self.env_id_base, "config": self._cfg_dict(),
                 "episode_stats": None if self._stats is None else self._stats.clone(),
-                "episodes_done": self._episodes.clone()}
+                "episodes_done": self._episodes.clone(),
+                "scenery": None if self._scenery is None else self._scenery[:, :self.num_envs].clone()}
 
     def load_state_dict(self, sd):
         """Restore a :meth:`state_dict`.  Raises when it was taken from an env whose Philox key, game ids or
@@ -645,7 +670,12 @@ class raw_env:
         stats = sd.get("episode_stats")
         if (stats is None) != (self._stats is None):
             raise ValueError("checkpoint and env disagree on RecordEpisodeStatistics")
+        scenery = sd.get("scenery")
+        if (scenery is None) != (self._scenery is None):
+            raise ValueError("checkpoint and env disagree on scenery= (the clouds and waves of render())")
         self.set_state(sd["state"])
+        if scenery is not None:
+            self._scenery[:, :self.num_envs].copy_(scenery)
         if stats is not None:
             self._stats.copy_(stats)
         if sd.get("episodes_done") is not None:
@@ -657,7 +687,8 @@ class raw_env:
         """``rgb_array`` frames of the current state (pikazoo_env.py:250-384, drawn by ``pz_render``):
         ``uint8[m, 304, 432, 3]`` for the games `lanes` (an int sequence / tensor; default: every game, as long
         as that stays below 1 GiB); ``scalar_api`` envs get the reference's ``[304, 432, 3]`` numpy array.
-        Clouds, waves and the punch effect are not drawn (they are not a function of the game state)."""
+        An env created with ``scenery=True`` also draws the clouds and waves -- and, like the reference's ``render()``,
+        then advances the env RNG of the games it draws (`lanes` must be distinct).  The punch effect is not drawn."""
         if self.render_mode is None:  # the reference warns and returns None (pikazoo_env.py:355-357)
             import warnings
 
@@ -679,6 +710,21 @@ class raw_env:
                 raise IndexError("lane out of range")
         elif self.num_envs * _render.HEIGHT * _render.WIDTH * 3 > (1 << 30):
             raise ValueError(f"rendering all {self.num_envs} games needs more than 1 GiB: pass lanes=")
+        if self._scenery is not None:
+            if lane_t is not None and int(torch.unique(lane_t).numel()) != int(lane_t.numel()):
+                raise ValueError("lanes must be distinct when the scenery is drawn (every frame ticks its game's clouds)")
+
+            class _Cols:  # pz_render takes the int32 columns (and advances their rng counters)
+                def __init__(self, ptr):
+                    self.ptr = ptr
+
+                def data_ptr(self):
+                    return self.ptr
+
+            frames = self._on_int32_state(lambda ptr: _render.render(
+                self._lib, _Cols(ptr), self.num_envs, self._stride, self._sprites, lane_t, self._stream(), out,
+                scenery=self._scenery, cfg_ref=self._cfg_ref, device=self.device))
+            return frames[0].cpu().numpy() if self.scalar_api else frames
         with torch.cuda.device(self.device):
             state = self._state_buf if self._state_view is not None else self._unpacked()[0]  # pz_render reads int32 columns
             frames = _render.render(self._lib, state, self.num_envs, self._stride, self._sprites, lane_t,

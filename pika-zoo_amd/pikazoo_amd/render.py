@@ -7,9 +7,11 @@ points to (by default the ``img`` directory of an installed ``pikazoo`` package)
 composes the static background once on the host, exactly in the order of ``draw_background`` (:296-325).
 :func:`synthetic_sprites` builds a sprite set of the same geometry from a seed (tests, demos without the assets).
 
-Drawn: background, both players with their mirroring rules, shadows, ball / hyper ball / trail, score boards.
-Not drawn (see ``include/pikazoo_hip.h``): clouds, waves and the punch effect -- they animate from the env RNG and from
-state that rendering itself mutates, so they are not a function of the 44 state words.
+Drawn: background, both players with their mirroring rules, shadows, ball / hyper ball / trail, score boards; and,
+for an env created with ``scenery=True``, the clouds and waves -- renderer-owned state outside the 44 words that, as in
+the reference, is drawn from the env RNG (ten clouds at construction, a tick of ``cloud_and_wave_engine`` with every
+``render()``), so rendering then changes the game's later random draws exactly like the reference's does.
+Not drawn (see ``include/pikazoo_hip.h``): the punch effect.
 """
 from __future__ import annotations
 
@@ -30,15 +32,17 @@ PIKACHU_FRAMES = [(0, 5), (1, 5), (2, 5), (3, 2), (4, 1), (5, 5), (6, 5)]  # get
 SPRITE_FILES = ([f"pikachu_{s}_{f}.png" for s, k in PIKACHU_FRAMES for f in range(k)]          # 0..27
                 + [f"ball_{i}.png" for i in range(5)] + ["ball_hyper.png"]                    # 28..33
                 + ["ball_trail.png", "shadow.png"]                                            # 34, 35
-                + [f"number_{i}.png" for i in range(10)])                                     # 36..45
+                + [f"number_{i}.png" for i in range(10)]                                      # 36..45
+                + ["cloud.png", "wave.png"])                                                  # 46, 47
 BACKGROUND_FILES = ["sky_blue.png", "mountain.png", "ground_red.png", "ground_line.png", "ground_line_leftmost.png",
                     "ground_line_rightmost.png", "ground_yellow.png", "net_pillar_top.png", "net_pillar.png"]
-SPRITE_SHAPES = ([(64, 64)] * 28 + [(40, 40)] * 7 + [(32, 8)] + [(32, 32)] * 10)              # (width, height)
+SPRITE_SHAPES = ([(64, 64)] * 28 + [(40, 40)] * 7 + [(32, 8)] + [(32, 32)] * 10 + [(48, 24), (16, 32)])  # (width, height)
+SCENERY_WORDS = 69
 BACKGROUND_SHAPES = {"sky_blue.png": (16, 16), "mountain.png": (432, 64), "ground_red.png": (16, 16),
                      "ground_line.png": (16, 16), "ground_line_leftmost.png": (16, 16),
                      "ground_line_rightmost.png": (16, 16), "ground_yellow.png": (16, 16),
                      "net_pillar_top.png": (8, 8), "net_pillar.png": (8, 8)}
-assert len(SPRITE_FILES) == len(SPRITE_SHAPES) == 46
+assert len(SPRITE_FILES) == len(SPRITE_SHAPES) == 48
 
 
 class PzSprite(C.Structure):
@@ -146,7 +150,7 @@ def compose_background(tiles: Dict[str, np.ndarray]) -> np.ndarray:
 
 
 class SpriteSet:
-    """The 46 dynamic sprites (RGBA8 atlas + descriptor table) and the composed background, on one device."""
+    """The 48 dynamic sprites (RGBA8 atlas + descriptor table) and the composed background, on one device."""
 
     def __init__(self, sprites, tiles, device):
         if len(sprites) != len(SPRITE_FILES):
@@ -213,12 +217,16 @@ def synthetic_sprites(seed: int, device) -> SpriteSet:
 
 
 def render(lib, state: torch.Tensor, n: int, stride: int, sprite_set: SpriteSet, lanes: Optional[torch.Tensor],
-           stream: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """uint8 ``[m, 304, 432, 3]`` frames of the games `lanes` (None: all n) through ``pz_render``."""
+           stream: int, out: Optional[torch.Tensor] = None, scenery: Optional[torch.Tensor] = None, cfg_ref=None,
+           device=None) -> torch.Tensor:
+    """uint8 ``[m, 304, 432, 3]`` frames of the games `lanes` (None: all n) through ``pz_render``.  With `scenery`
+    (``int32[69, stride]``) the clouds / waves of the drawn games advance first (and with them the games' env RNG
+    counters in `state`) and are drawn."""
     m = n if lanes is None else int(lanes.numel())
     if out is None or out.shape[0] != m:
-        out = torch.empty((m, HEIGHT, WIDTH, 3), dtype=torch.uint8, device=state.device)
-    _native.check(lib.pz_render(state.data_ptr(), n, stride, None if lanes is None else lanes.data_ptr(), m,
+        out = torch.empty((m, HEIGHT, WIDTH, 3), dtype=torch.uint8, device=device if device is not None else state.device)
+    _native.check(lib.pz_render(state.data_ptr(), n, stride, cfg_ref, None if lanes is None else lanes.data_ptr(), m,
                                 sprite_set.atlas.data_ptr(), sprite_set.table.data_ptr(),
-                                sprite_set.background.data_ptr(), out.data_ptr(), stream), "pz_render")
+                                sprite_set.background.data_ptr(), None if scenery is None else scenery.data_ptr(),
+                                out.data_ptr(), stream), "pz_render")
     return out

@@ -77,3 +77,88 @@ def test_render_api_behaviour():
         big.render()
     assert big.render(lanes=[5, 4095]).shape == (2, 304, 432, 3)
     assert "rgb_array" in big.metadata["render_modes"]
+
+
+@pytest.mark.parametrize("name,fmt", [("render_human_human", "int32"), ("render_p2_computer", "packed")])
+def test_rendering_with_scenery_follows_the_reference_render(name, fmt):
+    """The reference's own render() (recorded by oracle/ref_capture.capture_render: constructor with a render_mode,
+    render after reset and every few steps, per lane) replayed through the product: the 44 state words after every step
+    and after every frame (rendering advances the env RNG), the clouds / waves after every frame -- against the
+    reference; the frames themselves against the numpy oracle (whose draw lists tests/test_render_cpu.py pins to the
+    reference's)."""
+    from conftest import load_golden
+    from oracle import render_oracle as ro
+    from pikazoo_amd import pikazoo_v0
+    from pikazoo_amd.render import synthetic_sprites
+
+    d = load_golden(name)
+    meta = d["meta"]
+    lanes, steps, periods = meta["lanes"], meta["steps"], meta["periods"]
+    sprites = synthetic_sprites(11, "cuda:0")
+    env = pikazoo_v0.env(num_envs=lanes, device="cuda:0", seed=meta["seed"], env_id_base=meta["env_id_base"],
+                         render_mode="rgb_array", sprites=sprites, scenery=True, validate_actions=False,
+                         state_format=fmt, **meta["env_kwargs"])
+    assert np.array_equal(env.state.cpu().numpy(), d["state_ctor"])
+    assert np.array_equal(env._scenery[:, :lanes].cpu().numpy(), d["scenery_ctor"])
+    env.reset()
+    assert np.array_equal(env.state.cpu().numpy(), d["state0"])
+    k = checked = 0
+
+    def render(due, t):
+        nonlocal k, checked
+        frames = env.render(lanes=due).cpu().numpy()
+        st = env.state.cpu().numpy()
+        sc = env._scenery[:, :lanes].cpu().numpy()
+        for j, i in enumerate(due):
+            assert (int(d["frame_lane"][k]), int(d["frame_step"][k])) == (i, t)
+            assert np.array_equal(st[:, i], d["frame_state"][k]), (k, i, t)
+            assert np.array_equal(sc[:, i], d["frame_scenery"][k]), (k, i, t)
+            if k % 5 == 0:
+                want = ro.frame(st[:, i], sprites.sprites_host, sprites.background_host, sc[:, i])
+                assert np.array_equal(frames[j], want), (k, i, t)
+                checked += 1
+            k += 1
+
+    render(list(range(lanes)), -1)
+    for t in range(steps):
+        env.step(env.random_actions(meta["action_seed"], t))
+        due = [i for i in range(lanes) if (t + 1) % periods[i] == 0]
+        if due:
+            assert np.array_equal(env.state.cpu().numpy(), d["states"][t]), t
+            render(due, t)
+    assert k == len(d["frame_lane"]) and checked > 300
+    assert np.array_equal(env.state.cpu().numpy()[:43], d["states"][steps - 1][:43])
+
+
+def test_scenery_api_behaviour():
+    from pikazoo_amd import pikazoo_v0
+    from pikazoo_amd.render import synthetic_sprites
+
+    sprites = synthetic_sprites(2, "cuda:0")
+    with pytest.raises(ValueError):
+        pikazoo_v0.env(num_envs=4, scenery=True)  # needs a render_mode
+    kw = dict(num_envs=64, seed=9, render_mode="rgb_array", sprites=sprites)
+    plain, scen = pikazoo_v0.env(**kw), pikazoo_v0.env(scenery=True, **kw)
+    assert bool((scen.state[43] == 42).all()) and bool((plain.state[43] == 2).all())  # 40 cloud draws at construction
+    for e in (plain, scen):
+        e.reset()
+        e.step_random(5, k=30)
+    before = plain.state.clone()
+    plain.render()
+    assert torch.equal(plain.state, before)                    # without scenery render() has no side effects
+    before = scen.state.clone()
+    f1 = scen.render(lanes=[3, 5])
+    after = scen.state
+    changed = (after != before).any(dim=0).nonzero().flatten().tolist()
+    assert changed == [3, 5] and bool((after[43, [3, 5]] >= before[43, [3, 5]] + 27).all())  # 27 wave draws + respawns
+    assert torch.equal(after[:43], before[:43])
+    with pytest.raises(ValueError):
+        scen.render(lanes=[1, 1])
+    # checkpoints carry the clouds and waves
+    sd = scen.state_dict()
+    f2 = scen.render(lanes=[3, 5])
+    other = pikazoo_v0.env(scenery=True, **kw)
+    other.load_state_dict(sd)
+    assert torch.equal(other.render(lanes=[3, 5]), f2) and not torch.equal(f1, f2)
+    with pytest.raises(ValueError):
+        plain.load_state_dict(sd)
