@@ -3,7 +3,7 @@
 
 Builds csrc with -DPZ_ABLATE into pika-zoo_amd/lib/libpikazoo_hip_ablate.so and times the
 human-vs-human step at 65 536 games with traffic classes redirected to one workgroup's span or the
-frame skipped (cfg.reserved bits, see pz_kernels.hip).  Interleaved rounds in one process
+frame skipped (bits 3.. of cfg.packed_state, see pz_kernels.hip).  Interleaved rounds in one process
 (cdna_hip_programming.md rule 24); prints median / min microseconds per launch from HIP events.
 
     python tools/ablate.py --build      # here (cross-compile)
@@ -65,7 +65,7 @@ def main():
     assert lib.pz_reset(state.data_ptr(), n, n, C.byref(cfg), None, obs[0].data_ptr(), obs[1].data_ptr(), None, stream) == 0
 
     def run(flags, steps):
-        cfg.reserved = flags
+        cfg.packed_state = flags  # bits 3.. of this field are the timing-only switches (bit 0: packed state format)
         for t in range(steps):
             a = acts[t % 64]
             lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
