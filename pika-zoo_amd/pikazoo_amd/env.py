@@ -713,22 +713,15 @@ class raw_env:
         if self._scenery is not None:
             if lane_t is not None and int(torch.unique(lane_t).numel()) != int(lane_t.numel()):
                 raise ValueError("lanes must be distinct when the scenery is drawn (every frame ticks its game's clouds)")
-
-            class _Cols:  # pz_render takes the int32 columns (and advances their rng counters)
-                def __init__(self, ptr):
-                    self.ptr = ptr
-
-                def data_ptr(self):
-                    return self.ptr
-
+            # pz_render then advances the rng counters of the drawn games in the int32 columns
             frames = self._on_int32_state(lambda ptr: _render.render(
-                self._lib, _Cols(ptr), self.num_envs, self._stride, self._sprites, lane_t, self._stream(), out,
-                scenery=self._scenery, cfg_ref=self._cfg_ref, device=self.device))
-            return frames[0].cpu().numpy() if self.scalar_api else frames
-        with torch.cuda.device(self.device):
-            state = self._state_buf if self._state_view is not None else self._unpacked()[0]  # pz_render reads int32 columns
-            frames = _render.render(self._lib, state, self.num_envs, self._stride, self._sprites, lane_t,
-                                    self._stream(), out)
+                self._lib, ptr, self.device, self.num_envs, self._stride, self._sprites, lane_t, self._stream(), out,
+                scenery=self._scenery, cfg_ref=self._cfg_ref))
+        else:
+            with torch.cuda.device(self.device):
+                cols = self._state_buf if self._state_view is not None else self._unpacked()[0]  # (kept alive over the launch)
+                frames = _render.render(self._lib, cols.data_ptr(), self.device, self.num_envs, self._stride,
+                                        self._sprites, lane_t, self._stream(), out)
         return frames[0].cpu().numpy() if self.scalar_api else frames
 
     def close(self):

@@ -216,16 +216,15 @@ def synthetic_sprites(seed: int, device) -> SpriteSet:
     return SpriteSet(sprites, tiles, device)
 
 
-def render(lib, state: torch.Tensor, n: int, stride: int, sprite_set: SpriteSet, lanes: Optional[torch.Tensor],
-           stream: int, out: Optional[torch.Tensor] = None, scenery: Optional[torch.Tensor] = None, cfg_ref=None,
-           device=None) -> torch.Tensor:
-    """uint8 ``[m, 304, 432, 3]`` frames of the games `lanes` (None: all n) through ``pz_render``.  With `scenery`
-    (``int32[69, stride]``) the clouds / waves of the drawn games advance first (and with them the games' env RNG
-    counters in `state`) and are drawn."""
+def render(lib, state_ptr: int, device, n: int, stride: int, sprite_set: SpriteSet, lanes: Optional[torch.Tensor],
+           stream: int, out: Optional[torch.Tensor] = None, scenery: Optional[torch.Tensor] = None, cfg_ref=None) -> torch.Tensor:
+    """uint8 ``[m, 304, 432, 3]`` frames of the games `lanes` (None: all n) through ``pz_render``; `state_ptr` = the
+    ``int32[44, stride]`` columns on `device`.  With `scenery` (``int32[69, stride]``) the clouds / waves of the drawn
+    games advance first (and with them the games' env RNG counters in the state) and are drawn."""
     m = n if lanes is None else int(lanes.numel())
     if out is None or out.shape[0] != m:
-        out = torch.empty((m, HEIGHT, WIDTH, 3), dtype=torch.uint8, device=device if device is not None else state.device)
-    _native.check(lib.pz_render(state.data_ptr(), n, stride, cfg_ref, None if lanes is None else lanes.data_ptr(), m,
+        out = torch.empty((m, HEIGHT, WIDTH, 3), dtype=torch.uint8, device=device)
+    _native.check(lib.pz_render(state_ptr, n, stride, cfg_ref, None if lanes is None else lanes.data_ptr(), m,
                                 sprite_set.atlas.data_ptr(), sprite_set.table.data_ptr(),
                                 sprite_set.background.data_ptr(), None if scenery is None else scenery.data_ptr(),
                                 out.data_ptr(), stream), "pz_render")
