@@ -13,6 +13,7 @@ LIB_PATH = PKG_ROOT / "lib" / "libpikazoo_hip.so"
 
 ABI_VERSION = 5
 PACKED_BYTES_PER_GAME = 36
+SCENERY_WORDS = 69
 STATE_WORDS = 44
 OBS_DIM = 35
 SERVE_MODES = {"winner": 0, "alternate": 1, "random": 2}

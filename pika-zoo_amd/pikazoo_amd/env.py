@@ -217,7 +217,7 @@ class raw_env:
                           "pz_init")
         self._scenery = None
         if scenery:  # get_all_image's ten clouds: 40 draws of the env stream per game, right behind the constructor's two
-            self._scenery = torch.zeros((69, self._stride), dtype=torch.int32, device=dev)
+            self._scenery = torch.zeros((_native.SCENERY_WORDS, self._stride), dtype=torch.int32, device=dev)
             self._on_int32_state(lambda ptr: _native.check(
                 self._lib.pz_scenery_init(self._scenery.data_ptr(), ptr, n, self._stride, self._cfg_ref, self._stream()),
                 "pz_scenery_init"))

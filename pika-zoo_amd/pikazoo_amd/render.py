@@ -37,7 +37,7 @@ SPRITE_FILES = ([f"pikachu_{s}_{f}.png" for s, k in PIKACHU_FRAMES for f in rang
 BACKGROUND_FILES = ["sky_blue.png", "mountain.png", "ground_red.png", "ground_line.png", "ground_line_leftmost.png",
                     "ground_line_rightmost.png", "ground_yellow.png", "net_pillar_top.png", "net_pillar.png"]
 SPRITE_SHAPES = ([(64, 64)] * 28 + [(40, 40)] * 7 + [(32, 8)] + [(32, 32)] * 10 + [(48, 24), (16, 32)])  # (width, height)
-SCENERY_WORDS = 69
+SCENERY_WORDS = _native.SCENERY_WORDS
 BACKGROUND_SHAPES = {"sky_blue.png": (16, 16), "mountain.png": (432, 64), "ground_red.png": (16, 16),
                      "ground_line.png": (16, 16), "ground_line_leftmost.png": (16, 16),
                      "ground_line_rightmost.png": (16, 16), "ground_yellow.png": (16, 16),

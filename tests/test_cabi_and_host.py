@@ -76,6 +76,8 @@ def test_header_layout_matches_oracle_layout(oracle):
 
     text = (REPO / "include" / "pikazoo_hip.h").read_text()
     assert "#define PZ_STATE_WORDS 44" in text and "PZ_B_X = 26" in text and "PZ_E_SCORE_P1 = 38" in text
+    assert f"#define PZ_PACKED_BYTES_PER_GAME {_native.PACKED_BYTES_PER_GAME}" in text
+    assert f"#define PZ_SCENERY_WORDS {_native.SCENERY_WORDS}" in text and f"#define PZ_ABI_VERSION {_native.ABI_VERSION}" in text
     assert C.sizeof(oracle.Config) == C.sizeof(_native.PzConfig)
     for (n1, t1), (n2, t2) in zip(oracle.Config._fields_, _native.PzConfig._fields_):
         assert n1 == n2 and C.sizeof(t1) == C.sizeof(t2)
