@@ -545,7 +545,7 @@ def main():
             "timed_steps": main_res["timed_steps"], "replays": main_res["replays"],
             "launches_per_replay": main_res["launches_per_replay"], "timed_seconds": main_res["wall_s"],
             "burn_in_frames": args.burn_in,
-            "rccl_ranks": dist.world_size(), "dist_backend": dist.backend_name(),
+            "rccl_ranks": dist.world_size(), "dist_backend": dist.backend_name(), "dist_note": dist.fallback_note(),
             "build_id": _native.build_id(),
             "config": {
                 "workload": f"{args.num_envs} games per GPU, both players uniform-random actions "

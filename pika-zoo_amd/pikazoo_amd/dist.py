@@ -9,7 +9,9 @@ The only collective is a SUM all-reduce of a few int64 counters per reporting wi
 from __future__ import annotations
 
 import os
+import sys
 from dataclasses import dataclass
+from datetime import timedelta
 
 import torch
 import torch.distributed as dist
@@ -54,12 +56,36 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            try:
+                torch.cuda.set_device(local_rank)
+                dev = torch.device("cuda", local_rank)
+                dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
+                probe = torch.ones(1, dtype=torch.int64, device=dev)  # the communicator works before anything is timed
+                dist.all_reduce(probe)
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"RCCL all-reduce of ones gave {int(probe.item())}, expected {world}")
+            except Exception as exc:  # noqa: BLE001 - RCCL only carries the aggregate counters: keep the job alive
+                global _FALLBACK_NOTE
+                _FALLBACK_NOTE = f"nccl (RCCL) unavailable: {type(exc).__name__}: {exc}"[:300]
+                print(f"[pikazoo_amd.dist] {_FALLBACK_NOTE}; the counters fall back to gloo", file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    try:
+                        dist.destroy_process_group()
+                    except Exception:  # noqa: BLE001
+                        pass
+                # same rendezvous (under torchrun the store is served by the launcher's agent, not by rank 0)
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=180))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+_FALLBACK_NOTE = None
+
+
+def fallback_note():
+    """Why the process group is not on the requested nccl backend (None when it is, or was never asked for)."""
+    return _FALLBACK_NOTE
 
 
 def all_reduce_sum(values, device=None) -> list[int]:

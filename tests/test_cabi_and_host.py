@@ -148,6 +148,33 @@ if rank == 0:
 '''
 
 
+_FALLBACK_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.path.join(sys.argv[1], "pika-zoo_amd"))
+from pikazoo_amd import dist
+rank, world, _ = dist.init_from_env("nccl")   # no GPU in this container: RCCL cannot come up
+total, = dist.all_reduce_sum([rank + 1])
+if rank == 0:
+    open(os.path.join(sys.argv[2], "fallback.txt"), "w").write(f"{dist.backend_name()} {world} {total} {dist.fallback_note()}")
+'''
+
+
+def test_counters_fall_back_to_gloo_when_rccl_cannot_start(tmp_path):
+    """RCCL only carries the aggregate counters; if it cannot start, the ranks agree on gloo and say so."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU (RCCL starts fine with one)")
+    script = tmp_path / "worker.py"
+    script.write_text(_FALLBACK_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29543", str(script), str(REPO),
+                           str(tmp_path)], env=env, timeout=600)
+    backend, world, total, note = (tmp_path / "fallback.txt").read_text().split(" ", 3)
+    assert (backend, world, total) == ("gloo", "2", "3") and "unavailable" in note
+
+
 def test_two_rank_sharding_equals_single_process(tmp_path, oracle):
     """world_size-2 gloo run: shards stepped independently + one counter all-reduce give the same
     trajectories and totals as the single-process batch (env ids are global)."""
