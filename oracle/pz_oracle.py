@@ -17,6 +17,8 @@ import numpy as np
 
 _HERE = Path(__file__).resolve().parent
 _SO = _HERE / "_build" / "libpz_oracle.so"
+if os.environ.get("PZ_ORACLE_SANITIZED") == "1":  # tests: the -fsanitize=address,undefined build (oracle/Makefile: asan)
+    _SO = _HERE / "_build" / "libpz_oracle_asan.so"
 
 W = 44
 OBS = 35
@@ -105,7 +107,8 @@ def build(force: bool = False) -> Path:
     """Compile the C oracle with gcc (no-op when the .so is newer than its sources)."""
     srcs = [_HERE / "pz_oracle.c", _HERE / "pz_oracle.h"]
     if force or not _SO.exists() or any(s.stat().st_mtime > _SO.stat().st_mtime for s in srcs):
-        subprocess.check_call(["make", "-s", "-C", str(_HERE), "-B" if force else "all"],
+        target = "asan" if _SO.name.endswith("_asan.so") else "all"
+        subprocess.check_call(["make", "-s", "-C", str(_HERE)] + (["-B"] if force else []) + [target],
                               stdout=subprocess.DEVNULL)
     return _SO
 

@@ -223,3 +223,50 @@ def test_oracle_matches_reference_single_agent_view(oracle, name):
         assert np.array_equal(obs[me], d["obs"][t]) and np.array_equal(rew[me], d["rew"][t]), (name, t)
         assert np.array_equal(term, d["term"][t]) and np.array_equal(env.state[38:40].T, d["score"][t]), (name, t)
     assert d["term"].sum() > 10
+
+
+_SANITIZED_REPLAY = r'''
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np
+from conftest import golden_state, load_golden, oracle_config_from_meta
+from oracle import pz_oracle as po
+assert po._SO.name == "libpz_oracle_asan.so"
+for name in ("both_computer", "full_wrapper_stack", "serve_random"):
+    d = load_golden(name)
+    meta = d["meta"]
+    env = po.OracleEnv(meta["lanes"], oracle_config_from_meta(meta), nthreads=2)
+    env.reset()
+    for t in range(meta["steps"]):
+        env.step(d["actions"][t, 0], d["actions"][t, 1])
+    assert np.array_equal(env.state, golden_state(d, meta["steps"] - 1)), name
+big = po.OracleEnv(1000 + 37, po.make_config(is_player1_computer=True, is_player2_computer=True, winning_score=2,
+                                              serve="random", seed=5, env_id_base=(1 << 40) + 3, episode_stats=1), nthreads=4)
+big.reset(np.arange(1037) % 2)
+big.rollout_random(9, 0, 400)
+big.observe()
+print("sanitized replay ok", int(big.state[43].sum()))
+'''
+
+
+def test_oracle_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """SURVEY section 5: sanitizers on the CPU build (GPU ASan is not available on the pool).  The oracle compiled with
+    -fsanitize=address,undefined replays fixtures of every branch family (both computer players, all wrappers,
+    random serve) and a ragged multi-threaded batch; any report fails the run."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parent.parent
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not Path(asan).exists():
+        pytest.skip("libasan not available")
+    script = tmp_path / "replay.py"
+    script.write_text(_SANITIZED_REPLAY)
+    env = dict(os.environ, PZ_ORACLE_SANITIZED="1", LD_PRELOAD=asan, OMP_NUM_THREADS="4",
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, str(script), str(repo)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "sanitized replay ok" in r.stdout
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
