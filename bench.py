@@ -432,8 +432,9 @@ def main():
     args = parse_args()
     if int(os.environ.get("RANK", "0")) == 0:
         ensure_built()
-    rank, world, local_rank = dist.init_from_env(args.dist_backend)
-    if os.environ.get("PZ_BENCH_ONE_DEVICE") == "1":
+    one_device = os.environ.get("PZ_BENCH_ONE_DEVICE") == "1"  # rehearsal: every rank on cuda:0 of a 1-GPU box
+    rank, world, local_rank = dist.init_from_env(args.dist_backend, device_index=0 if one_device else None)
+    if one_device:
         local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:

@@ -41,10 +41,11 @@ def weak_shard(n_per_gpu: int, rank: int, world_size: int) -> Shard:
     return Shard(rank, world_size, int(n_per_gpu), rank * int(n_per_gpu), world_size * int(n_per_gpu))
 
 
-def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+def init_from_env(backend: str | None = None, device_index: int | None = None) -> tuple[int, int, int]:
     """Join the process group described by RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun).
 
-    Returns (rank, world_size, local_rank).  Single-process runs (no WORLD_SIZE) skip the group."""
+    Returns (rank, world_size, local_rank).  Single-process runs (no WORLD_SIZE) skip the group.
+    `device_index`: the GPU this rank uses when it is not LOCAL_RANK (rehearsals with several ranks on one GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -57,8 +58,9 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             try:
-                torch.cuda.set_device(local_rank)
-                dev = torch.device("cuda", local_rank)
+                index = local_rank if device_index is None else int(device_index)
+                torch.cuda.set_device(index)
+                dev = torch.device("cuda", index)
                 dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
                 probe = torch.ones(1, dtype=torch.int64, device=dev)  # the communicator works before anything is timed
                 dist.all_reduce(probe)
