@@ -10,6 +10,7 @@ float32 rewards of the fused RewardByBallPosition are bit-exact against the orac
 within 1e-6 of the reference's float64 sum.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -649,7 +650,8 @@ def test_randomized_config_sweep_vs_oracle(oracle):
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     tables_ref = C.byref(flight_tables(dev)[0])
-    for trial in range(40):
+    trials = int(os.environ.get("PZ_SWEEP_TRIALS", "60"))  # a one-off long run is kept under profiles/
+    for trial in range(trials):
         tb = tables_ref if rnd.random() < 0.5 else None  # flight look-up tables or computed predictors
         n = rnd.choice([1, 2, 3, 31, 63, 64, 65, 100, 127, 128, 129, 255, 300, 511, 640, 700])
         stride = n + rnd.choice([0, 0, 1, 7, 64, 130])
@@ -666,8 +668,25 @@ def test_randomized_config_sweep_vs_oracle(oracle):
             k["normal_state_outside"] = False  # "outside" only means something relative to RewardByBallPosition
         ocfg = oracle.make_config(**k)
         cfg = _native.PzConfig.from_buffer_copy(ocfg)  # identical layout (checked by the CPU tests)
+        packed = rnd.random() < 0.5                     # the state in the packed format (36 bytes per game)
+        cfg.packed_state = int(packed)
         ref = oracle.OracleEnv(n, ocfg, nthreads=2)
-        state = torch.full((44, stride), -99, dtype=torch.int32, device=dev)
+        if packed:
+            state = torch.full((36 * stride,), 0xA5, dtype=torch.uint8, device=dev)
+        else:
+            state = torch.full((44, stride), -99, dtype=torch.int32, device=dev)
+
+        def columns():
+            """(int32[44, n] state, nothing past lane n was written)"""
+            if not packed:
+                return cpu(state[:, :n]), bool((state[:, n:] == -99).all())
+            out = torch.full((44, stride), -99, dtype=torch.int32, device=dev)
+            flagged = torch.zeros(1, dtype=torch.int64, device=dev)
+            assert lib.pz_unpack_state(state.data_ptr(), n, stride, out.data_ptr(), stride, flagged.data_ptr(), stream) == 0
+            assert int(flagged.item()) == 0
+            clean = all(bool((part == 0xA5).all()) for part in (
+                state[16 * n:16 * stride], state[16 * stride + 16 * n:32 * stride], state[32 * stride + 4 * n:]))
+            return cpu(out[:, :n]), clean and bool((out[:, n:] == -99).all())
         # episode statistics: double[2][stride] returns + int32[stride] lengths
         stats = torch.zeros(20 * stride, dtype=torch.uint8, device=dev) if k["episode_stats"] else None
         obs = [torch.zeros((n, 35), dtype=torch.int32, device=dev) for _ in range(2)]
@@ -702,9 +721,10 @@ def test_randomized_config_sweep_vs_oracle(oracle):
                     ref.rollout_random(aseed, t, kk)
                     t += kk
             torch.cuda.synchronize()
-            ctx = (trial, phase, mode, n, stride, tb is not None, k)
-            assert np.array_equal(cpu(state[:, :n]), ref.state), ctx
-            assert bool((state[:, n:] == -99).all()), ctx
+            ctx = (trial, phase, mode, n, stride, tb is not None, packed, k)
+            got, untouched = columns()
+            assert np.array_equal(got, ref.state), ctx
+            assert untouched, ctx
             assert np.array_equal(cpu(obs[0]), ref.obs[0].view(np.int32)) and np.array_equal(cpu(obs[1]),
                                                                                            ref.obs[1].view(np.int32)), ctx
             assert np.array_equal(cpu(rew[0]), ref.rew[0].view(np.int32)) and np.array_equal(cpu(rew[1]),
