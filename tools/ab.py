@@ -91,7 +91,10 @@ def main():
     obs = [torch.zeros((n, 35), dtype=torch.int32, device=dev) for _ in range(2)]
     rew = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
     term = torch.zeros(n, dtype=torch.uint8, device=dev)
-    acts = torch.randint(0, 13 if wrappers else 18, (64, 2, n), dtype=torch.int32, device=dev)
+    # --slices N: distinct action slices cycled through (default 64 = 32 MB at 65 536 games, cache-resident; bench.py's
+    # default run streams 2 000 slices = 1 GB cold from HBM)
+    slices = int(args[args.index("--slices") + 1]) if "--slices" in args else 64
+    acts = torch.randint(0, 13 if wrappers else 18, (slices, 2, n), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     base = libs["base"]
     tables = None
@@ -126,7 +129,7 @@ def main():
                 assert rc == 0, rc
             return max(1, steps // rollout) * rollout
         for t in range(steps):
-            a = acts[t % 64]
+            a = acts[t % slices]
             lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
                         obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), None, tb, stream)
         return steps
@@ -150,7 +153,7 @@ def main():
         print(f"  {nm}: trajectory (observations, rewards, terminations) identical to base: {same}")
     # The K launches of a round are captured once per variant in a hipGraph and replayed: an eager ctypes launch
     # costs the host ~7 us, which would hide every kernel faster than that ("--eager" keeps the direct calls).
-    K, rounds = 400, 9
+    K, rounds = max(400, slices), 9
     eager = "--eager" in args
     side = torch.cuda.Stream()
     graphs = {}
