@@ -1,7 +1,7 @@
 /* Diagnostic (not product, not a test): how many loop trips do the device's flight predictors
  * need on states sampled from play, per 64-game wavefront and frame?
  *
- *   gcc -O2 -fopenmp -DPZO_FLIGHT_TRACE -Ioracle -o /tmp/flight_trips tools/flight_trips.c -lm && /tmp/flight_trips
+ *   gcc -O2 -fopenmp -DPZO_FLIGHT_TRACE -Ioracle -o /tmp/flight_trips tests/flight_trips.c -lm && /tmp/flight_trips
  *
  * Plays `waves` x 64 games of config 3 (player 2 = computer, player 1 random) with the oracle, records
  * every predictor call through the PZO_FLIGHT_TRACE hook, and replays the calls through a host model

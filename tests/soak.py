@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Long parity run on the GPU box (diagnostic, beyond the pytest suite): 65 536 games stepped through the single-frame
+"""Long parity run on the GPU box (test infrastructure beyond the pytest suite; not collected by pytest): 65 536 games stepped through the single-frame
 launch (`pz_step`: the pair kernel / scout kernel, actions from HBM) for tens of thousands of frames per
 configuration, full state compared with the CPU oracle every `--every` frames on EVERY lane.
 
-    python tools/soak.py [--frames 20000] [--every 2000] [--n 65536] [--packed]
+    python tests/soak.py [--frames 20000] [--every 2000] [--n 65536] [--packed]
 
 --packed: the same on the packed state format (36 bytes per game); its sticky misfit flags are checked with every unpack.
 Every run also tracks, frame by frame on the device, the extremes of the values the packed format stores in narrow
