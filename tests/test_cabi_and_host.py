@@ -96,6 +96,13 @@ def test_no_cpu_fallback_and_no_oracle_in_product():
     for p in (REPO / "pika-zoo_amd").rglob("*"):
         if p.suffix in (".py", ".hip", ".hpp", ".h", ".cpp"):
             assert "oracle" not in p.read_text().lower().replace("oracle/", "oracle/") or p.name == "never", p
+    # ... and neither may the tuning tools, the examples or the public header: oracle/ is for tests/, smoke() and
+    # bench.py's cpu_baseline / in-run parity leg only
+    for d in ("tools", "examples", "include"):
+        for p in (REPO / d).rglob("*"):
+            if p.suffix in (".py", ".sh", ".c", ".h"):
+                text = p.read_text()
+                assert "pz_oracle" not in text and "from oracle" not in text and "import oracle" not in text, p
 
 
 def test_spaces():
