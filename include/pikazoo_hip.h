@@ -122,7 +122,7 @@ typedef struct pz_config {
  * Every entry point that takes a pz_config reads / writes `state` in the format the config names (so winning_score
  * must be <= 65535 then); pz_observe takes the format as an argument; pz_render reads int32 columns only.  The
  * results are the same bit for bit: pz_unpack_state of a packed run equals the int32 run.  The field widths hold
- * every value play can produce (DESIGN.md section 4.5); pz_pack_state counts the games of a caller-supplied state that
+ * every value play can produce (DESIGN.md section 4.6); pz_pack_state counts the games of a caller-supplied state that
  * do not fit, and a step kernel that ever met a ball y velocity outside +-4095 would raise the game's misfit flag
  * (sticky; counted by pz_unpack_state). */
 #define PZ_PACKED_BYTES_PER_GAME 36

@@ -10,6 +10,9 @@
 //     load -> frame -> store chain plus the write drain, and the split halves the frame;
 //   * k-frame launches and larger batches: one wave per workgroup (step_kernel / step_games);
 //   * a computer player without flight tables: frame wave + scout wave (step_kernel<..., SCOUT>).
+// The state is either those 44 int32 columns (the default) or the packed format of pz_packed.hpp (36 bytes per
+// game in three columns; template parameter PACKED): the frame is the same code, only the loads and stores differ,
+// and the pair kernel then serves every batch size.
 //
 // At these batch sizes a SIMD runs one or two waves, so nothing hides a wave's own instruction latency:
 // the per-wave timeline (tools/stamps.py) is load -> frame -> stores, serialized.  All global

@@ -10,7 +10,7 @@
 // so a step launch reads 32-36 and writes 32-36 bytes of state per game with one 16-byte access per lane and group.
 // Field ranges follow from the rules of play (see each field); pz_pack_state validates states that come from outside,
 // and the step kernels flag (sticky bit 31 of A1 / B1) a ball y velocity that would not fit -- never seen in play,
-// where |y velocity| stays below 150.
+// where |y velocity| stays below 300.
 #pragma once
 
 #include <stdint.h>

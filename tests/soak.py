@@ -34,9 +34,9 @@ def main():
     n = int(args[args.index("--n") + 1]) if "--n" in args else 65536
     fmt = "packed" if "--packed" in args else "int32"
     configs = [
-        ("human_vs_human (pair kernel)", dict(), dict(), None),
-        ("config 3: p2 computer, flight tables (pair kernel)", dict(is_player2_computer=True), dict(is_player2_computer=True), None),
-        ("config 3: p2 computer, computed predictors (scout kernel)", dict(is_player2_computer=True, flight_tables=False),
+        ("human_vs_human", dict(), dict(), None),
+        ("config 3: p2 computer, flight tables", dict(is_player2_computer=True), dict(is_player2_computer=True), None),
+        ("config 3: p2 computer, computed predictors", dict(is_player2_computer=True, flight_tables=False),
          dict(is_player2_computer=True), None),
         ("both computer, random serve, tables", dict(is_player1_computer=True, is_player2_computer=True, serve="random"),
          dict(is_player1_computer=True, is_player2_computer=True, serve="random"), None),
