@@ -1154,10 +1154,6 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     Input in1{0, 0, 0}, in2{0, 0, 0};
     bool ground = false;
     PZ_FRAME_STAMP(0);
-    bool own_bold_pending = false;
-    const uint32_t round_rng = g.e.rng;
-    (void)own_bold_pending;
-    (void)round_rng;
     if (active) {
         if (g.e.round_ended) {  // reset (:149-164) or new round (:176-180); game_ended implies round_ended
             if (g.e.game_ended) {
@@ -1186,23 +1182,8 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
                 own.bold = keep;
                 bold_pending = true;
             } else {
-#ifdef PZ_AI_BOLD_UNDER_GATHER
-                if (kOwnAI) {  // the draw is made under the flight gathers below (the decision is its first reader)
-                    own.x = ROLE == 0 ? 36 : kGroundWidth - 36;
-                    own.y = kPlayerGroundY;
-                    own.yv = 0;
-                    own.coll = 0;
-                    own.state = 0;
-                    own.frame = 0;
-                    own.arm = 1;
-                    own.delay = 0;
-                    own_bold_pending = true;
-                } else
-#endif
-                {
-                    uint32_t own_draw = g.e.rng + (uint32_t)ROLE;
-                    player_new_round(own, ROLE == 0 ? 36 : kGroundWidth - 36, id, own_draw);
-                }
+                uint32_t own_draw = g.e.rng + (uint32_t)ROLE;
+                player_new_round(own, ROLE == 0 ? 36 : kGroundWidth - 36, id, own_draw);
             }
             other.x = ROLE == 0 ? kGroundWidth - 36 : 36;
             other.y = kPlayerGroundY;
@@ -1251,12 +1232,6 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             LandingProbe lp = lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv);
             CandidateProbe cp = lut.candidates_issue(scan && !PZ_ABLATE_SKIP(64), g.b.x, g.b.y, ayv);
             PreDrawn pre = PZ_ABLATE_SKIP(256) ? PreDrawn{1u, 1u, 1u} : predraw3(id, rng_base + draws_other);
-#ifdef PZ_AI_BOLD_UNDER_GATHER
-            if (own_bold_pending) {
-                uint32_t own_draw = round_rng + (uint32_t)ROLE;
-                own.bold = rng_integers(id, own_draw, 5u);
-            }
-#endif
             // Keep the Philox blocks where they are written -- under the two gathers.  Left alone the compiler sinks
             // them below the (rare) out-of-domain branches of the look-ups and waits for the gathers first.  The empty
             // statement reads the draws together with the gathered registers: the draws must be complete before it,
