@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Move the condensed output of one tools/profile.sh run into profiles/ (run here, after gpurun brought it back).
+
+    python tools/install_profile.py TAG [--replace OLDTAG] [--bench gpurun_out/bench_TAG.json] [--extra ...json]
+
+* copies gpurun_out/prof_TAG/out/TAG_* (and the bench lines, as TAG_bench_default[_extra].json) into profiles/;
+* `--replace OLDTAG`: removes profiles/OLDTAG_* (the evidence of an earlier build of the same round);
+* refreshes profiles/traffic.json (measured bytes per launch per workload, read by bench.py) from TAG_pmc_summary.json;
+* prints the figures profiles/README.md and DESIGN.md quote, so that the prose can be checked against them.
+"""
+import csv
+import json
+import shutil
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+PROFILES = REPO / "profiles"
+
+# traffic.json key -> (section prefix of profile.sh, kernel)
+TRAFFIC = {
+    "random_random": ("hh", "pz::step_pair_kernel<false, false, false>"),
+    "cfg3": ("cfg3", "pz::step_pair_kernel<false, true, false>"),
+    "cfg3_compute": ("cfg3c", "pz::step_kernel<false, true, 0, true, 1, false>"),
+    "random_random_524288": ("big", "pz::step_kernel<false, false, 0, true, 0, false>"),
+    "packed_random_random": ("pk", "pz::step_pair_kernel<false, false, true>"),
+    "packed_random_random_524288": ("pkbig", "pz::step_pair_kernel<false, false, true>"),
+}
+
+
+def main():
+    args = sys.argv[1:]
+    tag = args[0]
+    src = REPO / "gpurun_out" / f"prof_{tag}" / "out"
+    if "--replace" in args:
+        old = args[args.index("--replace") + 1]
+        for p in PROFILES.glob(f"{old}_*"):
+            p.unlink()
+    for p in sorted(src.glob(f"{tag}_*")):
+        shutil.copy(p, PROFILES / p.name)
+    for flag, name in (("--bench", "bench_default"), ("--extra", "bench_default_extra")):
+        if flag in args:
+            shutil.copy(args[args.index(flag) + 1], PROFILES / f"{tag}_{name}.json")
+    derived = json.loads((src / f"{tag}_pmc_summary.json").read_text())["derived"]
+    tpath = PROFILES / "traffic.json"
+    traffic = json.loads(tpath.read_text())
+    for key, (prefix, kernel) in TRAFFIC.items():
+        e = derived.get(prefix, {}).get(kernel)
+        if e is None or "hbm_bytes_per_launch" not in e:
+            print(f"  (no counters for {key}: section {prefix} missing)")
+            continue
+        traffic.setdefault(key, {}).update(hbm_bytes_per_launch=e["hbm_bytes_per_launch"],
+                                           fetch_size_kb_raw=e["fetch_size_kb_raw"], write_size_kb=e["write_size_kb"],
+                                           kernel=kernel, round=tag)
+        print(f"  traffic {key}: {e['hbm_bytes_per_launch'] / 1e6:.2f} MB = 2 x {e['fetch_size_kb_raw']:.0f} KB read + "
+              f"{e['write_size_kb']:.0f} KB written")
+    tpath.write_text(json.dumps(traffic, indent=1))
+    for prefix in ("hh", "pk", "cfg3", "cfg3c"):
+        for kernel, e in derived.get(prefix, {}).items():
+            if "valu_insts_per_wave" in e and ("pair" in kernel or ", 0, true, 1" in kernel):
+                print(f"  {prefix} {kernel}: VALU/wave {e['valu_insts_per_wave']:.0f}, active lanes "
+                      f"{e.get('valu_active_lane_share', 0):.2f}, VALU issue {e.get('valu_issue_share_of_wave_cycles', 0):.3f}, "
+                      f"waiting {e.get('sq_wait_any_share', 0):.2f}, waves/busy cycle "
+                      f"{e.get('avg_waves_resident_per_busy_SQ_cycle', 0):.1f}")
+    for name in ("kt", "big_kt", "pkbig_kt", "roll"):
+        p = src / f"{tag}_{name}_step_kernels_by_grid.csv"
+        if p.exists():
+            for row in csv.DictReader(p.open()):
+                if int(row["Calls"]) >= 50:
+                    print(f"  {name}: {row['Kernel']} games {row['Games']}: avg {float(row['AverageNs']) / 1e3:.2f} us "
+                          f"({row['Calls']} calls)")
+    for flag in ("--bench", "--extra"):
+        if flag in args:
+            d = json.loads(Path(args[args.index(flag) + 1]).read_text())
+            if flag == "--bench":
+                r = d["roofline"]
+                print(f"  bench: build {d['build_id']}: {d['value'] / 1e9:.2f} G, {r['launch_us']:.2f} us, frac {r['frac']:.3f}, "
+                      f"frac_wall {r['frac_wall']:.3f}, frac_traffic {r['frac_traffic']}, cpu {d['cpu_baseline']['value'] / 1e6:.0f} M")
+                for k, v in d.get("configs", {}).items():
+                    print(f"    {k}: {v['value'] / 1e9:.2f} G, {v['launch_us']:.2f} us, frac {v['frac']:.3f}, "
+                          f"parity {v.get('parity_bit_exact')}")
+            else:
+                for k, v in d.get("extra", {}).items():
+                    if isinstance(v, dict) and "us_per_frame" in v:
+                        print(f"    {k}: {v['us_per_frame']:.2f} us/frame, {v['value'] / 1e9:.2f} G")
+                    elif isinstance(v, dict) and "us_per_step" in v:
+                        print(f"    {k}: {v['us_per_step']:.2f} us/step, {v['value'] / 1e9:.2f} G")
+                    elif isinstance(v, dict) and "launch_us" in v:
+                        print(f"    {k}: {v['launch_us']:.2f} us")
+                    elif isinstance(v, dict):
+                        for kk, vv in v.items():
+                            print(f"    {k} {kk}: {vv['launch_us']:.2f} us, frac {vv['frac_of_8TBps']:.3f}")
+
+
+if __name__ == "__main__":
+    main()
