@@ -81,6 +81,62 @@ def main():
                 main_s.synchronize()
                 times.append(e0.elapsed_time(e1) * 1e3 / (4 * K))
         results[chains] = (statistics.median(times), min(times))
+    if "--separate" in args:
+        # the same sub-batch chains as SEPARATE hipGraphs, one per stream (different priorities = different hardware
+        # queues), replayed side by side from this one thread
+        for chains in (2, 4):
+            env = pikazoo_v0.env(num_envs=n, device=dev, seed=0, validate_actions=False, is_player2_computer=ai)
+            env.reset()
+            env.step_random(2, t0=0, k=1024)
+            acts = torch.empty((K, 2, n), dtype=torch.int32, device=dev)
+            for t in range(K):
+                a = env.random_actions(1, t)
+                acts[t, 0].copy_(a["player_1"]); acts[t, 1].copy_(a["player_2"])
+            torch.cuda.synchronize()
+            sub = n // chains
+            streams = [torch.cuda.Stream(device=dev, priority=-(c % 2)) for c in range(chains)]
+            cfgs, graphs = [], []
+            for c in range(chains):
+                lo = c * sub
+                cfg = _native.PzConfig.from_buffer_copy(env._cfg)
+                cfg.env_id_base = env.env_id_base + lo
+                cfgs.append(cfg)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(streams[c]):
+                    with torch.cuda.graph(g, stream=streams[c], capture_error_mode="thread_local"):
+                        cur = torch.cuda.current_stream(dev)
+                        for t in range(K):
+                            rc = lib.pz_step(env.state.data_ptr() + 4 * lo, sub, env._stride, C.byref(cfg),
+                                             acts[t, 0].data_ptr() + 4 * lo, acts[t, 1].data_ptr() + 4 * lo,
+                                             env._obs[0].data_ptr() + 140 * lo, env._obs[1].data_ptr() + 140 * lo,
+                                             env._rew_raw[0].data_ptr() + 4 * lo, env._rew_raw[1].data_ptr() + 4 * lo,
+                                             env._term_u8.data_ptr() + lo, None, env._tables_ref, cur.cuda_stream)
+                            assert rc == 0, rc
+                graphs.append(g)
+            for c in range(chains):
+                with torch.cuda.stream(streams[c]):
+                    graphs[c].replay()
+            torch.cuda.synchronize()
+            same = torch.equal(env.state, final[1])
+            times = []
+            for _ in range(7):
+                torch.cuda.synchronize()
+                e0 = torch.cuda.Event(enable_timing=True)
+                ends = [torch.cuda.Event(enable_timing=True) for _ in range(chains)]
+                e0.record(streams[0])
+                for c in range(1, chains):
+                    streams[c].wait_event(e0)
+                for _ in range(4):
+                    for c in range(chains):
+                        with torch.cuda.stream(streams[c]):
+                            graphs[c].replay()
+                for c in range(chains):
+                    ends[c].record(streams[c])
+                torch.cuda.synchronize()
+                times.append(max(e0.elapsed_time(e) for e in ends) * 1e3 / (4 * K))
+            med = statistics.median(times)
+            print(f"n={n} ai={ai} {chains} separate graphs on {chains} streams: {med:.3f} us per step (min {min(times):.3f}) -> "
+                  f"{n / med / 1e3:.2f} G env-steps/s; same trajectory as one chain: {same}")
     for c, (med, mn) in results.items():
         print(f"n={n} ai={ai} chains={c}: {med:.3f} us per step (min {mn:.3f})  -> {n / med / 1e3:.2f} G env-steps/s; "
               f"same trajectory as one chain: {torch.equal(final[c], final[1])}")
