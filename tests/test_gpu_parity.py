@@ -861,12 +861,13 @@ def test_flight_tables_hold_the_iterative_predictors(oracle):
                                                                    int(Yh[j]), 0, int(A[j]))
 
 
-def test_ball_states_outside_the_tables_take_the_computed_path(oracle):
+@pytest.mark.parametrize("fmt", ["int32", "packed"])
+def test_ball_states_outside_the_tables_take_the_computed_path(fmt, oracle):
     """A ball faster than the tables' domain (|y velocity| > 96 resp. 64) or with an x velocity they do not list is
     predicted in the kernel: plant such states and compare the next frames with the oracle."""
     n = 4096
     kw = dict(is_player1_computer=True, is_player2_computer=True, winning_score=3)
-    env = make_env(num_envs=n, seed=3, env_id_base=50, **kw)
+    env = make_env(num_envs=n, seed=3, env_id_base=50, state_format=fmt, **kw)
     raw = env.unwrapped
     ref = oracle.OracleEnv(n, oracle.make_config(seed=3, env_id_base=50, **kw), nthreads=8)
     env.reset(), ref.reset()
@@ -880,7 +881,7 @@ def test_ball_states_outside_the_tables_take_the_computed_path(oracle):
     st[1, ::2] = 200
     st[26, ::2] = st[0, ::2] + 10
     st[27, ::2] = 190
-    raw.state.copy_(st.to(raw.device))
+    raw.set_state(st.to(raw.device))
     ref.state[:] = st.numpy()
     for t in range(40, 70):
         acts = raw.random_actions(5, t)

@@ -44,7 +44,7 @@ def test_frames_match_the_numpy_oracle():
     st[39, :64] = 15 - torch.arange(64, device=st.device, dtype=torch.int32) % 16
     st[26, :32], st[27, :32] = 432, 0
     st[35, 32:64] = 50
-    env.state.copy_(st)
+    env.set_state(st)
     lanes = torch.arange(0, 64, 3, device="cuda:0")
     frames = env.render(lanes=lanes)
     assert frames.shape[0] == lanes.numel()
