@@ -106,25 +106,28 @@ typedef struct pz_config {
 /* ---- the packed state format (cfg->packed_state = 1) -----------------------------------------------
  * SURVEY section 8(f)-3 "int16 / bit-packed state".  The same 44 values in 36 bytes per game, three columns
  * (structure of arrays, game i at element i of each):
- *   group A  uint32[4][..] at byte 0            player 1, env block, ball.punch_effect_x
- *   group B  uint32[4][..] at byte 16 * stride  player 2, the ball
+ *   group A  uint32[4][..] at byte 0            player 1, env block, ball.punch_effect_x, ball.previous_previous_y
+ *   group B  uint32[4][..] at byte 16 * stride  player 2, the rest of the ball
  *   tail     uint32[..]    at byte 32 * stride  expected_landing_point_x (uint16) | computer_boldness of player 1,
  *                                               player 2 (uint8 each)
  * i.e. a buffer of pz_packed_state_bytes(stride) = 36 * stride bytes, 16-byte aligned.  Field layout:
  *   A0 / B0  x 9 | y 8 <<9 | y_velocity+32 6 <<17 | state 3 <<23 | frame_number 3 <<26 | delay_before_next_frame 3 <<29
  *   A1 / B1  bits 0-8: arm_swing_direction==1 | diving_direction+1 2 <<1 | lying_down_duration_left+2 3 <<3 |
  *            is_collision_with_ball_happened <<6 | computer_where_to_stand_by <<7 | power_hit_key_is_down_previous <<8
- *   A1       | punch_effect_x 9 <<9 | is_player2_serve <<18 | round_ended <<19 | game_ended <<20 | misfit flag <<31
+ *   A1       | punch_effect_x 9 <<9 | is_player2_serve <<18 | round_ended <<19 | game_ended <<20 |
+ *            previous_previous_y 10 signed <<21 | misfit flag <<31
  *   A2       score_p1 16 | score_p2 16 <<16          A3   rng draw counter
  *   B1       | is_power_hit <<9 | x_velocity+32 6 <<10 | y_velocity 13 signed <<16 | misfit flag <<31
  *   B2       x 9 | previous_x 9 <<9 | previous_previous_x 9 <<18
- *   B3       y 8 | previous_y 8 <<8 | previous_previous_y 8 <<16 | fine_rotation 6 <<24
+ *   B3       y 10 signed | previous_y 10 signed <<10 | fine_rotation 6 <<20
+ *            (the ball's y is signed: a ball falling onto the net top faster than its height is bounced to
+ *            y - y_velocity < 0, physics.py:406-419 -- the ceiling is tested before the net)
  * Every entry point that takes a pz_config reads / writes `state` in the format the config names (so winning_score
  * must be <= 65535 then); pz_observe takes the format as an argument; pz_render reads int32 columns only.  The
  * results are the same bit for bit: pz_unpack_state of a packed run equals the int32 run.  The field widths hold
  * every value play can produce; pz_pack_state counts the games of a caller-supplied state that
- * do not fit, and a step kernel that ever met a ball y velocity outside +-4095 would raise the game's misfit flag
- * (sticky; counted by pz_unpack_state). */
+ * do not fit, and a step kernel that ever met a ball y velocity outside +-4095 or a ball y outside -512..511 would
+ * raise the game's misfit flag (sticky; counted by pz_unpack_state). */
 #define PZ_PACKED_BYTES_PER_GAME 36
 int64_t pz_packed_state_bytes(int64_t stride);
 /* int32 columns -> packed; *misfits (int64, device, may be NULL) += games with a value outside its field */

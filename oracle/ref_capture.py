@@ -547,6 +547,48 @@ def capture_render(name: str, steps: int, periods, seed: int, action_seed: int, 
         background=np.asarray(static, np.int16), meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
 
 
+def capture_planted(name: str, seed: int, action_seed: int, env_id_base: int, env_kwargs: dict, frames: int = 16) -> dict:
+    """Corners random play practically never reaches: one reference env per planted ball state (very fast balls over
+    the net top / at the walls / at the ceiling, in both directions), stepped `frames` frames under the random policy.
+    The planted values are written into the reference's own ball attributes after 30 frames of normal play; recorded
+    like the trajectory fixtures (state words after every step)."""
+    cases = []
+    for x in (20, 194, 216, 238, 432):
+        for y in (0, 100, 177, 190, 192, 193, 252):
+            for xv, yv in ((13, 200), (-20, 177), (7, -250), (0, 292), (20, 60), (-10, -96), (1, 1)):
+                cases.append((x, y, xv, yv))
+    lanes = len(cases)
+    envs = [make_reference_env(seed, env_id_base + i, None, **env_kwargs) for i in range(lanes)]
+    for env, raw, shim in envs:
+        env.reset()
+    warm = 30
+    for t in range(warm):
+        a1, a2 = po.random_actions(lanes, env_id_base, action_seed, t, 18)
+        for i, (env, raw, shim) in enumerate(envs):
+            env.step({"player_1": int(a1[i]), "player_2": int(a2[i])})
+    for (x, y, xv, yv), (env, raw, shim) in zip(cases, envs):
+        b = raw.physics.ball
+        b.x, b.y, b.x_velocity, b.y_velocity = x, y, xv, yv
+    planted = np.stack([extract_state(raw, shim) for _, raw, shim in envs], axis=1).astype(np.int32)
+    states = np.zeros((frames, po.W, lanes), np.int32)
+    for t in range(frames):
+        a1, a2 = po.random_actions(lanes, env_id_base, action_seed, warm + t, 18)
+        for i, (env, raw, shim) in enumerate(envs):
+            if not raw.agents:
+                env.reset()
+            env.step({"player_1": int(a1[i]), "player_2": int(a2[i])})
+            states[t, :, i] = extract_state(raw, shim)
+    meta = dict(name=name, lanes=lanes, frames=frames, warm=warm, seed=seed, action_seed=action_seed,
+                env_id_base=env_id_base, env_kwargs=env_kwargs, cases=cases, fields=po.FIELD_NAMES)
+    return dict(planted=planted, states=states, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+
+
+PLANTED_RUNS = [
+    ("planted_fast_balls_human", dict(winning_score=15)),
+    ("planted_fast_balls_both_computer", dict(winning_score=15, is_player1_computer=True, is_player2_computer=True)),
+]
+
+
 RENDER_RUNS = [
     # name, steps, render periods per lane, env kwargs
     ("render_human_human", 1500, (1, 2, 3, 7, 25, 40), dict(winning_score=15)),
@@ -639,6 +681,13 @@ def main(argv=None):
         np.savez_compressed(GOLDEN / f"{name}.npz", **data)
         print(f"{name}: {lanes}x{steps} terminations={int(data['term'].sum())} "
               f"{(GOLDEN / (name + '.npz')).stat().st_size / 1e3:.0f} kB")
+    for k, (name, kw) in enumerate(PLANTED_RUNS):
+        if args.only and args.only != name:
+            continue
+        data = capture_planted(name, seed=8080 + k, action_seed=51 + k, env_id_base=12000 + 1000 * k, env_kwargs=kw)
+        np.savez_compressed(GOLDEN / f"{name}.npz", **data)
+        print(f"{name}: {data['planted'].shape[1]} planted states x {data['states'].shape[0]} frames, min ball y "
+              f"{int(data['states'][:, 27].min())} {(GOLDEN / (name + '.npz')).stat().st_size / 1e3:.0f} kB")
     for k, (name, steps, periods, kw) in enumerate(RENDER_RUNS):
         if args.only and args.only != name:
             continue

@@ -42,8 +42,8 @@ def _unpack(packed, n, pstride, stride):
 # field ranges of the packed format (include/pikazoo_hip.h), per state row: (low, high) inclusive
 _PLAYER_RANGES = [(0, 511), (0, 255), (-32, 31), (0, 7), (0, 7), None, (0, 7), (-1, 1), (-2, 5), (0, 1), (0, 255), (0, 1),
                   (0, 1)]
-_BALL_RANGES = [(0, 511), (0, 255), (-32, 31), (-4096, 4095), (0, 1), (0, 511), (0, 255), (0, 511), (0, 255), (0, 63),
-                (0, 65535), (0, 511)]
+_BALL_RANGES = [(0, 511), (-512, 511), (-32, 31), (-4096, 4095), (0, 1), (0, 511), (-512, 511), (0, 511), (-512, 511),
+                (0, 63), (0, 65535), (0, 511)]
 _ENV_RANGES = [(0, 65535), (0, 65535), (0, 1), (0, 1), (0, 1), None]
 
 
@@ -95,14 +95,16 @@ def test_pack_counts_states_that_do_not_fit_and_the_flag_survives():
     bad = state.clone()
     bad[29, 7] = 5000      # ball y velocity beyond the 13-bit field
     bad[0, 9] = -3         # player 1 x negative
+    bad[27, 200] = -600    # ball y below the 10-bit signed field
+    bad[34, 201] = 700     # previous_previous_y above it
     bad[38, 100] = 70000   # score beyond 16 bits
     bad[5, 11] = 0         # arm_swing_direction is +-1
     packed, misfits = _pack(bad, 256, 256, 256)
-    assert misfits == 4
+    assert misfits == 6
     back, flagged = _unpack(packed, 256, 256, 256)
-    assert flagged == 4
+    assert flagged == 6
     good = torch.ones(256, dtype=torch.bool, device=dev)
-    good[[7, 9, 100, 11]] = False
+    good[[7, 9, 100, 11, 200, 201]] = False
     assert torch.equal(back[:, good], state[:, good])
     # the Python host refuses both directions
     penv = make_env(num_envs=256, seed=1, state_format="packed")
@@ -306,3 +308,32 @@ def test_packed_render_and_scalar_api():
         obs, rew, term, trunc, infos = env.step({a: env.action_space(a).sample() for a in env.agents})
         steps += 1
     assert term["player_1"] is True and sorted(infos["player_1"]["score"]) == [0, 1] and steps > 10
+
+
+@pytest.mark.parametrize("name,fmt,tables", [("planted_fast_balls_human", "int32", True),
+                                             ("planted_fast_balls_human", "packed", True),
+                                             ("planted_fast_balls_both_computer", "int32", True),
+                                             ("planted_fast_balls_both_computer", "int32", False),
+                                             ("planted_fast_balls_both_computer", "packed", True),
+                                             ("planted_fast_balls_both_computer", "packed", False)])
+def test_planted_fast_balls_follow_the_reference(name, fmt, tables):
+    """The reference stepped from planted ball states random play never reaches (oracle/ref_capture.capture_planted):
+    among them balls bounced off the net top to a negative y -- the ball's y and its trail are signed quantities, in
+    the int32 columns and in the packed format's 10-bit fields alike."""
+    from conftest import load_golden
+    from test_oracle_golden import replay_planted
+
+    d = load_golden(name)
+
+    def make(meta, planted):
+        env = make_env(num_envs=meta["lanes"], seed=meta["seed"], env_id_base=meta["env_id_base"], state_format=fmt,
+                       flight_tables=tables, **meta["env_kwargs"])
+        raw = env.unwrapped
+        raw.set_state(torch.as_tensor(planted, device=raw.device))
+
+        def step(a1, a2):
+            env.step({"player_1": torch.as_tensor(a1, device=raw.device), "player_2": torch.as_tensor(a2, device=raw.device)})
+            return cpu(raw.state)
+        return step
+
+    replay_planted(d, make)

@@ -883,8 +883,14 @@ def test_ball_states_outside_the_tables_take_the_computed_path(fmt, oracle):
     st[27, ::2] = 190
     raw.set_state(st.to(raw.device))
     ref.state[:] = st.numpy()
+    negative_y = 0
     for t in range(40, 70):
         acts = raw.random_actions(5, t)
-        env.step(acts)
-        ref.step(cpu(acts["player_1"]), cpu(acts["player_2"]))
+        obs = env.step(acts)[0]
+        robs = ref.step(cpu(acts["player_1"]), cpu(acts["player_2"]))[0]
         assert np.array_equal(cpu(raw.state), ref.state), t
+        assert np.array_equal(cpu(obs["player_1"]), robs[0]), t
+        negative_y += int((ref.state[27] < 0).sum())
+    # the planted fast balls over the net top are bounced to y - y_velocity < 0 (physics.py:406-419: the ceiling is
+    # tested before the net): the reference's ball y is a signed quantity, and so are its copies in the trail
+    assert negative_y > 0 and int(ref.state[32].min()) < 0 and int(ref.state[34].min()) < 0

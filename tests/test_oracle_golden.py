@@ -270,3 +270,47 @@ def test_oracle_under_address_and_undefined_behaviour_sanitizers(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     assert "sanitized replay ok" in r.stdout
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+
+
+PLANTED_FIXTURES = ["planted_fast_balls_human", "planted_fast_balls_both_computer"]
+
+
+def replay_planted(d, make_stepper):
+    """Planted-state fixtures (oracle/ref_capture.capture_planted): `make_stepper(meta, planted_state)` returns
+    step(a1, a2) -> int32[44, lanes] state; every frame is compared with the reference's."""
+    from oracle import pz_oracle as po
+
+    meta = d["meta"]
+    step = make_stepper(meta, d["planted"])
+    for t in range(meta["frames"]):
+        a1, a2 = po.random_actions(meta["lanes"], meta["env_id_base"], meta["action_seed"], meta["warm"] + t, 18)
+        got = step(a1, a2)
+        want = d["states"][t]
+        if not np.array_equal(got, want):
+            f, l = np.argwhere(got != want)[0]
+            pytest.fail(f"frame {t} lane {l} (planted ball {meta['cases'][l]}) word {po.FIELD_NAMES[f]}: "
+                        f"{got[f, l]} != reference {want[f, l]}")
+
+
+@pytest.mark.parametrize("name", PLANTED_FIXTURES)
+def test_oracle_matches_reference_on_planted_fast_balls(name, oracle):
+    """Ball states random play practically never reaches, written into the reference's own ball and stepped by it: balls
+    faster than the court is high over the net top (bounced to a NEGATIVE y: the ceiling is tested before the net,
+    physics.py:406-419), at the walls, at the ceiling, with and without computer players (their flight predictions
+    start from those states)."""
+    d = load_golden(name)
+    assert int(d["states"][:, 27].min()) < 0  # the corner is in the fixture
+
+    def make(meta, planted):
+        kw = meta["env_kwargs"]
+        env = oracle.OracleEnv(meta["lanes"], oracle.make_config(
+            winning_score=kw.get("winning_score", 15), is_player1_computer=kw.get("is_player1_computer", False),
+            is_player2_computer=kw.get("is_player2_computer", False), seed=meta["seed"], env_id_base=meta["env_id_base"]))
+        env.state[:] = planted
+
+        def step(a1, a2):
+            env.step(a1, a2)
+            return env.state
+        return step
+
+    replay_planted(d, make)
