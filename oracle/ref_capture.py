@@ -583,6 +583,62 @@ def capture_planted(name: str, seed: int, action_seed: int, env_id_base: int, en
     return dict(planted=planted, states=states, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
 
 
+def capture_planted_random(name: str, lanes: int, seed: int, action_seed: int, env_id_base: int, env_kwargs: dict,
+                           frames: int = 12, plant_seed: int = 123) -> dict:
+    """The same with every attribute of both players, the ball and the scores drawn at random over its whole valid
+    range (reachable or not: the reference's code is defined for all of them), half of the balls next to a player."""
+    rng = np.random.default_rng(plant_seed)
+    envs = [make_reference_env(seed, env_id_base + i, None, **env_kwargs) for i in range(lanes)]
+    for env, raw, shim in envs:
+        env.reset()
+        for pl, lo, hi in ((raw.physics.player1, 32, 184), (raw.physics.player2, 248, 400)):
+            pl.x = int(rng.integers(lo, hi + 1))
+            pl.state = int(rng.integers(0, 5))
+            pl.y = 244 if pl.state in (0, 4) and rng.random() < 0.7 else int(rng.integers(108, 245))
+            pl.y_velocity = int(rng.integers(-16, 17))
+            pl.frame_number = int(rng.integers(0, 5))
+            pl.normal_status_arm_swing_direction = int(rng.choice([-1, 1]))
+            pl.delay_before_next_frame = int(rng.integers(0, 6))
+            pl.diving_direction = int(rng.integers(-1, 2))
+            pl.lying_down_duration_left = int(rng.integers(-1, 4))
+            pl.is_collision_with_ball_happened = bool(rng.integers(0, 2))
+            pl.computer_boldness = int(rng.integers(0, 5))
+            pl.computer_where_to_stand_by = int(rng.integers(0, 2))
+        b = raw.physics.ball
+        near = rng.random() < 0.5
+        p = raw.physics.player1 if rng.random() < 0.5 else raw.physics.player2
+        b.x = int(np.clip(p.x + rng.integers(-40, 41), 20, 432)) if near else int(rng.integers(20, 433))
+        b.y = int(np.clip(p.y + rng.integers(-40, 41), 0, 252)) if near else int(rng.integers(0, 253))
+        b.x_velocity = int(rng.integers(-20, 21))
+        b.y_velocity = int(rng.integers(-120, 121) if rng.random() < 0.8 else rng.integers(-300, 301))
+        b.is_power_hit = bool(rng.integers(0, 2))
+        b.fine_rotation = int(rng.integers(0, 51))
+        b.rotation = b.fine_rotation // 10
+        for kb in raw.keyboard_array:
+            kb.power_hit_key_is_down_previous = bool(rng.integers(0, 2))
+        top = env_kwargs.get("winning_score", 15)
+        raw.scores = [int(rng.integers(0, top)), int(rng.integers(0, top))]
+    planted = np.stack([extract_state(raw, shim) for _, raw, shim in envs], axis=1).astype(np.int32)
+    states = np.zeros((frames, po.W, lanes), np.int32)
+    for t in range(frames):
+        a1, a2 = po.random_actions(lanes, env_id_base, action_seed, t, 18)
+        for i, (env, raw, shim) in enumerate(envs):
+            if not raw.agents:
+                env.reset()
+            env.step({"player_1": int(a1[i]), "player_2": int(a2[i])})
+            states[t, :, i] = extract_state(raw, shim)
+    meta = dict(name=name, lanes=lanes, frames=frames, warm=0, seed=seed, action_seed=action_seed,
+                env_id_base=env_id_base, env_kwargs=env_kwargs, cases=[[] for _ in range(lanes)], fields=po.FIELD_NAMES)
+    return dict(planted=planted, states=states, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+
+
+PLANTED_RANDOM_RUNS = [
+    ("planted_random_states_human", dict(winning_score=3)),
+    ("planted_random_states_both_computer", dict(winning_score=3, is_player1_computer=True, is_player2_computer=True)),
+    ("planted_random_states_p2_computer_random_serve", dict(winning_score=2, is_player2_computer=True, serve="random")),
+]
+
+
 PLANTED_RUNS = [
     ("planted_fast_balls_human", dict(winning_score=15)),
     ("planted_fast_balls_both_computer", dict(winning_score=15, is_player1_computer=True, is_player2_computer=True)),
@@ -688,6 +744,14 @@ def main(argv=None):
         np.savez_compressed(GOLDEN / f"{name}.npz", **data)
         print(f"{name}: {data['planted'].shape[1]} planted states x {data['states'].shape[0]} frames, min ball y "
               f"{int(data['states'][:, 27].min())} {(GOLDEN / (name + '.npz')).stat().st_size / 1e3:.0f} kB")
+    for k, (name, kw) in enumerate(PLANTED_RANDOM_RUNS):
+        if args.only and args.only != name:
+            continue
+        data = capture_planted_random(name, 800, seed=9090 + k, action_seed=61 + k, env_id_base=20000 + 1000 * k,
+                                      env_kwargs=kw, plant_seed=321 + k)
+        np.savez_compressed(GOLDEN / f"{name}.npz", **data)
+        print(f"{name}: {data['planted'].shape[1]} planted states x {data['states'].shape[0]} frames "
+              f"{(GOLDEN / (name + '.npz')).stat().st_size / 1e3:.0f} kB")
     for k, (name, steps, periods, kw) in enumerate(RENDER_RUNS):
         if args.only and args.only != name:
             continue

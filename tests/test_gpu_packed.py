@@ -320,6 +320,23 @@ def test_planted_fast_balls_follow_the_reference(name, fmt, tables):
     """The reference stepped from planted ball states random play never reaches (oracle/ref_capture.capture_planted):
     among them balls bounced off the net top to a negative y -- the ball's y and its trail are signed quantities, in
     the int32 columns and in the packed format's 10-bit fields alike."""
+    _replay_planted_through_hip(name, fmt, tables)
+
+
+@pytest.mark.parametrize("fmt,tables", [("int32", True), ("int32", False), ("packed", True), ("packed", False)])
+@pytest.mark.parametrize("name", ["planted_random_states_human", "planted_random_states_both_computer",
+                                  "planted_random_states_p2_computer_random_serve"])
+def test_random_planted_states_follow_the_reference(name, fmt, tables):
+    """Every attribute of both players, the ball and the scores at random over its whole valid range, planted into the
+    reference and stepped by it (oracle/ref_capture.capture_planted_random): the HIP path in both state formats, with
+    and without the flight tables, reproduces every word of every frame."""
+    if not tables and "human" in name:
+        pytest.skip("no computer player: the tables are never consulted")
+    _replay_planted_through_hip(name, fmt, tables)
+
+
+def _replay_planted_through_hip(name, fmt, tables):
+    """A planted-state fixture through the product: set_state(planted), then every frame against the reference's."""
     from conftest import load_golden
     from test_oracle_golden import replay_planted
 

@@ -273,6 +273,9 @@ def test_oracle_under_address_and_undefined_behaviour_sanitizers(tmp_path):
 
 
 PLANTED_FIXTURES = ["planted_fast_balls_human", "planted_fast_balls_both_computer"]
+# every attribute of players / ball / scores at random over its whole valid range (capture_planted_random)
+PLANTED_RANDOM_FIXTURES = ["planted_random_states_human", "planted_random_states_both_computer",
+                           "planted_random_states_p2_computer_random_serve"]
 
 
 def replay_planted(d, make_stepper):
@@ -292,19 +295,21 @@ def replay_planted(d, make_stepper):
                         f"{got[f, l]} != reference {want[f, l]}")
 
 
-@pytest.mark.parametrize("name", PLANTED_FIXTURES)
+@pytest.mark.parametrize("name", PLANTED_FIXTURES + PLANTED_RANDOM_FIXTURES)
 def test_oracle_matches_reference_on_planted_fast_balls(name, oracle):
     """Ball states random play practically never reaches, written into the reference's own ball and stepped by it: balls
     faster than the court is high over the net top (bounced to a NEGATIVE y: the ceiling is tested before the net,
     physics.py:406-419), at the walls, at the ceiling, with and without computer players (their flight predictions
     start from those states)."""
     d = load_golden(name)
-    assert int(d["states"][:, 27].min()) < 0  # the corner is in the fixture
+    if name in PLANTED_FIXTURES:
+        assert int(d["states"][:, 27].min()) < 0  # the corner is in the fixture
 
     def make(meta, planted):
         kw = meta["env_kwargs"]
         env = oracle.OracleEnv(meta["lanes"], oracle.make_config(
-            winning_score=kw.get("winning_score", 15), is_player1_computer=kw.get("is_player1_computer", False),
+            winning_score=kw.get("winning_score", 15), serve=kw.get("serve", "winner"),
+            is_player1_computer=kw.get("is_player1_computer", False),
             is_player2_computer=kw.get("is_player2_computer", False), seed=meta["seed"], env_id_base=meta["env_id_base"]))
         env.state[:] = planted
 
