@@ -594,8 +594,17 @@ def capture_planted_random(name: str, lanes: int, seed: int, action_seed: int, e
         for pl, lo, hi in ((raw.physics.player1, 32, 184), (raw.physics.player2, 248, 400)):
             pl.x = int(rng.integers(lo, hi + 1))
             pl.state = int(rng.integers(0, 5))
-            pl.y = 244 if pl.state in (0, 4) and rng.random() < 0.7 else int(rng.integers(108, 245))
-            pl.y_velocity = int(rng.integers(-16, 17))
+            # (y, y_velocity) from the pairs a jump or a dive passes through: a player's y is the one attribute a frame
+            # moves without clamping, so an unreachable pair could leave the court
+            if pl.state in (0, 4) and rng.random() < 0.7:
+                pl.y, pl.y_velocity = 244, 0
+            else:
+                y, v = 244, (-16 if rng.random() < 0.7 else -5)
+                for _ in range(int(rng.integers(0, 33))):
+                    if y + v > 244:
+                        break
+                    y, v = y + v, v + 1
+                pl.y, pl.y_velocity = y, v
             pl.frame_number = int(rng.integers(0, 5))
             pl.normal_status_arm_swing_direction = int(rng.choice([-1, 1]))
             pl.delay_before_next_frame = int(rng.integers(0, 6))

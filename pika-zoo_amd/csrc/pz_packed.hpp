@@ -10,7 +10,8 @@
 // so a step launch reads 32-36 and writes 32-36 bytes of state per game with one 16-byte access per lane and group.
 // Field ranges follow from the rules of play (see each field); pz_pack_state validates states that come from outside,
 // and the step kernels flag (sticky bit 31 of A1 / B1) a ball y velocity or ball y that would not fit -- never seen in
-// play, where |y velocity| stays below 300.  The ball's y is SIGNED: a ball that falls onto the
+// play, where |y velocity| stays below 300 -- and likewise a player's y / y velocity, which only a
+// planted, unreachable state can drive out of the court.  The ball's y is SIGNED: a ball that falls onto the
 // net top faster than its height is bounced to y - y_velocity < 0 (physics.py:406-419: the ceiling is tested before
 // the net), so y and its two trail copies are 10-bit signed fields.
 #pragma once
@@ -62,6 +63,13 @@ __device__ __forceinline__ void unpack_player_misc(Player& p, uint32_t w)
     p.hitprev = (int)((w >> 8) & 1u);
 }
 
+// The two player fields that a frame moves without clamping them (a planted, unreachable (y, y_velocity) pair can leave
+// the court's y range): checked with every pack, like the ball's y and y velocity.
+__device__ __forceinline__ uint32_t player_overflow(const Player& p)
+{
+    return ((unsigned)p.y < 256u && (unsigned)(p.yv + 32) < 64u) ? 0u : kPackedOverflowBit;
+}
+
 // group A: {player 1 core, player 1 misc | punch_effect_x 9 <<9 | is_player2_serve <<18 | round_ended <<19 |
 //           game_ended <<20 | previous_previous_y 10 (signed) <<21 | overflow <<31, score 1 16 | score 2 16 <<16,
 //           rng draw counter}
@@ -71,7 +79,7 @@ __device__ __forceinline__ pk_u32x4 pack_group_a(const Game& g, uint32_t sticky)
     w.x = pack_player_core(g.p1);
     w.y = pack_player_misc(g.p1) | ((uint32_t)g.b.punch << 9) | ((uint32_t)(g.e.p2serve != 0) << 18) |
           ((uint32_t)(g.e.round_ended != 0) << 19) | ((uint32_t)(g.e.game_ended != 0) << 20) |
-          (((uint32_t)g.b.ppy & 0x3FFu) << 21) | sticky;
+          (((uint32_t)g.b.ppy & 0x3FFu) << 21) | sticky | player_overflow(g.p1);
     w.z = (uint32_t)g.e.s1 | ((uint32_t)g.e.s2 << 16);
     w.w = g.e.rng;
     return w;
@@ -100,7 +108,7 @@ __device__ __forceinline__ pk_u32x4 pack_group_b(const Game& g, uint32_t sticky)
     w.x = pack_player_core(g.p2);
     const bool fits = (unsigned)(g.b.yv + kPackedBallYvMax + 1) <= (unsigned)(2 * kPackedBallYvMax + 1) &&
                       (unsigned)(g.b.y + kPackedBallYMax + 1) <= (unsigned)(2 * kPackedBallYMax + 1);
-    const uint32_t over = fits ? 0u : kPackedOverflowBit;
+    const uint32_t over = (fits ? 0u : kPackedOverflowBit) | player_overflow(g.p2);
     w.y = pack_player_misc(g.p2) | ((uint32_t)(g.b.power != 0) << 9) | ((uint32_t)(g.b.xv + 32) << 10) |
           (((uint32_t)g.b.yv & 0x1FFFu) << 16) | sticky | over;
     w.z = (uint32_t)g.b.x | ((uint32_t)g.b.px << 9) | ((uint32_t)g.b.ppx << 18);
