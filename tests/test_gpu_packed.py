@@ -354,3 +354,23 @@ def _replay_planted_through_hip(name, fmt, tables):
         return step
 
     replay_planted(d, make)
+
+
+def test_unreachable_player_state_raises_the_misfit_flag():
+    """pz_pack_state accepts any state whose fields fit one by one; an UNREACHABLE combination (a player at the jump's
+    apex still moving up at full speed) then leaves the court's y range a few frames later -- the step kernel raises
+    the game's sticky misfit flag instead of corrupting the neighbouring fields silently, and the host refuses the state.
+    The int32 columns step such a state like the reference does (see the random planted fixtures)."""
+    from pikazoo_amd import _native
+
+    env = make_env(num_envs=128, seed=2, state_format="packed", auto_reset=False)
+    env.reset()
+    st = env.unwrapped.state.clone()
+    st[1, 5], st[2, 5], st[3, 5] = 110, -16, 1       # player 1 of game 5: y 110, y velocity -16, jumping
+    st[14, 9], st[15, 9], st[16, 9] = 112, -16, 1    # player 2 of game 9
+    env.unwrapped.set_state(st)                      # every field fits: accepted
+    noop = torch.zeros(128, dtype=torch.int32, device="cuda:0")
+    for _ in range(12):
+        env.step({"player_1": noop, "player_2": noop})
+    with pytest.raises(_native.PikazooNativeError, match="2 games carry"):
+        env.unwrapped.state
