@@ -61,3 +61,24 @@ def test_oracle_tracks_live_reference(oracle, name, kw, wr):
                 assert np.array_equal(env.episode_lengths[done], d["ep_l"][t][done])
                 np.testing.assert_allclose(env.episode_returns[:, done], d["ep_r"][t][:, done], rtol=0, atol=2e-6)
     assert meta["episodes"] == int(d["term"].sum()) and meta["episodes"] > 0
+
+
+@pytest.mark.parametrize("kw", [dict(winning_score=4), dict(winning_score=2, is_player1_computer=True, is_player2_computer=True),
+                                dict(winning_score=3, is_player2_computer=True, serve="random"),
+                                dict(winning_score=3, is_player1_computer=True, serve="alternate")])
+def test_oracle_tracks_live_reference_from_planted_states(oracle, kw):
+    """Fresh planted states on every configuration (the committed fixtures hold one draw of them): every attribute of
+    players / ball / scores at random over its valid range, plus the fast-ball corners, stepped by the live reference."""
+    for d in (rc.capture_planted_random("live", 1500, seed=31337, action_seed=5, env_id_base=7700, env_kwargs=kw,
+                                        frames=10, plant_seed=2024),
+              rc.capture_planted("live", seed=31338, action_seed=6, env_id_base=8800, env_kwargs=kw, frames=12)):
+        meta = json.loads(bytes(d["meta"]).decode())
+        env = oracle.OracleEnv(meta["lanes"], oracle.make_config(
+            winning_score=kw.get("winning_score", 15), serve=kw.get("serve", "winner"),
+            is_player1_computer=kw.get("is_player1_computer", False),
+            is_player2_computer=kw.get("is_player2_computer", False), seed=meta["seed"], env_id_base=meta["env_id_base"]))
+        env.state[:] = d["planted"]
+        for t in range(meta["frames"]):
+            a1, a2 = oracle.random_actions(meta["lanes"], meta["env_id_base"], meta["action_seed"], meta["warm"] + t, 18)
+            env.step(a1, a2)
+            assert np.array_equal(env.state, d["states"][t]), (kw, t)
