@@ -310,6 +310,13 @@ def test_packed_render_and_scalar_api():
     assert term["player_1"] is True and sorted(infos["player_1"]["score"]) == [0, 1] and steps > 10
 
 
+@pytest.mark.parametrize("fmt", ["int32", "packed"])
+def test_planted_fast_balls_with_normalized_observations(fmt):
+    """Negative ball y and out-of-bounds velocities through the fused NormalizeObservation: float32 (v - low) / range,
+    equal to the oracle's (whose arithmetic tests/test_oracle_golden.py ties to the reference's float64 quotient)."""
+    _replay_planted_through_hip("planted_fast_balls_both_computer", fmt, True, normalize=True)
+
+
 @pytest.mark.parametrize("name,fmt,tables", [("planted_fast_balls_human", "int32", True),
                                              ("planted_fast_balls_human", "packed", True),
                                              ("planted_fast_balls_both_computer", "int32", True),
@@ -335,22 +342,32 @@ def test_random_planted_states_follow_the_reference(name, fmt, tables):
     _replay_planted_through_hip(name, fmt, tables)
 
 
-def _replay_planted_through_hip(name, fmt, tables):
-    """A planted-state fixture through the product: set_state(planted), then every frame against the reference's."""
+def _replay_planted_through_hip(name, fmt, tables, normalize=False):
+    """A planted-state fixture through the product: set_state(planted), then every frame's state against the reference's
+    and every frame's observations (raw, or NormalizeObservation's float32) against _get_obs of that state."""
     from conftest import load_golden
+    from oracle import pz_oracle as po
     from test_oracle_golden import replay_planted
 
     d = load_golden(name)
 
     def make(meta, planted):
         env = make_env(num_envs=meta["lanes"], seed=meta["seed"], env_id_base=meta["env_id_base"], state_format=fmt,
-                       flight_tables=tables, **meta["env_kwargs"])
+                       flight_tables=tables, wrappers=dict(stack=[["NormalizeObservation", {}]]) if normalize else {},
+                       **meta["env_kwargs"])
         raw = env.unwrapped
         raw.set_state(torch.as_tensor(planted, device=raw.device))
 
+        checker = po.OracleEnv(meta["lanes"], po.make_config(normalize_obs=normalize))
+
         def step(a1, a2):
-            env.step({"player_1": torch.as_tensor(a1, device=raw.device), "player_2": torch.as_tensor(a2, device=raw.device)})
-            return cpu(raw.state)
+            obs = env.step({"player_1": torch.as_tensor(a1, device=raw.device),
+                            "player_2": torch.as_tensor(a2, device=raw.device)})[0]
+            state = cpu(raw.state)
+            checker.state[:] = state            # the observation is a function of the state: _get_obs of what we hold
+            o1, o2 = checker.observe()
+            assert np.array_equal(cpu(obs["player_1"]), o1) and np.array_equal(cpu(obs["player_2"]), o2)
+            return state
         return step
 
     replay_planted(d, make)
