@@ -391,3 +391,44 @@ def test_unreachable_player_state_raises_the_misfit_flag():
         env.step({"player_1": noop, "player_2": noop})
     with pytest.raises(_native.PikazooNativeError, match="2 games carry"):
         env.unwrapped.state
+
+
+@pytest.mark.parametrize("fmt", ["int32", "packed"])
+@pytest.mark.parametrize("name", ["planted_random_states_both_computer", "planted_random_states_p2_computer_random_serve",
+                                  "planted_fast_balls_both_computer"])
+def test_k_frame_launches_from_planted_states(name, fmt):
+    """The k-frame kernels (state in registers for the whole launch: pz_step_many on the fixture's own action tape,
+    pz_step_random / pz_rollout_random against the oracle) started from the planted states: the reference's last frame,
+    and the oracle's state after the random-policy frames."""
+    from conftest import load_golden
+    from oracle import pz_oracle as po
+
+    d = load_golden(name)
+    meta = d["meta"]
+    lanes, frames = meta["lanes"], meta["frames"]
+    lanes4 = lanes // 4 * 4                       # the trajectory kernels want a multiple of four games
+    kw = dict(num_envs=lanes4, seed=meta["seed"], env_id_base=meta["env_id_base"], state_format=fmt, **meta["env_kwargs"])
+    planted = torch.as_tensor(d["planted"][:, :lanes4].copy(), device="cuda:0")
+    tape = np.stack([np.stack(po.random_actions(lanes, meta["env_id_base"], meta["action_seed"], meta["warm"] + t, 18))
+                     for t in range(frames)])[:, :, :lanes4]
+    env = make_env(**kw)
+    env.unwrapped.set_state(planted)
+    out = env.unwrapped.step_many(torch.as_tensor(tape, device="cuda:0"))
+    assert np.array_equal(cpu(env.unwrapped.state), d["states"][frames - 1][:, :lanes4])
+    okw = meta["env_kwargs"]
+    cfg = po.make_config(winning_score=okw.get("winning_score", 15), serve=okw.get("serve", "winner"),
+                         is_player1_computer=okw.get("is_player1_computer", False),
+                         is_player2_computer=okw.get("is_player2_computer", False), seed=meta["seed"],
+                         env_id_base=meta["env_id_base"])
+    for mode in ("random", "rollout"):
+        env = make_env(**kw)
+        env.unwrapped.set_state(planted)
+        ref = po.OracleEnv(lanes4, cfg, nthreads=4)
+        ref.state[:] = d["planted"][:, :lanes4]
+        if mode == "random":
+            env.unwrapped.step_random(3, t0=0, k=17)
+        else:
+            traj = env.unwrapped.rollout_random(3, 17, t0=0)
+        ref.rollout_random(3, 0, 17)
+        assert np.array_equal(cpu(env.unwrapped.state), ref.state), mode
+    assert np.array_equal(cpu(traj["obs"]["player_1"][-1]), ref.obs[0])
