@@ -82,3 +82,45 @@ def test_oracle_tracks_live_reference_from_planted_states(oracle, kw):
             a1, a2 = oracle.random_actions(meta["lanes"], meta["env_id_base"], meta["action_seed"], meta["warm"] + t, 18)
             env.step(a1, a2)
             assert np.array_equal(env.state, d["states"][t]), (kw, t)
+
+
+def test_draw_list_tracks_live_reference_on_planted_states():
+    """render() of the live reference on random planted states (every pose / mirroring / score digit / hyper ball, balls
+    partly or wholly off screen): the oracle's draw list equals the recorded blits (punch effect aside)."""
+    from oracle import render_oracle as ro
+
+    files = ro.sprite_files()
+    sizes = None
+    rng = np.random.default_rng(77)
+    checked = 0
+    for i in range(400):
+        env, raw, shim = rc.make_reference_env(5, 300 + i, None, render_mode="rgb_array", winning_score=15)
+        env.reset()
+        for pl in (raw.physics.player1, raw.physics.player2):
+            pl.state = int(rng.integers(0, 5))
+            pl.frame_number = int(rng.integers(0, 5 if pl.state < 3 else (2 if pl.state == 3 else 1)))
+            pl.diving_direction = int(rng.integers(-1, 2))
+            pl.y = int(rng.integers(108, 245))
+        b = raw.physics.ball
+        b.x, b.y = int(rng.integers(20, 433)), int(rng.integers(-120, 253))
+        b.previous_x, b.previous_y = int(rng.integers(20, 433)), int(rng.integers(-120, 253))
+        b.previous_previous_x, b.previous_previous_y = int(rng.integers(20, 433)), int(rng.integers(-120, 253))
+        b.is_power_hit = bool(rng.integers(0, 2))
+        b.fine_rotation = int(rng.integers(0, 51))
+        b.rotation = b.fine_rotation // 10
+        raw.scores = [int(rng.integers(0, 16)), int(rng.integers(0, 16))]
+        raw.render()
+        blits = raw.screen.blits[rc.BACKGROUND_BLITS:]
+        if sizes is None:
+            sizes = [(0, 0)] * ro.SPRITE_COUNT
+            import struct
+            for k, f in enumerate(files):
+                with open(rc.REFERENCE_ROOT / "pikazoo" / "env" / "img" / f, "rb") as fh:
+                    head = fh.read(24)
+                sizes[k] = struct.unpack(">II", head[16:24])
+        want = [(files.index(f), int(flip), x, y, w, h) for (f, flip, scaled), x, y, w, h in blits if f != "ball_punch.png"]
+        sc = rc.extract_scenery(raw)
+        got = ro.draw_list(rc.extract_state(raw, shim), sizes, sc)
+        assert got == want, i
+        checked += len(got)
+    assert checked > 400 * 45
