@@ -44,6 +44,8 @@ def test_frames_match_the_numpy_oracle():
     st[39, :64] = 15 - torch.arange(64, device=st.device, dtype=torch.int32) % 16
     st[26, :32], st[27, :32] = 432, 0
     st[35, 32:64] = 50
+    # a ball bounced off the net top above the screen (the reference's ball y goes negative), hyper ball and trail too
+    st[27, 8:24], st[32, 8:24], st[34, 8:24], st[30, 8:24] = -12, -40, -110, 1
     env.set_state(st)
     lanes = torch.arange(0, 64, 3, device="cuda:0")
     frames = env.render(lanes=lanes)
