@@ -255,8 +255,7 @@ int pz_random_actions(int32_t *act_p1, int32_t *act_p2, int64_t n, int64_t env_i
  * rotation = fine_rotation // 10 physics.py:388, shadow, and on a power hit the hyper ball / trail at the two
  * previous positions) -> score boards (:327-336).  Sprites are RGBA8 (R | G<<8 | B<<16 | A<<24) in `atlas`,
  * described by `sprites[PZ_SPRITE_COUNT]` (device memory); blits use pygame's per-pixel-alpha rule
- * dC = (((sC - dC) * sA + sC) >> 8) + dC.  NOT drawn: the punch effect (:292-294; its radius and y live in two ball
- * attributes outside the 44 state words, set by the physics and counted down by render itself).
+ * dC = (((sC - dC) * sA + sC) >> 8) + dC.  The punch effect (:292-294) is drawn with `scenery` only (below).
  * frames: uint8 [m][304][432][3].
  *
  * Clouds and waves (cloud_and_wave.py) are state OUTSIDE the 44 words, owned by the reference's renderer and driven by
@@ -265,12 +264,22 @@ int pz_random_actions(int32_t *act_p1, int32_t *act_p2, int64_t n, int64_t env_i
  * heights and a few cloud respawns from the same stream -- so in the reference rendering changes the game's later
  * random draws.  `scenery` reproduces exactly that: int32[PZ_SCENERY_WORDS][stride], field-major like the state
  * (cloud i at words 4i..4i+3: top_left_point_x, top_left_point_y, top_left_point_x_velocity, size_diff_turn_number;
- * 40 wave.vertical_coord, 41 its velocity, 42..68 wave.y_coords).  pz_scenery_init = the constructor's part (call it
- * between pz_init and the first pz_reset); pz_render with scenery != NULL runs the engine for the rendered games
- * (advancing their rng draw counter in `state`; `lanes` must then hold distinct games and cfg must be given) and draws
- * the clouds -- scaled like pygame.transform.scale: source pixel = floor(k * source size / scaled size) -- and the
- * waves.  With scenery == NULL nothing is written to `state` (cfg may be NULL) and no clouds / waves are drawn.
- * Both calls take the int32 columns (a packed state is converted by the caller). */
+ * 40 wave.vertical_coord, 41 its velocity, 42..68 wave.y_coords; 69 ball.punch_effect_radius, 70 ball.punch_effect_y;
+ * 71..74 what pz_scenery_track remembers of the previous frame: both is_collision_with_ball_happened flags, game_ended,
+ * round_ended).
+ * pz_scenery_init = the constructor's part (call it between pz_init and the first pz_reset); pz_render with
+ * scenery != NULL runs the engine for the rendered games (advancing their rng draw counter in `state`; `lanes` must then
+ * hold distinct games and cfg must be given) and draws the clouds -- scaled like pygame.transform.scale: source pixel =
+ * floor(k * source size / scaled size) -- the waves and the punch effect.  With scenery == NULL nothing is written to
+ * `state` (cfg may be NULL) and none of the three is drawn.
+ * The punch effect's radius and y are two ball attributes outside the 44 state words: the physics sets them when the
+ * ball touches the ground (physics.py:427-430) or is power-hit (:628-632), render() counts the radius down by 2 per call
+ * (:292-294).  pz_scenery_track, called after EVERY pz_step of a batch whose scenery is kept, re-derives those two
+ * events from the state the step left (ground touch = round_ended; power hit = a player's collision flag rising while
+ * its state is 2; a frame that started a new round clears the radius first, :274-275) and sets radius / y like the
+ * physics does; after pz_reset the caller clears words 69 and 71..74 of the reset games; `resync` != 0 (after a k-frame launch, whose inner frames
+ * it cannot see) only clears the effect and re-reads the flags.
+ * All three calls take the int32 columns (a packed state is converted by the caller). */
 #define PZ_FRAME_WIDTH 432
 #define PZ_FRAME_HEIGHT 304
 enum pz_sprite_id {
@@ -282,15 +291,18 @@ enum pz_sprite_id {
     PZ_SPRITE_NUMBER = 36,        /* 10: number_0..9 */
     PZ_SPRITE_CLOUD = 46,
     PZ_SPRITE_WAVE = 47,
-    PZ_SPRITE_COUNT = 48
+    PZ_SPRITE_BALL_PUNCH = 48,
+    PZ_SPRITE_COUNT = 49
 };
-#define PZ_SCENERY_WORDS 69
+#define PZ_SCENERY_WORDS 75
 typedef struct pz_sprite {
     int32_t offset;   /* first pixel in the atlas */
     int32_t width, height;
 } pz_sprite;
 int pz_scenery_init(int32_t *scenery, int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
                     void *stream);
+int pz_scenery_track(int32_t *scenery, const int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
+                     int32_t resync, void *stream);
 int pz_render(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg, const int32_t *lanes, int64_t m,
               const uint32_t *atlas, const pz_sprite *sprites, const uint32_t *background,
               int32_t *scenery, uint8_t *frames, void *stream);

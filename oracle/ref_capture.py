@@ -462,7 +462,9 @@ INT_TABLE = (1, -2, 3, -4, 5, -6, 7, -8)
 # --------------------------------------------------------------------------------------
 # render(): the reference's draw list and what it does to the env RNG (render_mode="rgb_array")
 # --------------------------------------------------------------------------------------
-SCENERY_WORDS = 69  # 10 clouds x (x, y, x velocity, size_diff_turn_number), wave vertical_coord, its velocity, 27 y_coords
+# 10 clouds x (x, y, x velocity, size_diff_turn_number), wave vertical_coord, its velocity, 27 y_coords,
+# ball.punch_effect_radius, ball.punch_effect_y
+SCENERY_WORDS = 71
 # static part of a frame: draw_background (pikazoo_env.py:296-325), identical on every frame
 BACKGROUND_BLITS = 12 * 27 + 1 + 27 + 25 + 2 + 2 * 27 + 1 + 12
 
@@ -475,6 +477,7 @@ def extract_scenery(raw) -> np.ndarray:
                                 c.size_diff_turn_number)
     out[40], out[41] = raw.wave_.vertical_coord, raw.wave_.vertical_coord_velocity
     out[42:69] = raw.wave_.y_coords
+    out[69], out[70] = raw.physics.ball.punch_effect_radius, raw.physics.ball.punch_effect_y
     return out
 
 

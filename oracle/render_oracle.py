@@ -55,22 +55,27 @@ def sprite_index(state, frame):  # get_frame_number_for_player_animated_sprite :
 
 
 # sprite ids of the product (include/pikazoo_hip.h: pz_sprite_id) and the reference's file behind each
-SPRITE_CLOUD, SPRITE_WAVE, SPRITE_COUNT = 46, 47, 48
+SPRITE_CLOUD, SPRITE_WAVE, SPRITE_PUNCH, SPRITE_COUNT = 46, 47, 48, 49
 _PIKACHU_FRAMES = [(0, 5), (1, 5), (2, 5), (3, 2), (4, 1), (5, 5), (6, 5)]  # get_all_image :445-474
 
 
 def sprite_files():
     files = [f"pikachu_{st}_{fr}.png" for st, count in _PIKACHU_FRAMES for fr in range(count)]
     files += [f"ball_{k}.png" for k in range(5)] + ["ball_hyper.png", "ball_trail.png", "shadow.png"]
-    files += [f"number_{k}.png" for k in range(10)] + ["cloud.png", "wave.png"]
+    files += [f"number_{k}.png" for k in range(10)] + ["cloud.png", "wave.png", "ball_punch.png"]
     assert len(files) == SPRITE_COUNT
     return files
 
 
 # ---- clouds and waves (cloud_and_wave.py): state outside the 44 words, driven by the env RNG ----------------------
 # scenery words: cloud i at 4i: top_left_point_x, top_left_point_y, top_left_point_x_velocity, size_diff_turn_number;
-# 40: wave.vertical_coord, 41: wave.vertical_coord_velocity, 42..68: wave.y_coords
-SCENERY_WORDS = 69
+# 40: wave.vertical_coord, 41: wave.vertical_coord_velocity, 42..68: wave.y_coords; 69: ball.punch_effect_radius,
+# 70: ball.punch_effect_y (ball attributes outside the 44 state words); 71..74: what scenery_track remembers of the
+# previous frame (both collision flags, game_ended, round_ended)
+SCENERY_WORDS = 75
+P_COLL = 9
+B_PUNCH_X = 37
+E_ROUND_ENDED, E_GAME_ENDED = 41, 42
 
 
 def scenery_init(draw):
@@ -85,6 +90,25 @@ def scenery_init(draw):
     sc[40], sc[41] = 0, 2
     sc[42:69] = 314
     return sc
+
+
+def scenery_track(sc, col, auto_reset=True):
+    """What one frame of the physics does to the punch effect's radius / y, re-derived from the state `col` it left:
+    a frame that started a new round clears the radius (Ball.initialize_for_new_round physics.py:274-275), the
+    ball-world step sets them on a ground touch (:427-430 -- the frames that end with round_ended set), a ball-player
+    collision on a power hit (:628-632 -- the player's collision flag rose and its state is 2; player 2's after
+    player 1's, physics_engine :319-335)."""
+    col = [int(v) for v in col]
+    if not (sc[73] and not auto_reset):  # a finished game without auto-reset is not stepped
+        if sc[74]:
+            sc[69] = 0
+        if col[E_ROUND_ENDED]:
+            sc[69], sc[70] = 20, 252 + 20
+        for p, prev in ((0, 71), (1, 72)):
+            if col[p * P_WORDS + P_COLL] and not sc[prev] and col[p * P_WORDS + P_STATE] == 2:
+                sc[69], sc[70] = 20, col[B_Y]
+    sc[71], sc[72] = col[P_COLL], col[P_WORDS + P_COLL]
+    sc[73], sc[74] = col[E_GAME_ENDED], col[E_ROUND_ENDED]
 
 
 def scenery_tick(sc, draw):
@@ -104,14 +128,19 @@ def scenery_tick(sc, draw):
         sc[40] = -draw(40)
     for i in range(27):
         sc[42 + i] = 314 - sc[40] + draw(3)
+    if sc[69] > 0:  # draw_ball counts the punch effect down itself (pikazoo_env.py:292-293)
+        sc[69] -= 2
 
 
-def draw_list(col, sizes, scenery=None):
+def draw_list(col, sizes, scenery=None, punch_drawn=None):
     """The blits of raw_env.draw behind the static background, in the reference's order (:250-255), as
     (sprite id, mirrored, x, y, width, height) with (x, y) the top-left corner; `sizes[id]` = (width, height) of the
-    sprite files.  The punch effect (:292-294) is not part of it."""
+    sprite files.  With `scenery` (after its tick): clouds, waves and the punch effect (:292-294: drawn whenever its
+    radius was positive before the tick's decrement -- a 0 x 0 blit at the end)."""
     col = [int(v) for v in col]
     out = []
+    if punch_drawn is None:  # (the caller knows whether the radius was positive before the tick; default: is it now)
+        punch_drawn = scenery is not None and int(scenery[69]) > 0
 
     def centred(sid, x, y, flip=0):
         w, h = sizes[sid]
@@ -140,6 +169,9 @@ def draw_list(col, sizes, scenery=None):
     if col[B_POWER]:
         centred(SPRITE_HYPER, col[B_PX], col[B_PY])
         centred(SPRITE_TRAIL, col[B_PPX], col[B_PPY])
+    if scenery is not None and punch_drawn:
+        r = int(scenery[69])
+        out.append((SPRITE_PUNCH, 0, col[B_PUNCH_X] - r, int(scenery[70]) - r, 2 * r, 2 * r))
     s1, s2 = col[E_S1], col[E_S2]  # draw_scores_to_score_boards :327-336
     if s1 >= 10:
         out.append((SPRITE_NUMBER + 1, 0, 14, 10, *sizes[SPRITE_NUMBER + 1]))
@@ -171,6 +203,8 @@ def scaled(sprite, w, h):
     hh, ww = sprite.shape[:2]
     if (ww, hh) == (w, h):
         return sprite
+    if w <= 0 or h <= 0:
+        return sprite[:0, :0]
     return sprite[stretch_map(hh, h)][:, stretch_map(ww, w)]
 
 

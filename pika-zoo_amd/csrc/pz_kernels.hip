@@ -1262,7 +1262,44 @@ __global__ __launch_bounds__(kLanes) void scenery_init_kernel(int32_t* scenery, 
     word(40) = 0;
     word(41) = 2;
     for (int k = 0; k < 27; ++k) word(42 + k) = 314;
+    for (int k = 69; k < PZ_SCENERY_WORDS; ++k) word(k) = 0;  // no punch effect (physics.py:275), nothing remembered
     state[(int64_t)PZ_E_RNG_DRAW_COUNTER * stride + i] = (int32_t)rng;
+}
+
+// The punch effect's two ball attributes (physics.py:240-242,275), re-derived after a frame from the state it left:
+// the ball-world step sets them on a ground touch (:427-430 -- exactly the frames that end with round_ended set), the
+// ball-player collision on a power hit (:628-632 -- a player's collision flag rising while its state is 2; player 1
+// first, player 2's overrides it like in physics_engine :319-335).
+__global__ __launch_bounds__(kLanes) void scenery_track_kernel(int32_t* scenery, const int32_t* state, int64_t n,
+                                                               int64_t stride, const pz_config cfg, int resync)
+{
+    const int64_t i = (int64_t)blockIdx.x * kLanes + threadIdx.x;
+    if (i >= n) return;
+    auto word = [&](int w) -> int32_t& { return scenery[(int64_t)w * stride + i]; };
+    auto st = [&](int f) { return state[(int64_t)f * stride + i]; };
+    const int coll1 = st(PZ_P_IS_COLLISION_WITH_BALL_HAPPENED), coll2 = st(PZ_P_WORDS + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED);
+    const int ended = st(PZ_E_GAME_ENDED), round_ended = st(PZ_E_ROUND_ENDED);
+    if (resync) {
+        word(69) = 0;
+    } else if (!(word(73) != 0 && cfg.auto_reset == 0)) {  // (a finished game without auto-reset was not stepped)
+        int radius = word(69), y = word(70);
+        if (word(74) != 0) radius = 0;  // the frame started a new round: Ball.initialize_for_new_round (:274-275)
+        if (round_ended != 0) {
+            radius = kBallRadius;
+            y = kBallGroundY + kBallRadius;
+        }
+        if ((coll1 != 0 && word(71) == 0 && st(PZ_P_STATE) == 2) ||
+            (coll2 != 0 && word(72) == 0 && st(PZ_P_WORDS + PZ_P_STATE) == 2)) {
+            radius = kBallRadius;
+            y = st(PZ_B_Y);
+        }
+        word(69) = radius;
+        word(70) = y;
+    }
+    word(71) = coll1;
+    word(72) = coll2;
+    word(73) = ended;
+    word(74) = round_ended;
 }
 
 // cloud_and_wave_engine (cloud_and_wave.py:53-78) for the games about to be drawn: one thread per frame
@@ -1297,6 +1334,7 @@ __global__ __launch_bounds__(kLanes) void scenery_tick_kernel(int32_t* scenery, 
     }
     word(40) = vc;
     for (int k = 0; k < 27; ++k) word(42 + k) = 314 - vc + rng_integers(id, rng, 3u);
+    if (word(69) > 0) word(69) -= 2;  // draw_ball counts the punch effect down itself (pikazoo_env.py:292-293)
     state[(int64_t)PZ_E_RNG_DRAW_COUNTER * stride + i] = (int32_t)rng;
 }
 
@@ -1370,22 +1408,43 @@ __global__ __launch_bounds__(256) void render_kernel(const int32_t* __restrict__
             }
         }
     }
-#pragma unroll
-    for (int b = 0; b < 12; ++b) {
-        if (list[b].sprite < 0) continue;
-        const pz_sprite sp = sprites[list[b].sprite];
-        const bool centred = (list[b].flip & 1) != 0, mirrored = (list[b].flip & 2) != 0;
-        const int x0 = centred ? list[b].x0 - sp.width / 2 : list[b].x0;    // blit_center :40-43
-        const int y0 = centred ? list[b].y0 - sp.height / 2 : list[b].y0;
+    auto blit = [&](const Blit& bl) {
+        if (bl.sprite < 0) return;
+        const pz_sprite sp = sprites[bl.sprite];
+        const bool centred = (bl.flip & 1) != 0, mirrored = (bl.flip & 2) != 0;
+        const int x0 = centred ? bl.x0 - sp.width / 2 : bl.x0;    // blit_center :40-43
+        const int y0 = centred ? bl.y0 - sp.height / 2 : bl.y0;
         const int sy = row - y0;
-        if ((unsigned)sy >= (unsigned)sp.height || col + 3 < x0 || col >= x0 + sp.width) continue;
+        if ((unsigned)sy >= (unsigned)sp.height || col + 3 < x0 || col >= x0 + sp.width) return;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int sx = col + k - x0;
             if ((unsigned)sx < (unsigned)sp.width)
                 px[k] = blend_over(px[k], atlas[sp.offset + sy * sp.width + (mirrored ? sp.width - 1 - sx : sx)]);
         }
+    };
+#pragma unroll
+    for (int b = 0; b < 8; ++b) blit(list[b]);  // players, shadows, ball, hyper ball, trail
+    if (scenery != nullptr) {  // the punch effect, last blit of draw_ball (:292-294): ball_punch scaled to 2r x 2r
+        const int r = scenery[(int64_t)69 * stride + game];
+        if (r > 0) {
+            const pz_sprite sp = sprites[PZ_SPRITE_BALL_PUNCH];
+            const int size = 2 * r;
+            const int x0 = word(PZ_B_PUNCH_EFFECT_X) - r, y0 = scenery[(int64_t)70 * stride + game] - r;  // blit_center
+            const int dy = row - y0;
+            if ((unsigned)dy < (unsigned)size && col + 3 >= x0 && col < x0 + size) {
+                const int sy = dy * sp.height / size;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int dx = col + k - x0;
+                    if ((unsigned)dx < (unsigned)size)
+                        px[k] = blend_over(px[k], atlas[sp.offset + sy * sp.width + dx * sp.width / size]);
+                }
+            }
+        }
     }
+#pragma unroll
+    for (int b = 8; b < 12; ++b) blit(list[b]);  // score boards
     // 4 x RGB = 12 bytes = 3 dwords
     const uint32_t r0 = (px[0] & 0xFFFFFFu) | (px[1] << 24);
     const uint32_t r1 = ((px[1] >> 8) & 0xFFFFu) | (px[2] << 16);
@@ -1719,6 +1778,17 @@ int pz_scenery_init(int32_t* scenery, int32_t* state, int64_t n, int64_t stride,
     if (n == 0) return PZ_OK;
     hipLaunchKernelGGL(scenery_init_kernel, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, scenery, state,
                        n, stride, *cfg);
+    return (int)hipGetLastError();
+}
+
+int pz_scenery_track(int32_t* scenery, const int32_t* state, int64_t n, int64_t stride, const pz_config* cfg,
+                     int32_t resync, void* stream)
+{
+    if (!scenery || !state || !cfg) return PZ_E_NULL;
+    if (n < 0 || stride < n || stride > kMaxLanesPerLaunch) return PZ_E_SIZE;
+    if (n == 0) return PZ_OK;
+    hipLaunchKernelGGL(scenery_track_kernel, dim3(blocks_for(n, kLanes)), dim3(kLanes), 0, (hipStream_t)stream, scenery, state,
+                       n, stride, *cfg, (int)resync);
     return (int)hipGetLastError();
 }
 

@@ -13,7 +13,7 @@ LIB_PATH = PKG_ROOT / "lib" / "libpikazoo_hip.so"
 
 ABI_VERSION = 5
 PACKED_BYTES_PER_GAME = 36
-SCENERY_WORDS = 69
+SCENERY_WORDS = 75
 STATE_WORDS = 44
 OBS_DIM = 35
 SERVE_MODES = {"winner": 0, "alternate": 1, "random": 2}
@@ -82,6 +82,7 @@ _SIGNATURES = {
     "pz_random_actions": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _P]),
     "pz_selftest_predictor": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     "pz_scenery_init": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P]),
+    "pz_scenery_track": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.POINTER(PzConfig), C.c_int32, _P]),
     # (cfg may be None when no scenery is passed: ctypes passes NULL for None)
     "pz_render": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
 }

@@ -104,7 +104,8 @@ class raw_env:
     ``scenery`` (with ``render_mode="rgb_array"``: draw the reference's clouds and waves too.  They are renderer-owned
     state driven by the env RNG, so -- exactly as in the reference, pikazoo_env.py:475-477, cloud_and_wave.py:53-78 --
     the constructor then draws 40 values behind the two boldness draws and every ``render()`` advances the RNG of the
-    games it draws; off by default, which keeps ``render()`` free of side effects).
+    games it draws; the punch effect is drawn too: its two ball attributes are tracked after every ``step()``, a k-frame
+    launch clears it; off by default, which keeps ``render()`` free of side effects and ``step()`` a single launch).
 
     Returned tensors are views of env-owned buffers that the next ``step`` overwrites;
     ``clone()`` what must outlive it.
@@ -277,6 +278,14 @@ class raw_env:
             _native.check(self._lib.pz_pack_state(cols.data_ptr(), self.num_envs, self._stride, self._state_ptr,
                                                   self._stride, None, self._stream()), "pz_pack_state")
             return out
+
+    def _track_scenery(self, resync: bool = False):
+        """The punch effect's radius / y are ball attributes outside the 44 words: re-derive what this frame did to them
+        (``pz_scenery_track``).  After a k-frame launch (`resync`) the inner frames are gone: the effect is cleared."""
+        with torch.cuda.device(self.device):
+            cols = self._state_buf if self._state_view is not None else self._unpacked()[0]  # read-only for the call
+            _native.check(self._lib.pz_scenery_track(self._scenery.data_ptr(), cols.data_ptr(), self.num_envs, self._stride,
+                                                     self._cfg_ref, int(resync), self._stream()), "pz_scenery_track")
 
     def set_state(self, state: torch.Tensor):
         """Overwrite the state of every game with ``int32[44, num_envs]`` columns (either format)."""
@@ -459,6 +468,9 @@ class raw_env:
             _native.check(self._lib.pz_reset(self._state_ptr, self.num_envs, self._stride, self._cfg_ref,
                                              _ptr(m), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
                                              self._stats_ptr(), self._stream()), "pz_reset")
+        if self._scenery is not None:  # a new round clears the punch effect (physics.py:274-275); nothing to remember
+            rows = self._scenery[[69, 71, 72, 73, 74]]
+            self._scenery[[69, 71, 72, 73, 74]] = rows * (m == 0).to(rows.dtype) if m is not None else 0
         if self.scalar_api:
             return self._pack_obs(), {a: {"score": self._scores[0].tolist()} for a in self.agents}
         return self._pack_obs(), self._infos()
@@ -514,6 +526,8 @@ class raw_env:
                                        p[3], p[4], p[5], self._stats_ptr(), self._tables_ref, self._stream())
         if rc:
             _native.check(rc, "pz_step")
+        if self._scenery is not None:
+            self._track_scenery()
         self.steps_done += 1
         if self.scalar_api:
             return self._pack_step()
@@ -536,6 +550,8 @@ class raw_env:
                                                    self._term_u8.data_ptr(), self._stats_ptr(),
                                                    self._episodes.data_ptr(), self._tables_ref, self._stream()),
                           "pz_step_random")
+        if self._scenery is not None:
+            self._track_scenery(resync=int(k) != 1)
         self.steps_done += int(k)
         return self._pack_step()
 
@@ -565,6 +581,8 @@ class raw_env:
                 out["actions"].data_ptr(), out["_obs"][0].data_ptr(), out["_obs"][1].data_ptr(),
                 out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(), out["_term"].data_ptr(),
                 self._stats_ptr(), self._episodes.data_ptr(), self._tables_ref, self._stream()), "pz_rollout_random")
+        if self._scenery is not None:
+            self._track_scenery(resync=True)
         self.steps_done += k
         return self._finish_trajectory(out)
 
@@ -594,6 +612,8 @@ class raw_env:
                 out["_obs"][1].data_ptr(), out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(),
                 out["_term"].data_ptr(), self._stats_ptr(), self._episodes.data_ptr(), self._tables_ref,
                 self._stream()), "pz_step_many")
+        if self._scenery is not None:
+            self._track_scenery(resync=True)
         self.steps_done += k
         return self._finish_trajectory(out)
 

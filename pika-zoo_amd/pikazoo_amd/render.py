@@ -10,8 +10,9 @@ composes the static background once on the host, exactly in the order of ``draw_
 Drawn: background, both players with their mirroring rules, shadows, ball / hyper ball / trail, score boards; and,
 for an env created with ``scenery=True``, the clouds and waves -- renderer-owned state outside the 44 words that, as in
 the reference, is drawn from the env RNG (ten clouds at construction, a tick of ``cloud_and_wave_engine`` with every
-``render()``), so rendering then changes the game's later random draws exactly like the reference's does.
-Not drawn (see ``include/pikazoo_hip.h``): the punch effect.
+``render()``), so rendering then changes the game's later random draws exactly like the reference's does -- and the punch
+effect, whose two ball attributes (set by the physics on a ground touch / power hit, counted down by ``render()``) the env
+tracks after every ``step()`` (``pz_scenery_track``).
 """
 from __future__ import annotations
 
@@ -33,16 +34,16 @@ SPRITE_FILES = ([f"pikachu_{s}_{f}.png" for s, k in PIKACHU_FRAMES for f in rang
                 + [f"ball_{i}.png" for i in range(5)] + ["ball_hyper.png"]                    # 28..33
                 + ["ball_trail.png", "shadow.png"]                                            # 34, 35
                 + [f"number_{i}.png" for i in range(10)]                                      # 36..45
-                + ["cloud.png", "wave.png"])                                                  # 46, 47
+                + ["cloud.png", "wave.png", "ball_punch.png"])                                # 46, 47, 48
 BACKGROUND_FILES = ["sky_blue.png", "mountain.png", "ground_red.png", "ground_line.png", "ground_line_leftmost.png",
                     "ground_line_rightmost.png", "ground_yellow.png", "net_pillar_top.png", "net_pillar.png"]
-SPRITE_SHAPES = ([(64, 64)] * 28 + [(40, 40)] * 7 + [(32, 8)] + [(32, 32)] * 10 + [(48, 24), (16, 32)])  # (width, height)
+SPRITE_SHAPES = ([(64, 64)] * 28 + [(40, 40)] * 7 + [(32, 8)] + [(32, 32)] * 10 + [(48, 24), (16, 32), (40, 40)])  # (width, height)
 SCENERY_WORDS = _native.SCENERY_WORDS
 BACKGROUND_SHAPES = {"sky_blue.png": (16, 16), "mountain.png": (432, 64), "ground_red.png": (16, 16),
                      "ground_line.png": (16, 16), "ground_line_leftmost.png": (16, 16),
                      "ground_line_rightmost.png": (16, 16), "ground_yellow.png": (16, 16),
                      "net_pillar_top.png": (8, 8), "net_pillar.png": (8, 8)}
-assert len(SPRITE_FILES) == len(SPRITE_SHAPES) == 48
+assert len(SPRITE_FILES) == len(SPRITE_SHAPES) == 49
 
 
 class PzSprite(C.Structure):
@@ -150,7 +151,7 @@ def compose_background(tiles: Dict[str, np.ndarray]) -> np.ndarray:
 
 
 class SpriteSet:
-    """The 48 dynamic sprites (RGBA8 atlas + descriptor table) and the composed background, on one device."""
+    """The 49 dynamic sprites (RGBA8 atlas + descriptor table) and the composed background, on one device."""
 
     def __init__(self, sprites, tiles, device):
         if len(sprites) != len(SPRITE_FILES):

@@ -85,9 +85,9 @@ def test_render_api_behaviour():
 def test_rendering_with_scenery_follows_the_reference_render(name, fmt):
     """The reference's own render() (recorded by oracle/ref_capture.capture_render: constructor with a render_mode,
     render after reset and every few steps, per lane) replayed through the product: the 44 state words after every step
-    and after every frame (rendering advances the env RNG), the clouds / waves after every frame -- against the
-    reference; the frames themselves against the numpy oracle (whose draw lists tests/test_render_cpu.py pins to the
-    reference's)."""
+    and after every frame (rendering advances the env RNG), the clouds / waves and the punch effect's radius / y after
+    every frame -- against the reference; the frames themselves against the numpy oracle (whose draw lists
+    tests/test_render_cpu.py pins to the reference's)."""
     from conftest import load_golden
     from oracle import render_oracle as ro
     from pikazoo_amd import pikazoo_v0
@@ -101,7 +101,7 @@ def test_rendering_with_scenery_follows_the_reference_render(name, fmt):
                          render_mode="rgb_array", sprites=sprites, scenery=True, validate_actions=False,
                          state_format=fmt, **meta["env_kwargs"])
     assert np.array_equal(env.state.cpu().numpy(), d["state_ctor"])
-    assert np.array_equal(env._scenery[:, :lanes].cpu().numpy(), d["scenery_ctor"])
+    assert np.array_equal(env._scenery[:71, :lanes].cpu().numpy(), d["scenery_ctor"])
     env.reset()
     assert np.array_equal(env.state.cpu().numpy(), d["state0"])
     k = checked = 0
@@ -114,7 +114,7 @@ def test_rendering_with_scenery_follows_the_reference_render(name, fmt):
         for j, i in enumerate(due):
             assert (int(d["frame_lane"][k]), int(d["frame_step"][k])) == (i, t)
             assert np.array_equal(st[:, i], d["frame_state"][k]), (k, i, t)
-            assert np.array_equal(sc[:, i], d["frame_scenery"][k]), (k, i, t)
+            assert np.array_equal(sc[:71, i], d["frame_scenery"][k]), (k, i, t)  # clouds, waves, punch radius / y
             if k % 5 == 0:
                 want = ro.frame(st[:, i], sprites.sprites_host, sprites.background_host, sc[:, i])
                 assert np.array_equal(frames[j], want), (k, i, t)

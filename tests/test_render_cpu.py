@@ -133,7 +133,7 @@ RENDER_FIXTURES = ["render_human_human", "render_p2_computer"]
 def replay_render_fixture(d, on_frame):
     """Step the C oracle through a render fixture -- construction, clouds, reset, the random policy, a scenery tick
     wherever the reference rendered -- checking states / clouds / waves against the reference at every point, and call
-    `on_frame(k, lane, state_column, scenery)` for every recorded frame k."""
+    `on_frame(k, lane, state_column, scenery, punch_drawn)` for every recorded frame k."""
     from oracle import pz_oracle as po
     from oracle import render_oracle as ro
 
@@ -156,7 +156,7 @@ def replay_render_fixture(d, on_frame):
     # constructor: physics (draws 0, 1), then the ten clouds (get_all_image, pikazoo_env.py:475-477)
     scenery = [ro.scenery_init(stream(i)) for i in range(lanes)]
     assert np.array_equal(ref.state, d["state_ctor"])
-    assert np.array_equal(np.stack(scenery, axis=1), d["scenery_ctor"])
+    assert np.array_equal(np.stack(scenery, axis=1)[:71], d["scenery_ctor"])
     ref.reset()
     assert np.array_equal(ref.state, d["state0"])
     k = 0
@@ -164,10 +164,11 @@ def replay_render_fixture(d, on_frame):
     def frame(i, t):
         nonlocal k
         assert (int(d["frame_lane"][k]), int(d["frame_step"][k])) == (i, t)
+        punch_drawn = scenery[i][69] > 0     # draw_ball tests the radius before it counts it down
         ro.scenery_tick(scenery[i], stream(i))
-        assert np.array_equal(scenery[i], d["frame_scenery"][k]), (k, i, t)
+        assert np.array_equal(scenery[i][:71], d["frame_scenery"][k]), (k, i, t)   # clouds, waves, punch radius / y
         assert np.array_equal(ref.state[:, i], d["frame_state"][k]), (k, i, t)
-        on_frame(k, i, ref.state[:, i].copy(), scenery[i].copy())
+        on_frame(k, i, ref.state[:, i].copy(), scenery[i].copy(), punch_drawn)
         k += 1
 
     for i in range(lanes):
@@ -177,6 +178,7 @@ def replay_render_fixture(d, on_frame):
         ref.step(a1, a2)
         assert np.array_equal(ref.state, d["states"][t]), t
         for i in range(lanes):
+            ro.scenery_track(scenery[i], ref.state[:, i])   # what the frame did to the punch effect
             if (t + 1) % periods[i] == 0:
                 frame(i, t)
     assert k == len(d["frame_lane"])
@@ -193,20 +195,19 @@ def test_draw_list_clouds_waves_and_rng_match_the_reference_render(name):
     files = d["meta"]["files"]
     ours = ro.sprite_files()
     fid = {f: ours.index(f) for f in files if f in ours}
-    punch = files.index("ball_punch.png")
     # sprite sizes as the reference's surfaces report them
     sizes = {}
     for row in d["frame_draw"].reshape(-1, 6):
-        if row[0] >= 0 and files[row[0]] in fid and files[row[0]] != "cloud.png":
+        if row[0] >= 0 and files[row[0]] in fid and files[row[0]] not in ("cloud.png", "ball_punch.png"):
             sizes.setdefault(fid[files[row[0]]], (int(row[4]), int(row[5])))
-    sizes[ro.SPRITE_CLOUD] = (48, 24)
+    sizes[ro.SPRITE_CLOUD], sizes[ro.SPRITE_PUNCH] = (48, 24), (40, 40)
     size_list = [sizes.get(i, (0, 0)) for i in range(ro.SPRITE_COUNT)]
     seen = set()
 
-    def on_frame(k, lane, col, scenery):
-        want = [tuple(int(v) for v in r) for r in d["frame_draw"][k][:d["frame_count"][k]] if r[0] != punch]
+    def on_frame(k, lane, col, scenery, punch_drawn):
+        want = [tuple(int(v) for v in r) for r in d["frame_draw"][k][:d["frame_count"][k]]]
         want = [(fid[files[r[0]]],) + r[1:] for r in want]
-        got = ro.draw_list(col, size_list, scenery)
+        got = ro.draw_list(col, size_list, scenery, punch_drawn)
         assert got == want, (k, lane)
         seen.update(r[0] for r in got)
 
