@@ -708,7 +708,7 @@ class raw_env:
         ``uint8[m, 304, 432, 3]`` for the games `lanes` (an int sequence / tensor; default: every game, as long
         as that stays below 1 GiB); ``scalar_api`` envs get the reference's ``[304, 432, 3]`` numpy array.
         An env created with ``scenery=True`` also draws the clouds and waves -- and, like the reference's ``render()``,
-        then advances the env RNG of the games it draws (`lanes` must be distinct).  The punch effect is not drawn."""
+        then advances the env RNG of the games it draws (`lanes` must be distinct); it also draws the punch effect."""
         if self.render_mode is None:  # the reference warns and returns None (pikazoo_env.py:355-357)
             import warnings
 
