@@ -612,26 +612,31 @@ def test_step_many_equals_single_steps(oracle):
         va.unwrapped.step_many(torch.full((2, 2, 8), 18, dtype=torch.int32, device="cuda:0"))
 
 
-def test_large_batch_offsets(oracle):
-    """2^24 games in one launch (3 GB of state, 2 x 2.3 GB of observations): the 32-bit buffer offsets near
-    their upper range, checked against the oracle on slices at the start, middle and end of the batch."""
+@pytest.mark.parametrize("fmt", ["int32", "packed"])
+def test_large_batch_offsets(fmt, oracle):
+    """2^24 games in one launch (3 GB of state -- 0.6 GB packed --, 2 x 2.3 GB of observations): the 32-bit buffer
+    offsets near their upper range, through pz_step_random and pz_step (single-wave kernel / packed pair kernel),
+    checked against the oracle on slices at the start, middle and end of the batch."""
     n, seed, base, aseed = 1 << 24, 5, 3, 17
-    env = make_env(num_envs=n, seed=seed, env_id_base=base, winning_score=1)
+    env = make_env(num_envs=n, seed=seed, env_id_base=base, winning_score=1, state_format=fmt)
     raw = env.unwrapped
     env.reset()
-    for t in range(6):
+    for t in range(3):
         obs, rew, term, _, _ = env.step_random(aseed)
+    for t in range(3, 6):
+        obs, rew, term, _, _ = env.step(raw.random_actions(aseed, t))
+    state = raw.state  # (packed: one unpacked copy)
     for lo in (0, n // 2 - 256, n - 512):
         ref = oracle.OracleEnv(512, oracle.make_config(winning_score=1, seed=seed, env_id_base=base + lo))
         ref.reset()
         for t in range(6):
             a1, a2 = oracle.random_actions(512, base + lo, aseed, t)
             robs, rrew, rterm = ref.step(a1, a2)
-        assert np.array_equal(cpu(raw.state[:, lo:lo + 512]), ref.state), lo
+        assert np.array_equal(cpu(state[:, lo:lo + 512]), ref.state), lo
         assert np.array_equal(cpu(obs["player_1"][lo:lo + 512]), robs[0]), lo
         assert np.array_equal(cpu(obs["player_2"][lo:lo + 512]), robs[1]), lo
         assert np.array_equal(cpu(rew["player_2"][lo:lo + 512]), rrew[1]), lo
-    del env, raw, obs, rew, term
+    del env, raw, obs, rew, term, state
     torch.cuda.empty_cache()
 
 
