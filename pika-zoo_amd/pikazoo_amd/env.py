@@ -469,8 +469,9 @@ class raw_env:
                                              _ptr(m), self._obs[0].data_ptr(), self._obs[1].data_ptr(),
                                              self._stats_ptr(), self._stream()), "pz_reset")
         if self._scenery is not None:  # a new round clears the punch effect (physics.py:274-275); nothing to remember
-            rows = self._scenery[[69, 71, 72, 73, 74]]
-            self._scenery[[69, 71, 72, 73, 74]] = rows * (m == 0).to(rows.dtype) if m is not None else 0
+            words = [69, 71, 72, 73, 74]
+            keep = self._scenery[words, :self.num_envs] * (m == 0).to(torch.int32) if m is not None else 0
+            self._scenery[words, :self.num_envs] = keep
         if self.scalar_api:
             return self._pack_obs(), {a: {"score": self._scores[0].tolist()} for a in self.agents}
         return self._pack_obs(), self._infos()

@@ -164,3 +164,18 @@ def test_scenery_api_behaviour():
     assert torch.equal(other.render(lanes=[3, 5]), f2) and not torch.equal(f1, f2)
     with pytest.raises(ValueError):
         plain.load_state_dict(sd)
+    # a (masked) reset clears the punch effect and what the tracker remembers of the reset games only
+    odd = pikazoo_v0.env(num_envs=70, seed=3, render_mode="rgb_array", sprites=sprites, scenery=True, winning_score=1,
+                         auto_reset=False)
+    odd.reset()
+    for t in range(400):
+        odd.step(odd.random_actions(4, t))
+    sc = odd._scenery[:, :70].clone()
+    assert int((sc[69] > 0).sum()) > 0 and int(sc[73].sum()) > 0          # live punch effects, finished games
+    mask = torch.arange(70, device="cuda:0") % 2 == 0
+    odd.reset(mask=mask)
+    now = odd._scenery[:, :70]
+    assert bool((now[[69, 71, 72, 73, 74]][:, mask] == 0).all())
+    assert torch.equal(now[:, ~mask], sc[:, ~mask]) and torch.equal(now[:69], sc[:69])
+    odd.reset()
+    assert bool((odd._scenery[[69, 71, 72, 73, 74], :70] == 0).all())
