@@ -98,14 +98,14 @@ def parse_args():
 
 
 def make_env(shard, device, *, num_envs, p1_computer=False, p2_computer=False, wrappers=False, flight_tables=True,
-             state_format="int32"):
+             state_format="int32", obs16=False):
     from pikazoo_amd.wrappers import RewardByBallPosition, SimplifyAction
 
     env = pikazoo_v0.env(winning_score=15, serve="winner", is_player2_computer=p2_computer,
                          is_player1_computer=p1_computer,
                          num_envs=num_envs, device=device, seed=0, env_id_base=shard.env_id_base,
                          auto_reset=True, validate_actions=False, flight_tables=flight_tables,
-                         state_format=state_format)
+                         state_format=state_format, observation_dtype=torch.int16 if obs16 else torch.int32)
     if wrappers:
         env = SimplifyAction(env)
         env = RewardByBallPosition(env, WRAPPER_TABLE, 216, 176)
@@ -302,7 +302,7 @@ def cpu_baseline(args, raw_gpu, p2_computer, wrappers):
 
 
 def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=False, launch=None, steps=None,
-            warmup=None, burn=None, min_time=None, check_lanes=0, flight_tables=True, state_format="int32"):
+            warmup=None, burn=None, min_time=None, check_lanes=0, flight_tables=True, state_format="int32", obs16=False):
     num_envs = args.num_envs if num_envs is None else num_envs
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
@@ -310,7 +310,7 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     min_time = args.min_time if min_time is None else min_time
     launch = args.launch if launch is None else launch
     env = make_env(shard, device, num_envs=num_envs, p1_computer=args.p1_computer, p2_computer=p2_computer,
-                   wrappers=wrappers, flight_tables=flight_tables, state_format=state_format)
+                   wrappers=wrappers, flight_tables=flight_tables, state_format=state_format, obs16=obs16)
     raw = env.unwrapped
     env.reset()
     burn_in(raw, burn)
@@ -324,6 +324,8 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     per_step = BYTES_PER_ENV_STEP
     if state_format == "packed":
         per_step = BYTES_PER_ENV_STEP_PACKED_AI if (p2_computer or args.p1_computer) else BYTES_PER_ENV_STEP_PACKED
+    if obs16:
+        per_step -= 2 * 35 * 2  # int16 observation rows: 70 instead of 140 bytes per agent
     alg = per_step * num_envs
     res = {
         "wall_s": wall, "event_ms": run["event_ms"], "n_total": n_total, "timed_steps": run["timed_steps"],
@@ -533,6 +535,14 @@ def main():
                               dict(num_envs=524288, state_format="packed", steps=300, warmup=50, burn=512)),
             "int32_524288": ("524 288 games on one GPU, random/random, int32 state (config 4's batch on one GPU)",
                              dict(num_envs=524288, steps=300, warmup=50, burn=512)),
+            # opt-in int16 observations (the values of the int32 ones in half the bytes): 509 / 221 algorithmic bytes
+            "int16obs_headline": ("65 536 games, random/random, int32 state, int16 observations",
+                                  dict(num_envs=65536, obs16=True)),
+            "packed_int16obs_headline": ("65 536 games, random/random, packed state, int16 observations",
+                                         dict(num_envs=65536, state_format="packed", obs16=True)),
+            "packed_int16obs_524288": ("524 288 games on one GPU, random/random, packed state, int16 observations",
+                                       dict(num_envs=524288, state_format="packed", obs16=True, steps=300, warmup=50,
+                                            burn=512)),
         }
         # the flight tables are built once per device, outside every timed region: say what that costs
         from pikazoo_amd import env as _env

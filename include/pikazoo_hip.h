@@ -17,7 +17,8 @@
  *  - state is int32[PZ_STATE_WORDS][stride], field-major (structure of arrays): lane i
  *    (one independent game) owns column i; `n` lanes are live, stride >= n -- or, with
  *    cfg->packed_state, the bit-packed format below (36 bytes per game instead of 176);
- *  - observations are int32[n][35] row-major per agent (pikazoo_env.py:576-624);
+ *  - observations are int32[n][35] row-major per agent (pikazoo_env.py:576-624), or float32 / int16 rows as
+ *    cfg->normalize_obs names;
  *  - out-of-range actions are undefined behaviour here (the reference raises IndexError at
  *    pikazoo_env.py:182); the Python host validates them unless told not to.
  */
@@ -95,8 +96,11 @@ typedef struct pz_config {
     int32_t normal_state_mode;    /* RewardInNormalState (reward_in_normal_state.py:10-15): 0 off,
                                      1 applied before additional_reward, 2 after it */
     float   normal_state_reward;  /* its constant (reward_in_normal_state.py:8) */
-    int32_t normalize_obs;        /* NormalizeObservation (normalize_observation.py:18-35): observations
-                                     are float32 (obs - low) / (high - low) */
+    int32_t normalize_obs;        /* observation format: 0 int32 (the reference's Box dtype); 1 NormalizeObservation
+                                     (normalize_observation.py:18-35): float32 (obs - low) / (high - low); 2 int16: the
+                                     values of format 0 in 70-byte rows -- the observation tensors are the largest
+                                     stream a step writes, this halves them.  A format-2 tensor holds an EVEN number
+                                     of rows (n rounded up); k-frame launches then need n % 8 == 0 */
     int32_t episode_stats_mode;   /* RecordEpisodeStatistics (record_episode_statistics.py:27-40): 0 off,
                                      1 sums the env's own reward, 2 the fully wrapped reward */
     uint64_t seed;                /* Philox4x32-10 key of the env RNG stream */
@@ -182,7 +186,7 @@ int pz_reset(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
              const uint8_t *mask, int32_t *obs_p1, int32_t *obs_p2, void *episode_stats,
              void *stream);
 
-/* ---- raw_env._get_obs : pikazoo_env.py:576-624 (normalize != 0: NormalizeObservation on top) */
+/* ---- raw_env._get_obs : pikazoo_env.py:576-624 (normalize = the observation format, as cfg->normalize_obs) */
 int pz_observe(const int32_t *state, int64_t n, int64_t stride, int32_t normalize, int32_t packed,
                int32_t *obs_p1, int32_t *obs_p2, void *stream);
 
@@ -197,7 +201,7 @@ int pz_observe(const int32_t *state, int64_t n, int64_t stride, int32_t normaliz
  *                or the in-place auto reset). Used when cfg->episode_stats_mode != 0.  The returns are summed
  *                in float64 like the reference's Python floats (record_episode_statistics.py:31); float32
  *                rewards are widened before the add.
- * With cfg->normalize_obs the observation buffers receive float32 bit patterns.
+ * With cfg->normalize_obs == 1 the observation buffers receive float32 bit patterns, with 2 int16 rows.
  * tables: NULL, or the flight look-up tables above (used when a player is the computer). */
 int pz_step(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
             const int32_t *act_p1, const int32_t *act_p2,

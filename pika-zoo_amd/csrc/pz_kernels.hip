@@ -419,6 +419,43 @@ __device__ __forceinline__ void flush_rows(const int32_t* __restrict__ lds, cons
     }
 }
 
+// cfg.normalize_obs == 2: int16 observations.  The rows are staged as int32 like always and narrowed on the way out:
+// a lane reads eight staged values (two 16-byte LDS reads) and writes them as one 16-byte piece of the wave's
+// contiguous 64 x 70-byte span -- 5 passes instead of 9, half the bytes.  `tensor_bytes` covers an EVEN number of rows
+// (the caller pads an odd batch by one row): the last value of an odd row count shares its dword with the padding.
+constexpr uint32_t kWaveObsBytes16 = kLanes * PZ_OBS_DIM * 2;  // 4 480
+constexpr int kWaveObsVecs16 = (int)(kWaveObsBytes16 / 16);   // 280
+__device__ __forceinline__ void flush_rows16(const int32_t* __restrict__ lds, const void* tensor, uint32_t tensor_bytes,
+                                             int lane)
+{
+    const uint32_t wave_off = blockIdx.x * kWaveObsBytes16;
+    const Rsrc span = make_rsrc(static_cast<const char*>(tensor) + wave_off, tensor_bytes - wave_off);
+    const u32x4* src4 = reinterpret_cast<const u32x4*>(lds);
+#pragma unroll
+    for (int pass = 0; pass < (kWaveObsVecs16 + kLanes - 1) / kLanes; ++pass) {
+        const int v = pass * kLanes + lane;
+        if (v < kWaveObsVecs16) {
+            const u32x4 lo = src4[2 * v], hi = src4[2 * v + 1];
+            const u32x4 out = {(lo.x & 0xFFFFu) | (lo.y << 16), (lo.z & 0xFFFFu) | (lo.w << 16),
+                               (hi.x & 0xFFFFu) | (hi.y << 16), (hi.z & 0xFFFFu) | (hi.w << 16)};
+            __builtin_amdgcn_raw_buffer_store_b128(out, span, (uint32_t)v * 16u, 0, PZ_OBS_AUX);
+        }
+    }
+}
+
+// one agent's staged rows to frame `t` of its observation tensor, in the format cfg.normalize_obs names
+// (0: int32, 1: float32 bit patterns -- both 140-byte rows --, 2: int16, 70-byte rows of an even row count)
+__device__ __forceinline__ void flush_obs(const int32_t* __restrict__ lds, void* tensor, int64_t t, int64_t n, int format,
+                                          int lane)
+{
+    if (format == 2) {
+        const int64_t rows = (n + 1) & ~(int64_t)1;
+        flush_rows16(lds, static_cast<char*>(tensor) + t * rows * (PZ_OBS_DIM * 2), (uint32_t)(rows * (PZ_OBS_DIM * 2)), lane);
+    } else {
+        flush_rows(lds, static_cast<char*>(tensor) + t * n * kRowBytes, (uint32_t)n * kRowBytes, lane);
+    }
+}
+
 #ifdef PZ_STAMPS
 // Diagnostic build only (tools/stamps.py): per-wave timeline of one launch in 100 MHz ticks.
 __device__ unsigned long long g_pz_stamps[8192 * 8];
@@ -583,13 +620,13 @@ __device__ __forceinline__ void emit_outputs(const StepArgs& a, const Game& g, c
         __builtin_amdgcn_raw_buffer_store_b32(as_float ? __float_as_uint(r.f2) : (unsigned int)r.i2, rew2, voff, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, term, (uint32_t)i, 0, 0);
         PZ_STAMP(3);
-        if (!skip_obs) stage_obs(g, lds_obs[0], lds_obs[1], lane, a.cfg.normalize_obs != 0);
+        if (!skip_obs) stage_obs(g, lds_obs[0], lds_obs[1], lane, a.cfg.normalize_obs == 1);
     }
     __syncthreads();
     PZ_STAMP(4);
     if (!skip_obs) {
-        flush_rows(lds_obs[0], a.obs_p1 + t * a.n * PZ_OBS_DIM, n32 * kRowBytes, lane);
-        flush_rows(lds_obs[1], a.obs_p2 + t * a.n * PZ_OBS_DIM, n32 * kRowBytes, lane);
+        flush_obs(lds_obs[0], a.obs_p1, t, a.n, a.cfg.normalize_obs, lane);
+        flush_obs(lds_obs[1], a.obs_p2, t, a.n, a.cfg.normalize_obs, lane);
     }
 }
 
@@ -993,7 +1030,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         if (live) {
             const Player& me = ROLE == 0 ? g.p1 : g.p2;
             const Player& opp = ROLE == 0 ? g.p2 : g.p1;
-            if (a.cfg.normalize_obs)
+            if (a.cfg.normalize_obs == 1)
                 stage_one_obs_t<true>(me, opp, g.b, lds_obs[ROLE], lane);
             else
                 stage_one_obs_t<false>(me, opp, g.b, lds_obs[ROLE], lane);
@@ -1004,7 +1041,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         wave_lds_handover<false>();
         PZ_PAIR_STAMP(ROLE, 4);
         if (PZ_SKIP_OBS_STORES) return;
-        flush_rows(lds_obs[ROLE], ROLE == 0 ? a.obs_p1 : a.obs_p2, n32 * kRowBytes, lane);
+        flush_obs(lds_obs[ROLE], ROLE == 0 ? a.obs_p1 : a.obs_p2, 0, a.n, a.cfg.normalize_obs, lane);
         PZ_PAIR_STAMP(ROLE, 5);
     };
     // Interleaved A/B (tools/ab.py, us per launch, state first | observations first): human vs human 7.14 | 7.27,
@@ -1121,11 +1158,11 @@ __global__ __launch_bounds__(kLanes) void reset_kernel(int32_t* state, int64_t n
             if (episode_stats != nullptr)  // RecordEpisodeStatistics.reset (:23-25)
                 make_stats_io(episode_stats, true, stride, i).store(EpisodeStats{0.0, 0.0, 0});
         }
-        stage_obs(g, lds_obs[0], lds_obs[1], lane, cfg.normalize_obs != 0);
+        stage_obs(g, lds_obs[0], lds_obs[1], lane, cfg.normalize_obs == 1);
     }
     __syncthreads();
-    if (obs_p1 != nullptr) flush_rows(lds_obs[0], obs_p1, (uint32_t)n * kRowBytes, lane);
-    if (obs_p2 != nullptr) flush_rows(lds_obs[1], obs_p2, (uint32_t)n * kRowBytes, lane);
+    if (obs_p1 != nullptr) flush_obs(lds_obs[0], obs_p1, 0, n, cfg.normalize_obs, lane);
+    if (obs_p2 != nullptr) flush_obs(lds_obs[1], obs_p2, 0, n, cfg.normalize_obs, lane);
 }
 
 template <bool PACKED>
@@ -1139,11 +1176,11 @@ __global__ __launch_bounds__(kLanes) void observe_kernel(const int32_t* state, i
     if (i < n) {
         Game g;
         io.load(g);
-        stage_obs(g, lds_obs[0], lds_obs[1], lane, normalize != 0);
+        stage_obs(g, lds_obs[0], lds_obs[1], lane, normalize == 1);
     }
     __syncthreads();
-    if (obs_p1 != nullptr) flush_rows(lds_obs[0], obs_p1, (uint32_t)n * kRowBytes, lane);
-    if (obs_p2 != nullptr) flush_rows(lds_obs[1], obs_p2, (uint32_t)n * kRowBytes, lane);
+    if (obs_p1 != nullptr) flush_obs(lds_obs[0], obs_p1, 0, n, normalize, lane);
+    if (obs_p2 != nullptr) flush_obs(lds_obs[1], obs_p2, 0, n, normalize, lane);
 }
 
 __global__ __launch_bounds__(256) void random_actions_kernel(int32_t* act_p1, int32_t* act_p2, int64_t n,
@@ -1497,7 +1534,8 @@ static int check_common(const void* state, int64_t n, int64_t stride, const pz_c
     if (state == nullptr || cfg == nullptr) return PZ_E_NULL;
     if (n < 0 || stride < n || stride > kMaxLanesPerLaunch) return PZ_E_SIZE;
     if (cfg->winning_score < 1 || cfg->serve_mode < 0 || cfg->serve_mode > 2 || cfg->normal_state_mode < 0 ||
-        cfg->normal_state_mode > 2 || cfg->episode_stats_mode < 0 || cfg->episode_stats_mode > 2)
+        cfg->normal_state_mode > 2 || cfg->episode_stats_mode < 0 || cfg->episode_stats_mode > 2 ||
+        cfg->normalize_obs < 0 || cfg->normalize_obs > 2)
         return PZ_E_CONFIG;
 #ifndef PZ_ABLATE  // the timing-only build passes its switches in the upper bits of this field
     if (cfg->packed_state != 0 && cfg->packed_state != 1) return PZ_E_CONFIG;
@@ -1660,6 +1698,7 @@ int pz_observe(const int32_t* state, int64_t n, int64_t stride, int32_t normaliz
 {
     if (state == nullptr) return PZ_E_NULL;
     if (n < 0 || stride < n || stride > kMaxLanesPerLaunch) return PZ_E_SIZE;
+    if (normalize < 0 || normalize > 2) return PZ_E_CONFIG;
     if (misaligned16(obs_p1) || misaligned16(obs_p2) || (packed != 0 && misaligned16(state))) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
     if (packed != 0)
@@ -1737,7 +1776,8 @@ int pz_rollout_random(int32_t* state, int64_t n, int64_t stride, const pz_config
     if (!obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
     if (k < 1) return PZ_E_SIZE;
     // every frame's [n][35] slab must keep the 16-byte alignment of the vector stores: n * 140 % 16 == 0
-    if (misaligned16(obs_p1) || misaligned16(obs_p2) || (k > 1 && (n & 3) != 0)) return PZ_E_ALIGN;
+    if (misaligned16(obs_p1) || misaligned16(obs_p2) || (k > 1 && (n & (cfg->normalize_obs == 2 ? 7 : 3)) != 0))
+        return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
     StepArgs a{state,  n,          stride,        nullptr, nullptr, action_seed, t0, k, actions, obs_p1, obs_p2, rew_p1,
                rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), tables_of(tables),
@@ -1752,7 +1792,8 @@ int pz_step_many(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (!actions || !obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
     if (k < 1) return PZ_E_SIZE;
-    if (misaligned16(obs_p1) || misaligned16(obs_p2) || (k > 1 && (n & 3) != 0)) return PZ_E_ALIGN;
+    if (misaligned16(obs_p1) || misaligned16(obs_p2) || (k > 1 && (n & (cfg->normalize_obs == 2 ? 7 : 3)) != 0))
+        return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
     StepArgs a{state,  n,          stride,        actions, nullptr, 0, 0, k, nullptr, obs_p1, obs_p2, rew_p1,
                rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), tables_of(tables),

@@ -104,7 +104,10 @@ class raw_env:
     ``scenery`` (with ``render_mode="rgb_array"``: draw the reference's clouds and waves too.  They are renderer-owned
     state driven by the env RNG, so -- exactly as in the reference, pikazoo_env.py:475-477, cloud_and_wave.py:53-78 --
     the constructor then draws 40 values behind the two boldness draws and every ``render()`` advances the RNG of the
-    games it draws; the punch effect is drawn too: its two ball attributes are tracked after every ``step()``, a k-frame
+    games it draws; ``observation_dtype`` (``torch.int32``: the reference's Box dtype; ``torch.int16``: the same
+    values in half the bytes -- observations are the largest stream a step writes, so large batches run up to a third
+    faster again; the fused ``NormalizeObservation`` emits float32 and cannot be combined with it).  With ``scenery``
+    the punch effect is drawn too: its two ball attributes are tracked after every ``step()``, a k-frame
     launch clears it; off by default, which keeps ``render()`` free of side effects and ``step()`` a single launch).
 
     Returned tensors are views of env-owned buffers that the next ``step`` overwrites;
@@ -117,7 +120,8 @@ class raw_env:
                  is_player2_computer: bool = False, render_mode=None, *, num_envs: int = 1,
                  device="cuda", seed: int = 0, env_id_base: int = 0, auto_reset: Optional[bool] = None,
                  validate_actions: bool = True, scalar_api: bool = False, flight_tables: bool = True,
-                 sprite_dir=None, sprites=None, state_format: str = "int32", scenery: bool = False):
+                 sprite_dir=None, sprites=None, state_format: str = "int32", scenery: bool = False,
+                 observation_dtype=torch.int32):
         assert serve in ("winner", "alternate", "random")  # pikazoo_env.py:104
         if render_mode not in (None, "rgb_array"):
             raise NotImplementedError('render_mode must be None or "rgb_array" (no "human" window on a GPU batch)')
@@ -127,6 +131,10 @@ class raw_env:
             raise ValueError("num_envs must be >= 1")
         if state_format not in ("int32", "packed"):
             raise ValueError('state_format must be "int32" or "packed"')
+        if observation_dtype in ("int16", "int32"):
+            observation_dtype = getattr(torch, observation_dtype)
+        if observation_dtype not in (torch.int32, torch.int16):
+            raise ValueError("observation_dtype must be torch.int32 or torch.int16")
         if scenery and render_mode is None:
             raise ValueError('scenery=True needs render_mode="rgb_array"')
         if state_format == "packed" and int(winning_score) > 32767:
@@ -170,6 +178,7 @@ class raw_env:
         cfg.x_line, cfg.y_line = 216, 176
         cfg.auto_reset = int(self.auto_reset)
         cfg.packed_state = int(state_format == "packed")
+        cfg.normalize_obs = 2 if observation_dtype == torch.int16 else 0  # 0 int32, 1 float32 normalized, 2 int16
         cfg.seed = self.seed & 0xFFFFFFFFFFFFFFFF
         cfg.env_id_base = self.env_id_base
         self._cfg = cfg
@@ -345,8 +354,10 @@ class raw_env:
 
     def _fuse_normalize_obs(self):
         """wrappers/normalize_observation.py:18-35 inside the kernel: observations become float32."""
-        if self._cfg.normalize_obs:
+        if self._cfg.normalize_obs == 1:
             raise RuntimeError("NormalizeObservation is already applied")
+        if self._cfg.normalize_obs == 2:
+            raise NotImplementedError("NormalizeObservation emits float32: create the env with observation_dtype=torch.int32")
         self._cfg.normalize_obs = 1
 
     def _fuse_episode_stats(self):
@@ -380,10 +391,19 @@ class raw_env:
 
     @property
     def obs_dtype(self):
-        return torch.float32 if self._cfg.normalize_obs else torch.int32
+        return (torch.int32, torch.float32, torch.int16)[self._cfg.normalize_obs]
 
-    def _obs_view(self, i):
-        return self._obs[i] if not self._cfg.normalize_obs else self._obs[i].view(torch.float32)
+    def _obs_view(self, i, buf=None):
+        """The env-owned observation buffer of agent i (or `buf`, an int32 [n, 35] buffer) in the current format: the
+        int16 rows occupy the front of the same storage (an even number of them: include/pikazoo_hip.h)."""
+        buf = self._obs[i] if buf is None else buf
+        fmt = self._cfg.normalize_obs
+        if fmt == 0:
+            return buf
+        if fmt == 1:
+            return buf.view(torch.float32)
+        n = self.num_envs
+        return buf.view(torch.int16).view(-1)[:(n + 1) // 2 * 2 * _native.OBS_DIM].view(-1, _native.OBS_DIM)[:n]
 
     # ---- spaces (pikazoo_env.py:481-568) ----------------------------------------------------------
     def observation_space(self, agent=None):
@@ -391,7 +411,8 @@ class raw_env:
         # instance here (an lru_cache on the method would pin the env and its device tensors forever)
         sp = self._spaces.get("obs")
         if sp is None:
-            sp = self._spaces["obs"] = Box(low=OBS_LOW.copy(), high=OBS_HIGH.copy(), shape=(35,), dtype=np.int32)
+            dt = np.int16 if self._cfg.normalize_obs == 2 else np.int32
+            sp = self._spaces["obs"] = Box(low=OBS_LOW.astype(dt), high=OBS_HIGH.astype(dt), shape=(35,), dtype=dt)
         return sp
 
     def normalized_observation_space(self, agent=None):
@@ -568,12 +589,12 @@ class raw_env:
         k, n, dev = int(k), self.num_envs, self.device
         if k < 1:
             raise ValueError("k must be >= 1")
-        if k > 1 and n % 4 != 0:
-            raise ValueError("rollout_random needs num_envs to be a multiple of 4")
+        if k > 1 and n % self._traj_multiple() != 0:
+            raise ValueError(f"rollout_random needs num_envs to be a multiple of {self._traj_multiple()}")
         if out is None or out["_k"] != k:
             out = {"_k": k,
                    "actions": torch.empty((k, 2, n), dtype=torch.int32, device=dev),
-                   "_obs": [torch.empty((k, n, _native.OBS_DIM), dtype=torch.int32, device=dev) for _ in range(2)],
+                   "_obs": [torch.empty((k, n, _native.OBS_DIM), dtype=self._traj_obs_dtype(), device=dev) for _ in range(2)],
                    "_rew": [torch.empty((k, n), dtype=torch.int32, device=dev) for _ in range(2)],
                    "_term": torch.empty((k, n), dtype=torch.uint8, device=dev)}
         with torch.cuda.device(dev):
@@ -597,13 +618,13 @@ class raw_env:
         if actions.dtype != torch.int32 or actions.device != dev or not actions.is_contiguous():
             actions = actions.to(device=dev, dtype=torch.int32).contiguous()
         k = int(actions.shape[0])
-        if k > 1 and n % 4 != 0:
-            raise ValueError("step_many needs num_envs to be a multiple of 4")
+        if k > 1 and n % self._traj_multiple() != 0:
+            raise ValueError(f"step_many needs num_envs to be a multiple of {self._traj_multiple()}")
         if self.validate_actions and (int(actions.min().item()) < 0 or int(actions.max().item()) >= self.n_actions):
             raise IndexError(f"action out of range [0, {self.n_actions})")
         if out is None or out["_k"] != k:
             out = {"_k": k,
-                   "_obs": [torch.empty((k, n, _native.OBS_DIM), dtype=torch.int32, device=dev) for _ in range(2)],
+                   "_obs": [torch.empty((k, n, _native.OBS_DIM), dtype=self._traj_obs_dtype(), device=dev) for _ in range(2)],
                    "_rew": [torch.empty((k, n), dtype=torch.int32, device=dev) for _ in range(2)],
                    "_term": torch.empty((k, n), dtype=torch.uint8, device=dev)}
         out["actions"] = actions
@@ -618,15 +639,22 @@ class raw_env:
         self.steps_done += k
         return self._finish_trajectory(out)
 
+    def _traj_multiple(self):
+        """every frame's observation slab of a trajectory launch must stay 16-byte aligned: 140- resp. 70-byte rows"""
+        return 8 if self._cfg.normalize_obs == 2 else 4
+
+    def _traj_obs_dtype(self):
+        return torch.int16 if self._cfg.normalize_obs == 2 else torch.int32
+
     def _finish_trajectory(self, out):
         dt, odt = self.reward_dtype, self.obs_dtype
         rew = [r if dt == torch.int32 else r.view(torch.float32) for r in out["_rew"]]
-        out["obs"] = dict(zip(self.possible_agents, [o if odt == torch.int32 else o.view(odt) for o in out["_obs"]]))
+        out["obs"] = dict(zip(self.possible_agents, [o if o.dtype == odt else o.view(odt) for o in out["_obs"]]))
         out["rewards"] = dict(zip(self.possible_agents, rew))
         out["terminations"] = out["_term"].view(torch.bool)
         # keep the single-frame views coherent with the last frame
-        self._obs[0].copy_(out["_obs"][0][-1])
-        self._obs[1].copy_(out["_obs"][1][-1])
+        self._obs_view(0).copy_(out["obs"][self.possible_agents[0]][-1])
+        self._obs_view(1).copy_(out["obs"][self.possible_agents[1]][-1])
         self._rew_raw[0].copy_(out["_rew"][0][-1])
         self._rew_raw[1].copy_(out["_rew"][1][-1])
         self._term_u8.copy_(out["_term"][-1])
@@ -652,8 +680,7 @@ class raw_env:
             _native.check(self._lib.pz_observe(self._state_ptr, self.num_envs, self._stride,
                                                int(self._cfg.normalize_obs), int(self._cfg.packed_state),
                                                o1.data_ptr(), o2.data_ptr(), self._stream()), "pz_observe")
-        odt = self.obs_dtype
-        return {self.possible_agents[0]: o1.view(odt), self.possible_agents[1]: o2.view(odt)}
+        return {self.possible_agents[0]: self._obs_view(0, o1), self.possible_agents[1]: self._obs_view(1, o2)}
 
     # ---- checkpoint: the state tensor + the fused-wrapper words + what the trajectory is keyed by -------------
     _CFG_KEYS = ("winning_score", "serve_mode", "p1_computer", "p2_computer", "simplify_action", "ballpos_reward",

@@ -258,7 +258,7 @@ def test_no_vmem_store_data_hazard_in_device_code(built_lib, tmp_path):
         lo, hi = int(m.group(1)), int(m.group(2))
         states = 0  # wait states since the store: the hazard needs one (gfx90a: two); `s_nop N` supplies N + 1
         for nxt in ins[k + 1:k + 3]:
-            if states >= 2:
+            if states >= 2 or nxt.startswith("s_endpgm"):  # (the next kernel's code follows an s_endpgm)
                 break
             nop = re.match(r"s_nop (\d+)", nxt)
             states += int(nop.group(1)) + 1 if nop else 1

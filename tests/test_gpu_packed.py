@@ -432,3 +432,62 @@ def test_k_frame_launches_from_planted_states(name, fmt):
         ref.rollout_random(3, 0, 17)
         assert np.array_equal(cpu(env.unwrapped.state), ref.state), mode
     assert np.array_equal(cpu(traj["obs"]["player_1"][-1]), ref.obs[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# int16 observations (cfg.normalize_obs == 2 / observation_dtype=torch.int16)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt", ["int32", "packed"])
+@pytest.mark.parametrize("n,kw", [(1, dict()), (63, dict(is_player2_computer=True)), (64, dict()),
+                                  (1001, dict(is_player1_computer=True, is_player2_computer=True, flight_tables=False)),
+                                  (4096 + 8, dict(is_player2_computer=True, winning_score=2))])
+def test_int16_observations_hold_the_int32_values(n, kw, fmt, oracle):
+    """The same run with int32 and with int16 observations: identical states / rewards / terminations, and every
+    observation equal value for value -- after reset, after pz_step (pair kernel), pz_step_random (single wave),
+    observe(), and against the oracle at the end.  Odd sizes included: an int16 tensor holds an even number of rows."""
+    base = dict(num_envs=n, seed=6, env_id_base=11, state_format=fmt, **kw)
+    a = make_env(**base)
+    b = make_env(observation_dtype=torch.int16, **base)
+    assert b.observation_space("player_1").dtype == np.int16
+    oa, ob = a.reset()[0], b.reset()[0]
+    for ag in ("player_1", "player_2"):
+        assert ob[ag].dtype == torch.int16 and ob[ag].shape == (n, 35) and torch.equal(oa[ag], ob[ag].to(torch.int32))
+    for t in range(80):
+        acts = a.random_actions(5, t)
+        xa, xb = (a.step(acts), b.step(acts)) if t % 3 else (a.step_random(5, t0=t), b.step_random(5, t0=t))
+        if t % 10 == 0 or t == 79:
+            for ag in ("player_1", "player_2"):
+                assert torch.equal(xa[0][ag], xb[0][ag].to(torch.int32)), (t, ag)
+                assert torch.equal(xa[1][ag], xb[1][ag])
+            assert torch.equal(xa[2]["player_1"], xb[2]["player_1"]) and torch.equal(a.state, b.state)
+    fa, fb = a.observe(), b.observe()
+    assert fb["player_2"].dtype == torch.int16 and torch.equal(fa["player_2"], fb["player_2"].to(torch.int32))
+    okw = {k: v for k, v in kw.items() if k != "flight_tables"}
+    ref = oracle.OracleEnv(n, oracle.make_config(seed=6, env_id_base=11, **okw), nthreads=2)
+    ref.reset()
+    ref.rollout_random(5, 0, 80)
+    assert np.array_equal(cpu(b.state), ref.state) and np.array_equal(cpu(xb[0]["player_1"]).astype(np.int32), ref.obs[0])
+
+
+@pytest.mark.parametrize("fmt", ["int32", "packed"])
+def test_int16_observations_in_the_trajectory_launches(fmt):
+    n, k = 4096, 19
+    base = dict(num_envs=n, seed=9, is_player2_computer=True, winning_score=3, state_format=fmt)
+    a, b = make_env(**base), make_env(observation_dtype=torch.int16, **base)
+    a.reset(), b.reset()
+    ta, tb = a.rollout_random(4, k), b.rollout_random(4, k)
+    assert tb["obs"]["player_1"].dtype == torch.int16 and tb["obs"]["player_1"].shape == (k, n, 35)
+    for ag in ("player_1", "player_2"):
+        assert torch.equal(ta["obs"][ag], tb["obs"][ag].to(torch.int32)) and torch.equal(ta["rewards"][ag], tb["rewards"][ag])
+    tape = ta["actions"].clone()
+    ta, tb = a.step_many(tape), b.step_many(tape)
+    assert torch.equal(ta["obs"]["player_2"], tb["obs"]["player_2"].to(torch.int32)) and torch.equal(a.state, b.state)
+    # the single-frame views follow the last frame
+    assert torch.equal(b.observe()["player_1"], tb["obs"]["player_1"][-1])
+    odd = make_env(num_envs=4100, observation_dtype=torch.int16, state_format=fmt)   # 4100 % 8 != 0
+    odd.reset()
+    with pytest.raises(ValueError, match="multiple of 8"):
+        odd.rollout_random(1, 4)
+    from pikazoo_amd.wrappers import NormalizeObservation
+    with pytest.raises(NotImplementedError):
+        NormalizeObservation(odd)

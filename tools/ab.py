@@ -6,7 +6,7 @@ rounds in ONE process, median and min reported).
     python tools/ab.py [--ai] [--n 65536] [--rollout K] name1 name2 ...    # on the GPU box: time them
                                                                            # (--rollout: pz_rollout_random, K frames/launch)
     a name with the suffix "+t" runs that library WITH the flight look-up tables (pz_flight_tables), "+p" on the
-    packed state format, "+tp" both, e.g. `python tools/ab.py --ai base base+t base+tp`
+    packed state format, "+h" with int16 observations, combined at will, e.g. `python tools/ab.py --ai base base+t base+tph`
 
 A variant named "base" is always built with no extra flags.  Libraries go to
 pika-zoo_amd/lib/ab_<name>.so (git-ignored, shipped by gpurun).
@@ -85,10 +85,14 @@ def main():
     for nm in names:
         c = cfgs[nm] = _native.PzConfig.from_buffer_copy(cfg)
         c.packed_state = int("p" in mods(nm))
+        if "h" in mods(nm):
+            c.normalize_obs = 2  # int16 observations
     # every variant owns its state buffer and initialises it itself: variants may differ in the state's layout
     states = {nm: (torch.zeros(36 * n, dtype=torch.uint8, device=dev) if "p" in mods(nm)
                    else torch.zeros((44, n), dtype=torch.int32, device=dev)) for nm in names}
-    obs = [torch.zeros((n, 35), dtype=torch.int32, device=dev) for _ in range(2)]
+    obs32 = [torch.zeros((n, 35), dtype=torch.int32, device=dev) for _ in range(2)]
+    obs16 = [torch.zeros(((n + 1) // 2 * 2, 35), dtype=torch.int16, device=dev) for _ in range(2)]
+    obs = obs32
     rew = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
     term = torch.zeros(n, dtype=torch.uint8, device=dev)
     # --slices N: distinct action slices cycled through (default 64 = 32 MB at 65 536 games, cache-resident; bench.py's
@@ -105,6 +109,7 @@ def main():
         tables = _native.PzFlightTables(t_land.data_ptr(), t_hit.data_ptr())
     for nm in names:
         assert libs[nm].pz_init(states[nm].data_ptr(), n, n, C.byref(cfgs[nm]), stream) == 0
+        obs = obs16 if "h" in mods(nm) else obs32
         assert libs[nm].pz_reset(states[nm].data_ptr(), n, n, C.byref(cfgs[nm]), None, obs[0].data_ptr(), obs[1].data_ptr(),
                                  None, stream) == 0
 
@@ -120,6 +125,7 @@ def main():
         state = states[nm]
         tb = C.byref(tables) if "t" in mods(nm) else None
         cfg = cfgs[nm]
+        obs = obs16 if "h" in mods(nm) else obs32
         if rollout:
             for j in range(max(1, steps // rollout)):
                 rc = lib.pz_rollout_random(state.data_ptr(), n, n, C.byref(cfg), 7, j * rollout, rollout,
@@ -146,8 +152,9 @@ def main():
         states[nm].copy_(snapshots[nm])
         run(nm, 128)
         torch.cuda.synchronize()
+        o = obs16 if "h" in mods(nm) else obs32
         finals[nm] = ((t_obs[0].clone(), t_obs[1].clone(), t_rew[0].clone(), t_term.clone()) if rollout
-                      else (obs[0].clone(), obs[1].clone(), rew[0].clone(), term.clone()))
+                      else (o[0][:n].to(torch.int32), o[1][:n].to(torch.int32), rew[0].clone(), term.clone()))
     for nm in names:
         same = all(torch.equal(a, b) for a, b in zip(finals[nm], finals["base"]))
         print(f"  {nm}: trajectory (observations, rewards, terminations) identical to base: {same}")
