@@ -84,6 +84,8 @@ def parse_args():
     ap.add_argument("--state-format", choices=["int32", "packed"], default="int32",
                     help="headline run: state as int32[44, N] columns (BASELINE's contract, default) or in the packed "
                          "36-byte format (SURVEY 8(f)-3)")
+    ap.add_argument("--int16-obs", action="store_true",
+                    help="headline run with int16 observations (same values, half the bytes; default int32 like the reference's Box)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall budget of the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on CPU baseline threads")
     ap.add_argument("--check-lanes", type=int, default=2048, help="lanes replayed on the CPU oracle for parity")
@@ -504,7 +506,7 @@ def main():
 
     main_res = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers,
                        check_lanes=args.check_lanes if single else 0, flight_tables=tables,
-                       state_format=args.state_format)
+                       state_format=args.state_format, obs16=args.int16_obs)
     raw_main = main_res.pop("raw")
     cpu = None
     if single and not args.no_cpu:
@@ -589,6 +591,8 @@ def main():
             wl = f"random_random_{args.num_envs}"
         if args.state_format == "packed":
             wl = "packed_" + wl
+        if args.int16_obs:
+            wl += "_int16obs"
         traffic = load_traffic(wl, args.num_envs)
         launch_s = main_res["launch_us"] * 1e-6
         out = {
@@ -596,7 +600,7 @@ def main():
             "value": main_res["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": main_res["wall_us_per_step"] * 1e-3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
-            "state_format": args.state_format,
+            "state_format": args.state_format, "observation_dtype": "int16" if args.int16_obs else "int32",
             "data": "synthetic",
             "timed_steps": main_res["timed_steps"], "replays": main_res["replays"],
             "launches_per_replay": main_res["launches_per_replay"], "timed_seconds": main_res["wall_s"],

@@ -25,6 +25,8 @@ TRAFFIC = {
     "random_random_524288": ("big", "pz::step_kernel<false, false, 0, true, 0, false>"),
     "packed_random_random": ("pk", "pz::step_pair_kernel<false, false, true>"),
     "packed_random_random_524288": ("pkbig", "pz::step_pair_kernel<false, false, true>"),
+    "packed_random_random_int16obs": ("ph", "pz::step_pair_kernel<false, false, true>"),
+    "packed_random_random_524288_int16obs": ("phbig", "pz::step_pair_kernel<false, false, true>"),
 }
 
 
@@ -62,7 +64,7 @@ def main():
                       f"{e.get('valu_active_lane_share', 0):.2f}, VALU issue {e.get('valu_issue_share_of_wave_cycles', 0):.3f}, "
                       f"waiting {e.get('sq_wait_any_share', 0):.2f}, waves/busy cycle "
                       f"{e.get('avg_waves_resident_per_busy_SQ_cycle', 0):.1f}")
-    for name in ("kt", "big_kt", "pkbig_kt", "roll"):
+    for name in ("kt", "big_kt", "pkbig_kt", "phbig_kt", "roll"):
         p = src / f"{tag}_{name}_step_kernels_by_grid.csv"
         if p.exists():
             for row in csv.DictReader(p.open()):

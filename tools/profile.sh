@@ -9,6 +9,7 @@
 #   kt_roll   --kernel-trace --stats of pz_rollout_random / pz_step_many (k = 32)
 #   pmc_pk    the four passes on the headline workload with the packed state format (65 536 games)
 #   pmc_pkbig FETCH_SIZE / WRITE_SIZE / kernel stats at 524 288 games with the packed state format
+#   pmc_ph    FETCH_SIZE / WRITE_SIZE / kernel stats: packed state + int16 observations, 65 536 and 524 288 games
 #
 # Every PMC pass is its own rocprofv3 run with --kernel-trace only (MI355X_MICROARCH.md, rocprofv3 PMC slots:
 # FETCH_SIZE and WRITE_SIZE do not fit one pass; gpurun refuses --pmc together with the API trace domains).
@@ -16,7 +17,7 @@
 set -u
 TAG=${1:?tag}
 shift
-SECTIONS=${*:-kt pmc_hh pmc_cfg3 pmc_cfg3c pmc_big kt_roll pmc_pk pmc_pkbig}
+SECTIONS=${*:-kt pmc_hh pmc_cfg3 pmc_cfg3c pmc_big kt_roll pmc_pk pmc_pkbig pmc_ph}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -56,6 +57,13 @@ for s in $SECTIONS; do
         run pkbig_fetch --kernel-trace --pmc FETCH_SIZE -- $PY bench.py --no-cpu --no-configs --state-format packed --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
         run pkbig_write --kernel-trace --pmc WRITE_SIZE -- $PY bench.py --no-cpu --no-configs --state-format packed --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
         run pkbig_kt --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --state-format packed --num-envs 524288 --steps 300 --warmup 50 --burn-in 256 --launch cabi || exit 1
+        ;;
+    pmc_ph)
+        run ph_fetch --kernel-trace --pmc FETCH_SIZE -- $PY bench.py --no-cpu --no-configs --state-format packed --int16-obs --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1
+        run ph_write --kernel-trace --pmc WRITE_SIZE -- $PY bench.py --no-cpu --no-configs --state-format packed --int16-obs --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1
+        run phbig_fetch --kernel-trace --pmc FETCH_SIZE -- $PY bench.py --no-cpu --no-configs --state-format packed --int16-obs --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
+        run phbig_write --kernel-trace --pmc WRITE_SIZE -- $PY bench.py --no-cpu --no-configs --state-format packed --int16-obs --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
+        run phbig_kt --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --state-format packed --int16-obs --num-envs 524288 --steps 300 --warmup 50 --burn-in 256 --launch cabi || exit 1
         ;;
     kt_roll) run roll --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --rollouts || exit 1 ;;
     *) echo "unknown section $s"; exit 2 ;;
