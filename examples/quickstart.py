@@ -57,10 +57,11 @@ def main():
     print(f"rollout_random: {n * 32 * 50 / (time.perf_counter() - t0) / 1e9:.2f} G env-steps/s; "
           f"trajectory obs {tuple(out['obs']['player_1'].shape)}")
 
-    # a larger batch in the packed state format (36 instead of 176 bytes of state per game; same results): this is where
-    # the step launch streams HBM, and a third fewer bytes are a third less time
-    for fmt in ("int32", "packed"):
-        big = pikazoo_v0.env(num_envs=524288, device="cuda:0", seed=0, validate_actions=False, state_format=fmt)
+    # a larger batch in the packed state format (36 instead of 176 bytes of state per game; same results) and with int16
+    # observations (same values, half the bytes): this is where the step launch streams HBM, and fewer bytes are less time
+    for fmt, odt in (("int32", torch.int32), ("packed", torch.int32), ("packed", torch.int16)):
+        big = pikazoo_v0.env(num_envs=524288, device="cuda:0", seed=0, validate_actions=False, state_format=fmt,
+                             observation_dtype=odt)
         big.reset()
         acts = big.random_actions(action_seed=7)
         for _ in range(20):
@@ -70,7 +71,8 @@ def main():
         for _ in range(200):
             big.step(acts)
         torch.cuda.synchronize()
-        print(f"524 288 games, state_format={fmt}: {524288 * 200 / (time.perf_counter() - t0) / 1e9:.1f} G env-steps/s")
+        print(f"524 288 games, state_format={fmt}, observations {str(odt).split('.')[-1]}: "
+              f"{524288 * 200 / (time.perf_counter() - t0) / 1e9:.1f} G env-steps/s")
         del big
 
     # rgb_array frames of a few games, drawn on the GPU from the state.  The sprites are the reference's PNG files:
