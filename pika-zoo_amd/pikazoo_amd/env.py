@@ -689,6 +689,7 @@ class raw_env:
 
     def _cfg_dict(self):
         d = {k: getattr(self._cfg, k) for k in self._CFG_KEYS}
+        d["normalize_obs"] = int(self._cfg.normalize_obs == 1)  # (int32 vs int16 observations: same trajectory)
         d["additional_reward"] = [float(v) for v in self._cfg.additional_reward]
         return d
 
