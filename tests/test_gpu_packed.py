@@ -491,3 +491,75 @@ def test_int16_observations_in_the_trajectory_launches(fmt):
     from pikazoo_amd.wrappers import NormalizeObservation
     with pytest.raises(NotImplementedError):
         NormalizeObservation(odd)
+
+
+def _random_valid_states(n, rng):
+    """int32[44, n]: every attribute at random over its valid range (players' (y, y_velocity) from the pairs a jump or
+    a dive passes through), half of the balls next to a player -- the whole state space, reachable or not."""
+    st = np.zeros((44, n), np.int32)
+    for base, lo, hi in ((0, 32, 184), (13, 248, 400)):
+        st[base + 0] = rng.integers(lo, hi + 1, n)
+        st[base + 3] = rng.integers(0, 5, n)
+        steps = rng.integers(0, 33, n)
+        v0 = np.where(rng.random(n) < 0.7, -16, -5)
+        y, v = np.full(n, 244), v0.copy()
+        for k in range(33):
+            move = (k < steps) & (y + v <= 244)
+            y, v = np.where(move, y + v, y), np.where(move, v + 1, v)
+        ground = np.isin(st[base + 3], (0, 4)) & (rng.random(n) < 0.7)
+        st[base + 1], st[base + 2] = np.where(ground, 244, y), np.where(ground, 0, v)
+        st[base + 4] = rng.integers(0, 5, n)
+        st[base + 5] = rng.choice([-1, 1], n)
+        st[base + 6] = rng.integers(0, 6, n)
+        st[base + 7] = rng.integers(-1, 2, n)
+        st[base + 8] = rng.integers(-1, 4, n)
+        st[base + 9] = rng.integers(0, 2, n)
+        st[base + 10] = rng.integers(0, 5, n)
+        st[base + 11] = rng.integers(0, 2, n)
+        st[base + 12] = rng.integers(0, 2, n)
+    near = rng.random(n) < 0.5
+    who = rng.random(n) < 0.5
+    px, py = np.where(who, st[0], st[13]), np.where(who, st[1], st[14])
+    st[26] = np.where(near, np.clip(px + rng.integers(-40, 41, n), 20, 432), rng.integers(20, 433, n))
+    st[27] = np.where(near, np.clip(py + rng.integers(-40, 41, n), 0, 252), rng.integers(0, 253, n))
+    st[28] = rng.integers(-20, 21, n)
+    st[29] = np.where(rng.random(n) < 0.8, rng.integers(-120, 121, n), rng.integers(-300, 301, n))
+    st[30] = rng.integers(0, 2, n)
+    st[31], st[32] = rng.integers(20, 433, n), rng.integers(-100, 253, n)
+    st[33], st[34] = rng.integers(20, 433, n), rng.integers(-100, 253, n)
+    st[35] = rng.integers(0, 51, n)
+    st[36] = rng.integers(20, 433, n)
+    st[37] = rng.integers(20, 433, n)
+    st[38], st[39] = rng.integers(0, 3, n), rng.integers(0, 3, n)
+    st[40] = rng.integers(0, 2, n)
+    st[43] = rng.integers(4, 1 << 20, n)
+    return st
+
+
+@pytest.mark.parametrize("fmt", ["int32", "packed"])
+@pytest.mark.parametrize("kw", [dict(), dict(is_player1_computer=True, is_player2_computer=True),
+                                dict(is_player2_computer=True, serve="random", flight_tables=False)])
+def test_whole_state_space_at_scale_vs_oracle(kw, fmt, oracle):
+    """262 144 random valid states (the fixtures hold 2 400 stepped by the reference itself; this is the same
+    generator at scale against the oracle, which the live tests tie to the reference on such states): 12 frames of
+    pz_step, every word of every game, both state formats."""
+    n, frames = 262144, 12
+    rng = np.random.default_rng(20241011)
+    planted = _random_valid_states(n, rng)
+    env = make_env(num_envs=n, seed=15, env_id_base=1 << 21, winning_score=3, state_format=fmt, **kw)
+    raw = env.unwrapped
+    raw.set_state(torch.as_tensor(planted, device=raw.device))
+    okw = {k: v for k, v in kw.items() if k != "flight_tables"}
+    ref = oracle.OracleEnv(n, oracle.make_config(winning_score=3, seed=15, env_id_base=1 << 21, **okw), nthreads=16)
+    ref.state[:] = planted
+    for t in range(frames):
+        acts = raw.random_actions(8, t)
+        obs = env.step(acts)[0]
+        ref.step(cpu(acts["player_1"]), cpu(acts["player_2"]))
+        if t % 4 == 3:
+            hs = cpu(raw.state)
+            if not np.array_equal(hs, ref.state):
+                f, l = np.argwhere(hs != ref.state)[0]
+                pytest.fail(f"frame {t} lane {l} word {oracle.FIELD_NAMES[f]}: hip {hs[f, l]} != oracle {ref.state[f, l]}; "
+                            f"planted {planted[:, l].tolist()}")
+    assert np.array_equal(cpu(obs["player_1"]), ref.obs[0]) and np.array_equal(cpu(obs["player_2"]), ref.obs[1])
