@@ -613,6 +613,9 @@ def main():
                             f"auto-reset, p1_computer={args.p1_computer}, p2_computer={args.p2_computer}, "
                             f"fused_wrappers={args.wrappers}",
                 "num_envs_per_gpu": args.num_envs, "num_envs_total": main_res["n_total"],
+                # the K + W action slices are distinct and streamed from HBM: a long tape (default 1.2 GB) is read cold,
+                # a short one (--steps 20: 13 MB) stays in the caches like actions a policy has just written
+                "action_tape_bytes": (args.steps + args.warmup) * 2 * 4 * args.num_envs,
                 "launch": args.launch,
                 "kernel": kernel_name(args.num_envs, args.p2_computer or args.p1_computer, tables,
                                       args.state_format == "packed"),
