@@ -380,10 +380,11 @@ def measure_rollout(args, shard, device, k, tape=False, p2_computer=False):
             "bytes_per_game_step": bytes_per_step, "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS}
 
 
-def measure_policy_in_the_loop(args, shard, device, launches=2048):
+def measure_policy_in_the_loop(args, shard, device, launches=2048, fused=False):
     """The reference's own benchmark loop, literally: sample both agents' actions, then step -- here the policy
     kernel (pz_random_actions, uniform random like ``action_space.sample()``) and pz_step alternate inside one hipGraph,
-    so every step's actions have just been written (cache-hot) and the policy launch is part of the timed region."""
+    so every step's actions have just been written (cache-hot) and the policy launch is part of the timed region.
+    fused=True: the same loop as ONE launch per step -- pz_step_random(k=1) draws the policy inside the step kernel."""
     env = make_env(shard, device, num_envs=args.num_envs, p1_computer=args.p1_computer)
     raw = env.unwrapped
     lib = _native.load()
@@ -397,9 +398,13 @@ def measure_policy_in_the_loop(args, shard, device, launches=2048):
     def loop(stream, t0):
         s = stream.cuda_stream
         for t in range(t0, t0 + launches):
-            rc = lib.pz_random_actions(a1.data_ptr(), a2.data_ptr(), n, raw.env_id_base, ACTION_SEED, t, raw.n_actions, s)
-            rc = rc or lib.pz_step(p[0], n, raw._stride, raw._cfg_ref, a1.data_ptr(), a2.data_ptr(), p[1], p[2], p[3],
-                                   p[4], p[5], None, raw._tables_ref, s)
+            if fused:
+                rc = lib.pz_step_random(p[0], n, raw._stride, raw._cfg_ref, ACTION_SEED, t, 1, p[1], p[2], p[3], p[4], p[5],
+                                        None, raw._episodes.data_ptr(), raw._tables_ref, s)
+            else:
+                rc = lib.pz_random_actions(a1.data_ptr(), a2.data_ptr(), n, raw.env_id_base, ACTION_SEED, t, raw.n_actions, s)
+                rc = rc or lib.pz_step(p[0], n, raw._stride, raw._cfg_ref, a1.data_ptr(), a2.data_ptr(), p[1], p[2], p[3],
+                                       p[4], p[5], None, raw._tables_ref, s)
             if rc:
                 _native.check(rc, "policy + step")
 
@@ -420,8 +425,9 @@ def measure_policy_in_the_loop(args, shard, device, launches=2048):
         ev1.record(stream)
         stream.synchronize()
     us = ev0.elapsed_time(ev1) * 1e3 / (reps * launches)
-    return {"value": n / (us * 1e-6), "us_per_step": us, "launches_per_step": 2,
-            "note": "policy kernel + step kernel per step, both inside the timed region"}
+    return {"value": n / (us * 1e-6), "us_per_step": us, "launches_per_step": 1 if fused else 2,
+            "note": ("pz_step_random(k=1): the random policy drawn inside the step launch" if fused else
+                     "policy kernel + step kernel per step, both inside the timed region")}
 
 
 def load_traffic(workload_key, num_envs):
@@ -565,6 +571,7 @@ def main():
     extra = {}
     if args.extra and world == 1:
         extra["policy_in_the_loop"] = measure_policy_in_the_loop(args, shard, device)
+        extra["policy_fused_into_the_step"] = measure_policy_in_the_loop(args, shard, device, fused=True)
         extra["rollout_k32"] = measure_rollout(args, shard, device, k=32)
         extra["step_many_k32"] = measure_rollout(args, shard, device, k=32, tape=True)
         extra["rollout_k32_p2_computer"] = measure_rollout(args, shard, device, k=32, p2_computer=True)
