@@ -19,14 +19,14 @@ PROFILES = REPO / "profiles"
 
 # traffic.json key -> (section prefix of profile.sh, kernel)
 TRAFFIC = {
-    "random_random": ("hh", "pz::step_pair_kernel<false, false, false>"),
-    "cfg3": ("cfg3", "pz::step_pair_kernel<false, true, false>"),
+    "random_random": ("hh", "pz::step_pair_kernel<false, false, false, false>"),
+    "cfg3": ("cfg3", "pz::step_pair_kernel<false, true, false, false>"),
     "cfg3_compute": ("cfg3c", "pz::step_kernel<false, true, 0, true, 1, false>"),
     "random_random_524288": ("big", "pz::step_kernel<false, false, 0, true, 0, false>"),
-    "packed_random_random": ("pk", "pz::step_pair_kernel<false, false, true>"),
-    "packed_random_random_524288": ("pkbig", "pz::step_pair_kernel<false, false, true>"),
-    "packed_random_random_int16obs": ("ph", "pz::step_pair_kernel<false, false, true>"),
-    "packed_random_random_524288_int16obs": ("phbig", "pz::step_pair_kernel<false, false, true>"),
+    "packed_random_random": ("pk", "pz::step_pair_kernel<false, false, true, false>"),
+    "packed_random_random_524288": ("pkbig", "pz::step_pair_kernel<false, false, true, false>"),
+    "packed_random_random_int16obs": ("ph", "pz::step_pair_kernel<false, false, true, false>"),
+    "packed_random_random_524288_int16obs": ("phbig", "pz::step_pair_kernel<false, false, true, false>"),
 }
 
 
