@@ -158,7 +158,7 @@ int pz_unpack_state(const void *packed, int64_t n, int64_t packed_stride, int32_
 #define PZ_FT_YV_MAX 96
 #define PZ_FT_HIT_YV_MAX 64
 typedef struct pz_flight_tables {
-    const uint16_t *landing;     /* pz_flight_table_bytes(0) bytes, or NULL */
+    const uint16_t *landing;     /* pz_flight_table_bytes(0) bytes (the entries + 2 bytes of padding), 4-byte aligned, or NULL */
     const uint16_t *power_hit;   /* pz_flight_table_bytes(1) bytes, 16-byte aligned, or NULL */
 } pz_flight_tables;
 int64_t pz_flight_table_bytes(int32_t which);   /* 0: landing, 1: power_hit */

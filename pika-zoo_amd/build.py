@@ -34,13 +34,15 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
-def source_id() -> str:
+def source_id(extra_flags=()) -> str:
     """Digest of the sources and compiler flags the library is built from; baked into the library as
-    ``pz_build_id()`` so that a stale prebuilt .so (git-ignored, but shipped to the GPU box) is never run."""
+    ``pz_build_id()`` so that a stale prebuilt .so (git-ignored, but shipped to the GPU box) is never run.
+    `extra_flags` are part of it: a diagnostic variant (``-DPZ_ABLATE`` ...) written to the product path carries
+    another id than the product and is refused by ``_native.load()`` / rebuilt by ``needs_build()``."""
     h = hashlib.sha256()
     for d in DEPS:
         h.update(d.name.encode() + b"\0" + d.read_bytes() + b"\0")
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join([*FLAGS, *extra_flags]).encode())
     return h.hexdigest()[:16]
 
 
@@ -66,12 +68,12 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
-    if not force and not needs_build():
+    if not force and not extra_flags and not needs_build():
         return LIB
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     # compile to a temporary name and rename: other ranks / processes never see a half-written library
     tmp = LIB.with_suffix(f".so.tmp{os.getpid()}")
-    cmd = [hipcc_path(), *FLAGS, "-shared", "-fPIC", f'-DPZ_BUILD_ID="{source_id()}"',
+    cmd = [hipcc_path(), *FLAGS, "-shared", "-fPIC", f'-DPZ_BUILD_ID="{source_id(tuple(extra_flags))}"',
            f"-I{INCLUDE}", f"-I{CSRC}", *extra_flags, "-o", str(tmp), *map(str, SOURCES)]
     if verbose:
         print(" ".join(cmd), flush=True)

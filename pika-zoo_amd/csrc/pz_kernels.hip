@@ -132,7 +132,7 @@ __device__ __forceinline__ FlightLut make_lut(const pz_flight_tables& t)
     FlightLut lut;
     lut.has_landing = t.landing != nullptr;
     lut.has_power_hit = t.power_hit != nullptr;
-    lut.landing = make_rsrc(t.landing, lut.has_landing ? (uint32_t)(kFtLandingEntries * 2) : 0u);
+    lut.landing = make_rsrc(t.landing, lut.has_landing ? (uint32_t)kFtLandingBytes : 0u);
     lut.power_hit = make_rsrc(t.power_hit, lut.has_power_hit ? (uint32_t)(kFtHitEntries * 16) : 0u);
     return lut;
 }
@@ -296,7 +296,7 @@ __device__ __forceinline__ void store_game_packed(const Game& g, const PackedIO&
 __device__ __forceinline__ RngId make_rng_id(const pz_config& cfg, int64_t lane_index)
 {
     const uint64_t gid = (uint64_t)(cfg.env_id_base + lane_index);
-    return RngId{(uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32)};
+    return RngId{(uint32_t)gid, (uint32_t)(gid >> 32), make_schedule(cfg.seed)};
 }
 
 // ---- observation pack: _get_obs (pikazoo_env.py:576-624) ------------------------------------
@@ -521,6 +521,17 @@ struct Rewards {
     float f1, f2;    // after the fused reward wrappers
 };
 
+// one entry of RewardByBallPosition's table in a per-lane register, through an opaque move.  Indexing the kernel
+// argument with the (per-lane) zone is a global load from the kernarg segment -- and the compiler turns a select
+// over the eight scalars back into exactly that load -- whose wait also drains every store issued before it (gfx9
+// counts loads and stores in one in-order vmcnt): a dependent memory round trip in front of the reward store.
+__device__ __forceinline__ float zone_reward(const pz_config& cfg, int k)
+{
+    float v;
+    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(cfg.additional_reward[k]));
+    return v;
+}
+
 __device__ __forceinline__ Rewards shape_rewards(const pz_config& cfg, const Game& g, int reward, bool frozen)
 {
     Rewards r{reward, -reward, (float)reward, (float)(-reward)};
@@ -530,9 +541,10 @@ __device__ __forceinline__ Rewards shape_rewards(const pz_config& cfg, const Gam
         r.f2 = (r.f2 == 0.0f) ? cfg.normal_state_reward : r.f2;
     }
     if (cfg.ballpos_reward) {  // reward_by_ball_position.py:22-29: zone from the post-step ball position
-        const int zone = (g.b.y > cfg.y_line ? 1 : 0) + (g.b.x >= cfg.x_line ? 2 : 0);
-        r.f1 += cfg.additional_reward[zone];
-        r.f2 += cfg.additional_reward[4 + zone];
+        // additional_reward[i * 4 + zone], zone = (y > y_line) + 2 * (x >= x_line)
+        const bool low = g.b.y > cfg.y_line, right = g.b.x >= cfg.x_line;
+        r.f1 += right ? (low ? zone_reward(cfg, 3) : zone_reward(cfg, 2)) : (low ? zone_reward(cfg, 1) : zone_reward(cfg, 0));
+        r.f2 += right ? (low ? zone_reward(cfg, 7) : zone_reward(cfg, 6)) : (low ? zone_reward(cfg, 5) : zone_reward(cfg, 4));
     }
     if (cfg.normal_state_mode == 2) {  // the wrapper outside RewardByBallPosition
         r.f1 = (r.f1 == 0.0f) ? cfg.normal_state_reward : r.f1;
@@ -630,6 +642,133 @@ __device__ __forceinline__ void emit_outputs(const StepArgs& a, const Game& g, c
     }
 }
 
+// ---- outputs of one frame of a trajectory launch (kRollout / kTape) ------------------------------------------------
+// A lone wave issues in order, so whatever it waits for it waits for alone.  The single-frame flush (flush_rows) lets
+// the compiler pair every few LDS reads with their stores -- ten read -> wait -> store round trips per frame, a
+// quarter of the wave's cycles in SQ_WAIT_ANY (profiles/r03a_pmc_summary.json).  Here a frame's rows leave in three
+// steps: `stage` (rewards / flag / actions stored, rows written to LDS), then `flush`: all 18 16-byte pieces of both
+// tensors requested from LDS at once (72 VGPRs), independent work of the caller (the NEXT frame's policy draw), the
+// 18 stores back to back.  The slab pointers advance by one frame per frame; sizes are loop-invariant.
+// N stores the range check drops (empty descriptor): place holders in the in-order vmcnt, see step_kernel's frame loop
+template <int N>
+__device__ __forceinline__ void issue_dropped_stores()
+{
+    const Rsrc nowhere = make_rsrc(nullptr, 0u);
+#pragma unroll
+    for (int k = 0; k < N; ++k)  // (distinct, non-adjacent offsets: the compiler merges identical and adjacent stores)
+        __builtin_amdgcn_raw_buffer_store_b32(0u, nowhere, (uint32_t)k * 256u, 0, 0);
+}
+
+template <bool OBS16>
+struct TrajOut {
+    char *rew1, *rew2, *term, *act, *obs1, *obs2;  // this frame's slabs (obs: this wave's span of the slab)
+    uint32_t n32, obs_frame_bytes, obs_span_bytes; // games; bytes of one frame of an observation tensor; of it from the span on
+    uint32_t voff, ioff, piece_off[9];             // lane offsets: dword / byte outputs; the nine 16-byte pieces (~0u: none)
+
+    __device__ __forceinline__ void init(const StepArgs& a, int64_t i, int lane, bool live)
+    {
+        n32 = (uint32_t)a.n;
+        constexpr bool half = OBS16;  // int16 rows: 70 bytes, an even number of rows per frame
+        const uint32_t rows = half ? (uint32_t)((a.n + 1) & ~(int64_t)1) : n32;
+        const uint32_t wave_bytes = half ? kWaveObsBytes16 : kWaveObsBytes;
+        obs_frame_bytes = rows * (half ? (uint32_t)(PZ_OBS_DIM * 2) : kRowBytes);
+        const uint32_t wave_off = blockIdx.x * wave_bytes;
+        obs_span_bytes = obs_frame_bytes - wave_off;
+        rew1 = static_cast<char*>(a.rew_p1);
+        rew2 = static_cast<char*>(a.rew_p2);
+        term = reinterpret_cast<char*>(a.terminated);
+        act = reinterpret_cast<char*>(a.act_out);
+        obs1 = reinterpret_cast<char*>(a.obs_p1) + wave_off;
+        obs2 = reinterpret_cast<char*>(a.obs_p2) + wave_off;
+        voff = live ? (uint32_t)i * 4u : ~0u;  // (rows past the end of the batch: dropped by the range check)
+        ioff = live ? (uint32_t)i : ~0u;
+        const int vecs = half ? kWaveObsVecs16 : kWaveObsVecs;
+#pragma unroll
+        for (int pass = 0; pass < 9; ++pass) {
+            const int v = pass * kLanes + lane;
+            piece_off[pass] = v < vecs ? (uint32_t)v * 16u : ~0u;
+        }
+    }
+    __device__ __forceinline__ void advance()
+    {
+        rew1 += n32 * 4u;
+        rew2 += n32 * 4u;
+        term += n32;
+        act += n32 * 8u;
+        obs1 += obs_frame_bytes;
+        obs2 += obs_frame_bytes;
+    }
+    // rewards, flag, (rollout) the actions taken; both agents' rows into LDS
+    __device__ __forceinline__ void stage(const StepArgs& a, const Game& g, const Rewards& r, bool as_float, bool live,
+                                          int a1, int a2, bool with_actions, int lane,
+                                          int32_t (*lds_obs)[kLanes * PZ_OBS_DIM])
+    {
+        if (with_actions) {
+            const Rsrc ao = make_rsrc(act, n32 * 8u);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a1, ao, voff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, voff, n32 * 4u, 0);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(as_float ? __float_as_uint(r.f1) : (unsigned int)r.i1,
+                                              make_rsrc(rew1, n32 * 4u), voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(as_float ? __float_as_uint(r.f2) : (unsigned int)r.i2,
+                                              make_rsrc(rew2, n32 * 4u), voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, make_rsrc(term, n32), ioff, 0, 0);
+        if (live) stage_obs(g, lds_obs[0], lds_obs[1], lane, a.cfg.normalize_obs == 1);
+        // the rows are read back by this wave only: its LDS instructions execute in issue order
+        wave_lds_handover<false>();
+    }
+    // both tensors' pieces requested from LDS at once, `between()` (independent work of the caller), then the stores
+    // (no SGPR offset on the 16-byte stores: see flush_rows).  The row format is a compile-time parameter here.  As a
+    // run-time branch it cost either way: with a store sequence per format the compiler sees a path through the frame
+    // with no row store at all (the two branches are lowered through a flag it cannot correlate) and sizes the wait
+    // for the computer player's loop-carried gathers for that path -- vmcnt(0), a full drain of the previous frame's
+    // stores per frame; with one shared store sequence the pieces go through 72 register copies per frame.
+    template <class Between>
+    __device__ __forceinline__ void flush(const int32_t (*lds_obs)[kLanes * PZ_OBS_DIM], int lane, Between&& between)
+    {
+        const u32x4* src1 = reinterpret_cast<const u32x4*>(lds_obs[0]);
+        const u32x4* src2 = reinterpret_cast<const u32x4*>(lds_obs[1]);
+        if constexpr (OBS16) {  // five pieces per tensor, each narrowed from two staged ones
+            u32x4 lo1[5], hi1[5], lo2[5], hi2[5];
+#pragma unroll
+            for (int pass = 0; pass < 5; ++pass) {
+                const int v = min(pass * kLanes + lane, kWaveObsVecs16 - 1);
+                lo1[pass] = src1[2 * v];
+                hi1[pass] = src1[2 * v + 1];
+                lo2[pass] = src2[2 * v];
+                hi2[pass] = src2[2 * v + 1];
+            }
+            between();
+            auto narrow = [](const u32x4 lo, const u32x4 hi) {
+                return u32x4{(lo.x & 0xFFFFu) | (lo.y << 16), (lo.z & 0xFFFFu) | (lo.w << 16),
+                             (hi.x & 0xFFFFu) | (hi.y << 16), (hi.z & 0xFFFFu) | (hi.w << 16)};
+            };
+            const Rsrc s1 = make_rsrc(obs1, obs_span_bytes), s2 = make_rsrc(obs2, obs_span_bytes);
+#pragma unroll
+            for (int pass = 0; pass < 5; ++pass)
+                __builtin_amdgcn_raw_buffer_store_b128(narrow(lo1[pass], hi1[pass]), s1, piece_off[pass], 0, PZ_OBS_AUX);
+#pragma unroll
+            for (int pass = 0; pass < 5; ++pass)
+                __builtin_amdgcn_raw_buffer_store_b128(narrow(lo2[pass], hi2[pass]), s2, piece_off[pass], 0, PZ_OBS_AUX);
+        } else {
+            u32x4 p1[9], p2[9];
+#pragma unroll
+            for (int pass = 0; pass < 9; ++pass) p1[pass] = src1[min(pass * kLanes + lane, kWaveObsVecs - 1)];
+#pragma unroll
+            for (int pass = 0; pass < 9; ++pass) p2[pass] = src2[min(pass * kLanes + lane, kWaveObsVecs - 1)];
+            between();
+            const Rsrc s1 = make_rsrc(obs1, obs_span_bytes), s2 = make_rsrc(obs2, obs_span_bytes);
+#pragma unroll
+            for (int pass = 0; pass < 9; ++pass)
+                __builtin_amdgcn_raw_buffer_store_b128(p1[pass], s1, piece_off[pass], 0, PZ_OBS_AUX);
+#pragma unroll
+            for (int pass = 0; pass < 9; ++pass)
+                __builtin_amdgcn_raw_buffer_store_b128(p2[pass], s2, piece_off[pass], 0, PZ_OBS_AUX);
+        }
+    }
+    static constexpr int kStores = OBS16 ? 10 : 18;  // row stores per frame
+};
+
 // The scout wave of step_kernel<..., SCOUT>: for its workgroup's 64 games it loads just what decides
 // whether a computer player will scan the power-hit directions this frame (the ball, the computer
 // players' x / y / state, the two round flags), advances the ball like the frame will, and evaluates the
@@ -713,11 +852,20 @@ __device__ __forceinline__ void scout_candidates_posted(const int32_t* __restric
 // frame of pz_step (scout_candidates, scout_landing_after_hits), kScoutPosted for the k-frame modes
 // (scout_candidates_posted).  The scout executes exactly the workgroup barriers of the main wave.
 // PACKED: the state buffer holds the packed format (pz_packed.hpp); the whole groups are written back (no scout wave).
-template <bool AI1, bool AI2, int MODE, bool SPARSE, int SCOUT = kNoScout, bool PACKED = false>
-__global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
+// OBS16 (trajectory modes only): int16 observation rows (cfg.normalize_obs == 2), compile-time there.
+#ifndef PZ_TRAJ_WAVES
+#define PZ_TRAJ_WAVES 1
+#endif
+template <bool AI1, bool AI2, int MODE, bool SPARSE, int SCOUT = kNoScout, bool PACKED = false, bool OBS16 = false>
+// (trajectory modes: one wave per SIMD by design -- two with a scout wave -- so the wave may have its share of the whole
+//  register file: a frame's 18 row pieces are in flight from LDS together)
+__global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes)
+__attribute__((amdgpu_waves_per_eu(1, (MODE == kRollout || MODE == kTape) ? (SCOUT != kNoScout ? 2 : PZ_TRAJ_WAVES) : 8)))
+void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
 {
     const HotArgs hot{state, n, stride, act_p1, act_p2};
     static_assert(!PACKED || (SCOUT == kNoScout && !SPARSE), "the packed format has no scout and no changed-only variant");
+    static_assert(!OBS16 || MODE == kRollout || MODE == kTape, "the single-frame launches take the row format at run time");
     static_assert(SCOUT == kNoScout || ((AI1 || AI2) && (MODE == kActions) == (SCOUT == kScoutLoads)),
                   "kScoutLoads serves the single-frame AI launch, kScoutPosted the k-frame ones");
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
@@ -743,7 +891,6 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
                 __syncthreads();  // step_games: this frame's ball posted
                 scout_candidates_posted(posts, cand, scout_scratch, lane);
                 __syncthreads();  // step_games: candidates handed over
-                if (MODE == kRollout || MODE == kTape) __syncthreads();  // emit_outputs of the frame
             }
         }
         if (MODE != kRollout && MODE != kTape) __syncthreads();  // emit_outputs (this wave stages no rows)
@@ -763,7 +910,12 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
     const StatsIO sio = make_stats_io(a.episode_stats, with_stats, a.stride, i);
 
     Game g{};
-    const RngId id = make_rng_id(a.cfg, live ? i : 0);
+    RngId id = make_rng_id(a.cfg, live ? i : 0);
+    KeySchedule policy = make_schedule(a.action_seed);
+    if (MODE != kActions) {  // the frame loop's two key schedules live in VGPRs (see KeySchedule)
+        park_in_vgprs(id.ks);
+        if (MODE != kTape) park_in_vgprs(policy);
+    }
     const FlightLut lut = make_lut(a.tables);
     int reward = 0;
     bool frozen = false;
@@ -796,7 +948,44 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
     Rewards rw{0, 0, 0.0f, 0.0f};
     if (MODE != kActions) {
         const uint32_t n_actions = a.cfg.simplify_action ? 13u : 18u;
+        constexpr bool kTraj = MODE == kRollout || MODE == kTape;
+        // Human vs human: computer_boldness is drawn at every round start (physics.py:218) and read by nothing, so only
+        // the LAST draw of a launch is observable (in the state written back): the frames remember that draw's
+        // counter and the two Philox blocks run once, behind the loop, instead of on three frames out of four.
+#ifndef PZ_NO_DEFER_BOLD
+        constexpr bool kDeferBold = !AI1 && !AI2;
+#else
+        constexpr bool kDeferBold = false;
+#endif
+        BoldDefer bold{false, 0u};
+        TrajOut<OBS16> out;
+        if (kTraj) out.init(a, i, lane, live);
+        if (MODE != kTape) policy_actions(id.id_lo, id.id_hi, policy, a.t0, n_actions, a1, a2);
+        // The frame in two halves (pz_physics.hpp, frame_head / frame_tail): the head of frame s + 1 -- round start, ball
+        // step, the computer player's table gathers issued -- runs BEFORE frame s's observation rows are stored, so
+        // that the gathers are not queued behind those 18 stores in the in-order vmcnt.
+        const ScoutLink link{cand, hits, posts};
+        bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
+#ifndef PZ_NO_PRELOOP_DRAIN
+        // Every state load lands BEFORE the frame loop: left to itself the compiler waits for the 44 columns where the
+        // first frame reads them -- inside the loop body, counting down to vmcnt(0) -- where on every later frame
+        // those waits drain the previous frame's 18 row stores instead (and the gathers queued behind them).
+        if (kTraj) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
+#endif
+#ifdef PZ_NO_HEAD_PIPELINE
+        FrameHead head{};
+#else
+        FrameHead head = frame_head<AI1, AI2, SCOUT, kDeferBold>(g, a.cfg, id, live, lane, lut, link, &bold);
+        // The compiler sizes the tail's wait for the head's gathers for the worst path into the loop: from here
+        // nothing would follow them (vmcnt(0): every frame drains its predecessor's row stores after all), around the
+        // back edge a frame's 18 row stores do.  Eighteen dropped stores make the two paths look alike: vmcnt(18).
+        if (kTraj && (AI1 || AI2)) issue_dropped_stores<TrajOut<OBS16>::kStores>();
+#endif
         for (int32_t s = 0; s < a.k; ++s) {
+#ifdef PZ_NO_HEAD_PIPELINE
+            resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
+            head = frame_head<AI1, AI2, SCOUT, kDeferBold>(g, a.cfg, id, live, lane, lut, link, &bold);
+#endif
             if (MODE == kTape) {
                 // The tape is fetched kTapeChunk frames at a time and parked in LDS: a per-frame global load
                 // would put a full memory latency on every frame of a lone wave, and its wait (vmcnt is
@@ -815,28 +1004,42 @@ __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes) void step_
                 }
                 a1 = tape_lds[(slot * 2 + 0) * kLanes + lane];
                 a2 = tape_lds[(slot * 2 + 1) * kLanes + lane];
-            } else {
-                policy_actions(id.id_lo, id.id_hi, a.action_seed, a.t0 + (uint64_t)s, n_actions, a1, a2);
             }
-            const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
 #ifdef PZ_PREDICT_EVERY_HIT
             const bool last_frame = true;
 #else
             const bool last_frame = s == a.k - 1;
 #endif
-            reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane, lut,
-                                                 ScoutLink{cand, hits, posts}, nullptr, last_frame);
+            frozen = head.frozen;
+            reward = frame_tail<AI1, AI2, SCOUT, false>(g, a.cfg, id, a1, a2, live, head, lds_obs[0], lane, lut, link,
+                                                        nullptr, last_frame);
             finished += (unsigned int)(live && g.e.game_ended && !frozen);
             rw = shape_rewards(a.cfg, g, reward, frozen);
             if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
-            if (MODE == kRollout || MODE == kTape) {
-                if (MODE == kRollout && a.act_out != nullptr) {
-                    const Rsrc ao = make_rsrc(a.act_out + (int64_t)s * 2 * a.n, n32 * 8u);
-                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a1, ao, io.voff, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, io.voff, n32 * 4u, 0);
-                }
-                emit_outputs(a, g, rw, as_float, live, i, lane, s, lds_obs, false);
+            // the next frame's policy draw (one block too many per launch): in a trajectory launch it is the independent
+            // VALU work that runs under the LDS reads of this frame's rows
+            auto next_policy = [&]() {
+                if (MODE != kTape)
+                    policy_actions(id.id_lo, id.id_hi, policy, a.t0 + (uint64_t)s + 1u, n_actions, a1, a2);
+            };
+            if (kTraj) out.stage(a, g, rw, as_float, live, a1, a2, MODE == kRollout && a.act_out != nullptr, lane, lds_obs);
+#ifndef PZ_NO_HEAD_PIPELINE
+            if (s + 1 < a.k) {  // (this frame's outputs are staged: the game may move on)
+                resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
+                head = frame_head<AI1, AI2, SCOUT, kDeferBold>(g, a.cfg, id, live, lane, lut, link, &bold);
             }
+#endif
+            if (kTraj) {
+                out.flush(lds_obs, lane, next_policy);
+                out.advance();
+            } else {
+                next_policy();
+            }
+        }
+        if (kDeferBold && bold.pending) {  // draws number `counter`, `counter + 1` of the env stream (physics.py:218)
+            uint32_t counter = bold.counter;
+            g.p1.bold = rng_integers(id, counter, 5u);
+            g.p2.bold = rng_integers(id, counter, 5u);
         }
     } else if (!PZ_SKIP_FRAME) {
         const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
@@ -948,7 +1151,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         if (with_stats) sio.load(st);
     }
     if (RANDOM)  // (issued behind the loads: the block runs while they are in flight)
-        policy_actions(id.id_lo, id.id_hi, a.action_seed, a.t0, a.cfg.simplify_action ? 13u : 18u, a1, a2);
+        policy_actions(id.id_lo, id.id_hi, make_schedule(a.action_seed), a.t0, a.cfg.simplify_action ? 13u : 18u, a1, a2);
     const Game loaded = g;  // what the columns held before the frame
     const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     bool frozen = false;
@@ -959,7 +1162,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     // slowest thing in the kernel), the launches of one variant run back to back with the same bits
     if (blockIdx.x == 0 && threadIdx.x == 0) g_pz_ablate_bits = a.cfg.packed_state;
 #endif
-    LandingProbe after_hit{false, false, 0u};
+    LandingProbe after_hit{false, false, 0u, 0u};
     bool bold_pending = false;  // a human player's new-round boldness draw, made behind the stores
     const int reward = step_games_pair<ROLE, AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, xchg, kLanes * PZ_OBS_DIM,
                                                         lane, lut, after_hit, bold_pending);
@@ -1203,7 +1406,7 @@ __global__ __launch_bounds__(256) void random_actions_kernel(int32_t* act_p1, in
     if (i >= n) return;
     const uint64_t gid = (uint64_t)(env_id_base + i);
     int a1, a2;
-    policy_actions((uint32_t)gid, (uint32_t)(gid >> 32), action_seed, t, n_actions, a1, a2);
+    policy_actions((uint32_t)gid, (uint32_t)(gid >> 32), make_schedule(action_seed), t, n_actions, a1, a2);
     act_p1[i] = a1;
     act_p2[i] = a2;
 }
@@ -1561,20 +1764,31 @@ static int check_common(const void* state, int64_t n, int64_t stride, const pz_c
 
 static inline unsigned int blocks_for(int64_t n, int per) { return (unsigned int)((n + per - 1) / per); }
 
-template <int MODE, bool SPARSE, bool PACKED = false>
-static int launch_step_ai(const StepArgs& a, hipStream_t stream)
+// one step_kernel instantiation per player configuration; the trajectory modes also per observation row format
+// (OBS16, compile-time there: see TrajOut::flush)
+template <int MODE, bool SPARSE, int SCOUT, bool PACKED, bool OBS16>
+static int launch_step_players(const StepArgs& a, hipStream_t stream)
 {
-    const dim3 grid(blocks_for(a.n, kLanes)), block(kLanes);
+    const dim3 grid(blocks_for(a.n, kLanes)), block(SCOUT != kNoScout ? 2 * kLanes : kLanes);
     const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
     if (ai1 && ai2)
-        hipLaunchKernelGGL((step_kernel<true, true, MODE, SPARSE, kNoScout, PACKED>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+        hipLaunchKernelGGL((step_kernel<true, true, MODE, SPARSE, SCOUT, PACKED, OBS16>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
     else if (ai1)
-        hipLaunchKernelGGL((step_kernel<true, false, MODE, SPARSE, kNoScout, PACKED>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+        hipLaunchKernelGGL((step_kernel<true, false, MODE, SPARSE, SCOUT, PACKED, OBS16>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
     else if (ai2)
-        hipLaunchKernelGGL((step_kernel<false, true, MODE, SPARSE, kNoScout, PACKED>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
-    else
-        hipLaunchKernelGGL((step_kernel<false, false, MODE, SPARSE, kNoScout, PACKED>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+        hipLaunchKernelGGL((step_kernel<false, true, MODE, SPARSE, SCOUT, PACKED, OBS16>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+    else if constexpr (SCOUT == kNoScout)  // (a scout wave only ever serves a computer player)
+        hipLaunchKernelGGL((step_kernel<false, false, MODE, SPARSE, SCOUT, PACKED, OBS16>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
     return (int)hipGetLastError();
+}
+
+template <int MODE, bool SPARSE, bool PACKED = false, int SCOUT = kNoScout>
+static int launch_step_ai(const StepArgs& a, hipStream_t stream)
+{
+    if constexpr (MODE == kRollout || MODE == kTape) {
+        if (a.cfg.normalize_obs == 2) return launch_step_players<MODE, SPARSE, SCOUT, PACKED, true>(a, stream);
+    }
+    return launch_step_players<MODE, SPARSE, SCOUT, PACKED, false>(a, stream);
 }
 
 template <bool AI1, bool AI2, bool RANDOM = false>
@@ -1618,18 +1832,17 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
 #if !defined(PZ_NO_SCOUT_WAVE) && !defined(PZ_ABLATE) && !defined(PZ_STAMPS)
     if (a.n < PZ_TWO_WAVE_MAX_LANES && !tables) {  // a computer player is present (else: pair kernel above)
         constexpr int kScout = MODE == kActions ? kScoutLoads : kScoutPosted;
-        const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
         constexpr bool kSparse = MODE == kActions || MODE == kRandom;
-        if (ai1 && ai2)
-            hipLaunchKernelGGL((step_kernel<true, true, MODE, kSparse, kScout>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
-        else if (ai1)
-            hipLaunchKernelGGL((step_kernel<true, false, MODE, kSparse, kScout>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
-        else if (ai2)
-            hipLaunchKernelGGL((step_kernel<false, true, MODE, kSparse, kScout>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
-        if (ai1 || ai2) return (int)hipGetLastError();
+        if (ai1 || ai2) return launch_step_ai<MODE, kSparse, false, kScout>(a, stream);
     }
 #endif
     return launch_step_ai<MODE, MODE == kActions || MODE == kRandom>(a, stream);
+}
+
+// the look-ups load whole dwords / 16-byte rows
+static inline bool tables_misaligned(const pz_flight_tables* t)
+{
+    return t != nullptr && (misaligned16(t->power_hit) || (reinterpret_cast<uintptr_t>(t->landing) & 3u) != 0);
 }
 
 static pz_flight_tables tables_of(const pz_flight_tables* t)
@@ -1657,13 +1870,13 @@ const char* pz_build_id(void) { return kBuildIdRecord + 12; }
 
 int64_t pz_flight_table_bytes(int32_t which)
 {
-    return which == 0 ? kFtLandingEntries * 2 : (which == 1 ? kFtHitEntries * 16 : 0);
+    return which == 0 ? kFtLandingBytes : (which == 1 ? kFtHitEntries * 16 : 0);
 }
 
 int pz_build_flight_tables(uint16_t* landing, uint16_t* power_hit, void* stream)
 {
     if (landing == nullptr && power_hit == nullptr) return PZ_E_NULL;
-    if (misaligned16(power_hit)) return PZ_E_ALIGN;
+    if (misaligned16(power_hit) || (reinterpret_cast<uintptr_t>(landing) & 3u) != 0) return PZ_E_ALIGN;
     if (landing != nullptr)
         hipLaunchKernelGGL(build_landing_table_kernel, dim3(blocks_for(kFtLandingEntries, 256)), dim3(256), 0,
                            (hipStream_t)stream, landing);
@@ -1680,7 +1893,7 @@ const char* pz_error_string(int code)
         case PZ_E_NULL: return "required pointer is NULL";
         case PZ_E_SIZE: return "bad size (n < 0, stride < n, k < 1, or more than 24 403 223 games in one launch)";
         case PZ_E_CONFIG: return "pz_config field out of range";
-        case PZ_E_ALIGN: return "buffer is not 16-byte aligned (observations, packed state, power_hit table)";
+        case PZ_E_ALIGN: return "buffer is not 16-byte aligned (observations, packed state, power_hit table; landing table: 4)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown pikazoo error";
     }
 }
@@ -1766,7 +1979,7 @@ int pz_step(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, con
     if (!act_p1 || !act_p2 || !obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
     if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
-    if (tables != nullptr && misaligned16(tables->power_hit)) return PZ_E_ALIGN;
+    if (tables_misaligned(tables)) return PZ_E_ALIGN;
     StepArgs a{state,  n,          stride,        act_p1,  act_p2, 0, 0, 1, nullptr, obs_p1, obs_p2, rew_p1,
                rew_p2, terminated, episode_stats, nullptr, tables_of(tables), *cfg};
     return launch_step<kActions>(a, (hipStream_t)stream);
@@ -1780,6 +1993,7 @@ int pz_step_random(int32_t* state, int64_t n, int64_t stride, const pz_config* c
     if (!obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
     if (k < 1) return PZ_E_SIZE;
     if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
+    if (tables_misaligned(tables)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
     StepArgs a{state,  n,          stride,        nullptr, nullptr, action_seed, t0, k, nullptr, obs_p1, obs_p2, rew_p1,
                rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), tables_of(tables),
@@ -1798,6 +2012,7 @@ int pz_rollout_random(int32_t* state, int64_t n, int64_t stride, const pz_config
     // every frame's [n][35] slab must keep the 16-byte alignment of the vector stores: n * 140 % 16 == 0
     if (misaligned16(obs_p1) || misaligned16(obs_p2) || (k > 1 && (n & (cfg->normalize_obs == 2 ? 7 : 3)) != 0))
         return PZ_E_ALIGN;
+    if (tables_misaligned(tables)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
     StepArgs a{state,  n,          stride,        nullptr, nullptr, action_seed, t0, k, actions, obs_p1, obs_p2, rew_p1,
                rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), tables_of(tables),
@@ -1814,6 +2029,7 @@ int pz_step_many(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg
     if (k < 1) return PZ_E_SIZE;
     if (misaligned16(obs_p1) || misaligned16(obs_p2) || (k > 1 && (n & (cfg->normalize_obs == 2 ? 7 : 3)) != 0))
         return PZ_E_ALIGN;
+    if (tables_misaligned(tables)) return PZ_E_ALIGN;
     if (n == 0) return PZ_OK;
     StepArgs a{state,  n,          stride,        actions, nullptr, 0, 0, k, nullptr, obs_p1, obs_p2, rew_p1,
                rew_p2, terminated, episode_stats, reinterpret_cast<unsigned long long*>(episodes_done), tables_of(tables),

@@ -76,28 +76,62 @@ struct Game {
 struct Input {
     int xd, yd, hit;
 };
-// per-lane RNG identity (Philox counter words 0,1 and key)
+// The ten round keys of a Philox key (k + r * Weyl constant).  Wave-uniform values; as plain scalars the compiler
+// either recomputes them at every block (straight-line kernels: fine) or, in a frame loop, hoists all of them and then
+// spills them -- two key schedules are 40 SGPRs of the 102, and every spilled key comes back through a v_readlane in
+// front of its xor.  The k-frame kernels therefore park their schedules in VGPRs (park_in_vgprs), of which a lone wave
+// per SIMD has hundreds to spare.
+struct KeySchedule {
+    uint32_t k0[10], k1[10];
+};
+
+__device__ __forceinline__ KeySchedule make_schedule(uint32_t k0, uint32_t k1)
+{
+    KeySchedule ks;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        ks.k0[r] = k0 + (uint32_t)r * 0x9E3779B9u;
+        ks.k1[r] = k1 + (uint32_t)r * 0xBB67AE85u;
+    }
+    return ks;
+}
+__device__ __forceinline__ KeySchedule make_schedule(uint64_t key) { return make_schedule((uint32_t)key, (uint32_t)(key >> 32)); }
+
+__device__ __forceinline__ void park_in_vgprs(KeySchedule& ks)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        asm("v_mov_b32 %0, %1" : "=v"(ks.k0[r]) : "s"(ks.k0[r]));
+        asm("v_mov_b32 %0, %1" : "=v"(ks.k1[r]) : "s"(ks.k1[r]));
+    }
+}
+
+// per-lane RNG identity (Philox counter words 0,1) and the env stream's key
 struct RngId {
-    uint32_t id_lo, id_hi, k0, k1;
+    uint32_t id_lo, id_hi;
+    KeySchedule ks;
 };
 
 // ---------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11).  Only words 0 and 1 of the output block are used.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // one v_bitop3_b32 (gfx950) instead of two v_xor_b32
+}
+
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t& o0, uint32_t& o1)
+                                              const KeySchedule& ks, uint32_t& o0, uint32_t& o1)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         // one 32x32->64 multiply per lane pair (v_mad_u64_u32) instead of separate hi/lo products
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        c0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        c0 = xor3((uint32_t)(p1 >> 32), c1, ks.k0[r]);
         c1 = (uint32_t)p1;
-        c2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c2 = xor3((uint32_t)(p0 >> 32), c3, ks.k1[r]);
         c3 = (uint32_t)p0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
     }
     o0 = c0;
     o1 = c1;
@@ -108,18 +142,17 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 __device__ __forceinline__ int rng_integers(const RngId& id, uint32_t& counter, uint32_t n)
 {
     uint32_t o0, o1;
-    philox4x32_10(id.id_lo, id.id_hi, counter, 0u, id.k0, id.k1, o0, o1);
+    philox4x32_10(id.id_lo, id.id_hi, counter, 0u, id.ks, o0, o1);
     counter += 1;
     return (int)__umulhi(o0, n);
 }
 
-// uniform random policy: both players' actions of one game at step t
-__device__ __forceinline__ void policy_actions(uint32_t id_lo, uint32_t id_hi, uint64_t action_seed,
+// uniform random policy: both players' actions of one game at step t (`policy`: the schedule of the action seed)
+__device__ __forceinline__ void policy_actions(uint32_t id_lo, uint32_t id_hi, const KeySchedule& policy,
                                                uint64_t t, uint32_t n_actions, int& a1, int& a2)
 {
     uint32_t o0, o1;
-    philox4x32_10(id_lo, id_hi, (uint32_t)t, 1u + 2u * (uint32_t)(t >> 32), (uint32_t)action_seed,
-                  (uint32_t)(action_seed >> 32), o0, o1);
+    philox4x32_10(id_lo, id_hi, (uint32_t)t, 1u + 2u * (uint32_t)(t >> 32), policy, o0, o1);
     a1 = (int)__umulhi(o0, n_actions);
     a2 = (int)__umulhi(o1, n_actions);
 }
@@ -178,7 +211,7 @@ __device__ __forceinline__ Input decode_action(const ActionTables& t, int action
 // Round / game initialisation
 // ---------------------------------------------------------------------------------------
 // Player.initialize_for_new_round (physics.py:181-218); boldness is drawn for humans too.
-__device__ __forceinline__ void player_new_round(Player& p, int x0, const RngId& id, uint32_t& rng)
+__device__ __forceinline__ void player_new_round_undrawn(Player& p, int x0)
 {
     p.x = x0;
     p.y = kPlayerGroundY;
@@ -188,6 +221,11 @@ __device__ __forceinline__ void player_new_round(Player& p, int x0, const RngId&
     p.frame = 0;
     p.arm = 1;
     p.delay = 0;
+}
+
+__device__ __forceinline__ void player_new_round(Player& p, int x0, const RngId& id, uint32_t& rng)
+{
+    player_new_round_undrawn(p, x0);
     p.bold = rng_integers(id, rng, 5u);
 }
 
@@ -466,6 +504,8 @@ constexpr int kFtYvCount = 2 * PZ_FT_YV_MAX + 1;
 constexpr int kFtHitYMin = 61;                             // the scan needs |ball.y - player.y| < 48, player.y >= 108
 constexpr int kFtHitYCount = kBallGroundY - kFtHitYMin + 1;
 constexpr int64_t kFtLandingEntries = (int64_t)kFtYvCount * kFtXvCount * kFtYCount * kFtXCount;
+// the look-up loads the DWORD that holds an entry (an odd number of 2-byte entries: the buffer ends with two bytes of padding)
+constexpr int64_t kFtLandingBytes = (kFtLandingEntries * 2 + 3) & ~(int64_t)3;
 constexpr int64_t kFtHitEntries = (int64_t)(PZ_FT_HIT_YV_MAX + 1) * kFtHitYCount * kFtXCount;  // of 8 x uint16
 
 // x velocity -> table row, or -1
@@ -483,7 +523,9 @@ __device__ __forceinline__ int ft_xv_value(int index) { return index == 0 ? -20 
 // branch closes: the two gathers of a decision and the Philox blocks between them would run one after the other.)
 struct LandingProbe {
     bool in, wanted;
-    uint32_t value;
+    uint32_t shift;  // 0 / 16: the half of `value` that is the entry
+    uint32_t value;  // the table dword holding the entry, exactly as loaded: nothing touches the register before
+                     // landing_finish (a 16-bit load's widening would be an instruction waiting for it at the issue site)
 };
 struct CandidateProbe {
     bool in, wanted;
@@ -496,7 +538,9 @@ struct FlightLut {
 
     // calculate_expected_landing_point_x_for (physics.py:643-686)
     // (`wanted` false: the lane needs no prediction; finish returns `keep`)
-    __device__ __forceinline__ LandingProbe landing_issue(bool wanted, int x, int y, int xv, int yv) const
+    // locate: everything but the load (a k-frame launch issues the load in one frame half and re-derives the rest,
+    // a pure function of the unmoved ball, in the other: only the loaded register crosses its loop's back edge)
+    __device__ __forceinline__ LandingProbe landing_locate(bool wanted, int x, int y, int xv, int yv, uint32_t& offset) const
     {
         const int xi = ft_xv_index(xv);
         const bool in = wanted & has_landing & (xi >= 0) & ((unsigned)(x - kBallRadius) < (unsigned)kFtXCount) &
@@ -506,12 +550,20 @@ struct FlightLut {
         uint32_t e = __umul24((uint32_t)(yv + PZ_FT_YV_MAX), (uint32_t)kFtXvCount) + (uint32_t)xi;
         e = __umul24(e, (uint32_t)kFtYCount) + (uint32_t)y;
         e = __umul24(e, (uint32_t)kFtXCount) + (uint32_t)(x - kBallRadius);
-        return LandingProbe{in, wanted, (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(landing, in ? e * 2u : 0u, 0, 0)};
+        offset = in ? (e * 2u) & ~3u : 0u;
+        return LandingProbe{in, wanted, (e & 1u) * 16u, 0u};
+    }
+    __device__ __forceinline__ LandingProbe landing_issue(bool wanted, int x, int y, int xv, int yv) const
+    {
+        uint32_t offset;
+        LandingProbe p = landing_locate(wanted, x, y, xv, yv, offset);
+        p.value = __builtin_amdgcn_raw_buffer_load_b32(landing, offset, 0, 0);
+        return p;
     }
     __device__ __forceinline__ int landing_finish(const LandingProbe& p, int x, int y, int xv, int yv, int keep) const
     {
         if (p.wanted & !p.in) return predict_landing_x<true>(x, y, xv, yv);
-        return p.in ? (int)p.value : keep;
+        return p.in ? (int)((p.value >> p.shift) & 0xFFFFu) : keep;
     }
     __device__ __forceinline__ int landing_x(int x, int y, int xv, int yv) const
     {
@@ -520,16 +572,27 @@ struct FlightLut {
 
     // the six candidates of decide_whether_input_power_hit (physics.py:796-816) for the ball (x, y, |yv|);
     // `wanted`: this lane's computer player scans this frame
-    __device__ __forceinline__ CandidateProbe candidates_issue(bool wanted, int x, int y, int ayv) const
+    __device__ __forceinline__ CandidateProbe candidates_locate(bool wanted, int x, int y, int ayv, uint32_t& offset) const
     {
         const bool in = wanted & has_power_hit & ((unsigned)(x - kBallRadius) < (unsigned)kFtXCount) &
                         ((unsigned)(y - kFtHitYMin) < (unsigned)kFtHitYCount) & ((unsigned)ayv <= (unsigned)PZ_FT_HIT_YV_MAX);
         uint32_t e = __umul24((uint32_t)ayv, (uint32_t)kFtHitYCount) + (uint32_t)(y - kFtHitYMin);
         e = __umul24(e, (uint32_t)kFtXCount) + (uint32_t)(x - kBallRadius);
-        return CandidateProbe{in, wanted, __builtin_amdgcn_raw_buffer_load_b128(power_hit, in ? e * 16u : 0u, 0, 0)};
+        offset = in ? e * 16u : 0u;
+        return CandidateProbe{in, wanted, lut_u32x4{0u, 0u, 0u, 0u}};
+    }
+    __device__ __forceinline__ CandidateProbe candidates_issue(bool wanted, int x, int y, int ayv) const
+    {
+        uint32_t offset;
+        CandidateProbe p = candidates_locate(wanted, x, y, ayv, offset);
+        p.value = __builtin_amdgcn_raw_buffer_load_b128(power_hit, offset, 0, 0);
+        return p;
     }
     __device__ __forceinline__ void candidates_finish(const CandidateProbe& p, int x, int y, int ayv, int (&ex)[6]) const
     {
+        // the row's fourth dword is padding: keep its register reserved until here all the same -- handed out as a
+        // temporary while the load is in flight, the first write to it would have to wait for the whole gather
+        asm volatile("" ::"v"(p.value.w));
         ex[0] = (int)(p.value.x & 0xFFFFu);
         ex[1] = (int)(p.value.x >> 16);
         ex[2] = (int)(p.value.y & 0xFFFFu);
@@ -724,9 +787,9 @@ __device__ __forceinline__ PreDrawn predraw3(const RngId& id, uint32_t counter)
 {
     PreDrawn pre;
     uint32_t unused;
-    philox4x32_10(id.id_lo, id.id_hi, counter, 0u, id.k0, id.k1, pre.w0, unused);
-    philox4x32_10(id.id_lo, id.id_hi, counter + 1u, 0u, id.k0, id.k1, pre.w1, unused);
-    philox4x32_10(id.id_lo, id.id_hi, counter + 2u, 0u, id.k0, id.k1, pre.w2, unused);
+    philox4x32_10(id.id_lo, id.id_hi, counter, 0u, id.ks, pre.w0, unused);
+    philox4x32_10(id.id_lo, id.id_hi, counter + 1u, 0u, id.ks, pre.w1, unused);
+    philox4x32_10(id.id_lo, id.id_hi, counter + 2u, 0u, id.ks, pre.w2, unused);
     return pre;
 }
 
@@ -928,20 +991,44 @@ struct ScoutLink {
     int32_t* posts;       // LDS [64][kPostPitch]  (kScoutPosted)
 };
 
-template <bool AI1, bool AI2, int SCOUT = kNoScout>
-__device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
-                                          bool& frozen, int32_t* __restrict__ scratch, int lane,
-                                          const FlightLut& lut, const ScoutLink link = ScoutLink{nullptr, nullptr, nullptr},
-                                          bool* ex_pending = nullptr, const bool last_frame = true)
+// DEFER_BOLD (human vs human, k-frame launches): a round start records the counter of its two boldness draws in
+// `*bold` instead of drawing them -- computer_boldness is read by the computer player's decision only, so the caller
+// makes the launch's last recorded draw once, behind its frame loop.
+struct BoldDefer {
+    bool pending;
+    uint32_t counter;
+};
+
+// The frame comes in two halves, so that a k-frame launch can run the head of frame t+1 BEFORE it stores frame t's
+// observation rows (pz_kernels.hip, step_kernel): the head ends by issuing the computer player's table gathers, and
+// gfx9 counts loads and stores in one in-order vmcnt -- gathers issued behind a frame's 18 row stores are not back
+// before those have drained, gathers issued in front of them are (5.5 -> 4.3 us per frame was the drain).
+//   frame_head  [auto-reset / new round (its draws)] -> ball-world step -> [scout post] -> gathers + pre-drawn decision
+//               words issued;
+//   frame_tail  action decode -> decisions -> player moves -> ball-player collisions -> scoring.
+// Nothing between the two may touch the game: the caller stages frame t's outputs before head(t+1).
+// Only what cannot be re-derived crosses from head to tail (in a k-frame launch: around the loop's back edge) -- the
+// ball-world step's result and the registers the gathers land in, untouched; everything else the tail recomputes from
+// the game, which nothing moves in between.
+struct FrameHead {
+    bool frozen, ground;
+    uint32_t landing_word;    // LandingProbe::value
+    lut_u32x4 candidate_row;  // CandidateProbe::value
+    PreDrawn pre;
+};
+
+template <bool AI1, bool AI2, int SCOUT = kNoScout, bool DEFER_BOLD = false>
+__device__ __forceinline__ FrameHead frame_head(Game& g, const pz_config& cfg, const RngId& id, bool live, int lane,
+                                                const FlightLut& lut, const ScoutLink link, BoldDefer* bold)
 {
+    static_assert(!DEFER_BOLD || (!AI1 && !AI2), "a computer player reads its boldness");
     // The reference empties `agents` on termination (:237-238) and expects reset() before the
     // next step; auto_reset applies reset() (:149-164) in place.  Both that and the new-round
     // branch (:176-180) end in the same per-round initialisation, kept at one call site so the
     // wave runs the (divergent, Philox-drawing) body once.
-    frozen = live && g.e.game_ended && !cfg.auto_reset;
-    const bool active = live && !frozen;
-    Input in1{0, 0, 0}, in2{0, 0, 0};
-    bool ground = false;
+    FrameHead h{};
+    h.frozen = live && g.e.game_ended && !cfg.auto_reset;
+    const bool active = live && !h.frozen;
     PZ_FRAME_STAMP(0);
     if (active) {
         if (g.e.round_ended) {  // game_ended implies round_ended
@@ -952,22 +1039,20 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
                 g.e.s2 = 0;
             }
             g.e.round_ended = 0;
-            start_round(g, cfg, id);
+            if (DEFER_BOLD) {
+                player_new_round_undrawn(g.p1, 36);
+                player_new_round_undrawn(g.p2, kGroundWidth - 36);
+                bold->pending = true;
+                bold->counter = g.e.rng;
+                g.e.rng += 2u;
+                ball_new_round(g.b, get_server(cfg, g.e, id));
+            } else {
+                start_round(g, cfg, id);
+            }
         }
         PZ_FRAME_STAMP(1);
-
-        // :182-184 -- every player's key state is sampled, computer-controlled or not
-        if (cfg.simplify_action) {
-            in1 = decode_action(kSimpleTablesP1, a1, g.p1.hitprev);
-            in2 = decode_action(kSimpleTablesP2, a2, g.p2.hitprev);
-        } else {
-            in1 = decode_action(kFullTables, a1, g.p1.hitprev);
-            in2 = decode_action(kFullTables, a2, g.p2.hitprev);
-        }
-
-        PZ_FRAME_STAMP(2);
         // physics_engine
-        ground = ball_world_step(g.b);
+        h.ground = ball_world_step(g.b);
         PZ_FRAME_STAMP(3);
     }
     if (SCOUT == kScoutPosted) {
@@ -985,19 +1070,53 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
     // runs as in the pair kernel (step_games_pair) -- both gathers issued, the first decision's three possible draws
     // computed under them, branch-free decisions.  One candidate gather serves both players (same ball).
     const bool by_tables = (AI1 || AI2) && SCOUT == kNoScout && lut.has_landing && lut.has_power_hit;  // wave-uniform
+    if (by_tables && active) {
+        const bool scan = (AI1 && power_hit_scan_needed(g.p1, g.b)) || (AI2 && power_hit_scan_needed(g.p2, g.b));
+        h.landing_word = lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv).value;
+        h.candidate_row = lut.candidates_issue(scan, g.b.x, g.b.y, abs(g.b.yv)).value;
+        h.pre = predraw3(id, g.e.rng);
+    }
+    return h;
+}
+
+// PIN: the caller runs head and tail back to back (single frame): keep the head's Philox blocks under its gathers
+template <bool AI1, bool AI2, int SCOUT = kNoScout, bool PIN = true>
+__device__ __forceinline__ int frame_tail(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
+                                          FrameHead& h, int32_t* __restrict__ scratch, int lane, const FlightLut& lut,
+                                          const ScoutLink link, bool* ex_pending, const bool last_frame)
+{
+    const bool active = live && !h.frozen, ground = h.ground;
+    Input in1{0, 0, 0}, in2{0, 0, 0};
+    if (active) {
+        // :182-184 -- every player's key state is sampled, computer-controlled or not
+        if (cfg.simplify_action) {
+            in1 = decode_action(kSimpleTablesP1, a1, g.p1.hitprev);
+            in2 = decode_action(kSimpleTablesP2, a2, g.p2.hitprev);
+        } else {
+            in1 = decode_action(kFullTables, a1, g.p1.hitprev);
+            in2 = decode_action(kFullTables, a2, g.p2.hitprev);
+        }
+        PZ_FRAME_STAMP(2);
+    }
+    const bool by_tables = (AI1 || AI2) && SCOUT == kNoScout && lut.has_landing && lut.has_power_hit;  // wave-uniform
     if (by_tables) {
         if (active) {
-            const bool scan1 = AI1 && power_hit_scan_needed(g.p1, g.b);
-            const bool scan2 = AI2 && power_hit_scan_needed(g.p2, g.b);  // player 2 has not moved yet
-            const int ayv = abs(g.b.yv);
             int ex[6] = {0, 0, 0, 0, 0, 0};
-            LandingProbe lp = lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv);
-            CandidateProbe cp = lut.candidates_issue(scan1 | scan2, g.b.x, g.b.y, ayv);
-            PreDrawn pre = predraw3(id, g.e.rng);
-            asm volatile("" : "+v"(pre.w0), "+v"(pre.w1), "+v"(pre.w2), "+v"(lp.value), "+v"(cp.value.x), "+v"(cp.value.y),
-                         "+v"(cp.value.z));  // keeps the Philox blocks under the gathers (see step_games_pair)
+            if (PIN)
+                asm volatile("" : "+v"(h.pre.w0), "+v"(h.pre.w1), "+v"(h.pre.w2), "+v"(h.landing_word), "+v"(h.candidate_row.x),
+                             "+v"(h.candidate_row.y), "+v"(h.candidate_row.z));  // (see step_games_pair)
+            // what the head's gathers were issued for, re-derived (nobody has moved since): player 2 has not moved yet
+            const bool scan1 = AI1 && power_hit_scan_needed(g.p1, g.b);
+            const bool scan2 = AI2 && power_hit_scan_needed(g.p2, g.b);
+            const int ayv = abs(g.b.yv);
+            uint32_t unused;
+            LandingProbe lp = lut.landing_locate(true, g.b.x, g.b.y, g.b.xv, g.b.yv, unused);
+            lp.value = h.landing_word;
+            CandidateProbe cp = lut.candidates_locate(scan1 | scan2, g.b.x, g.b.y, ayv, unused);
+            cp.value = h.candidate_row;
             g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, 0);  // :314-315, one evaluation serves both
             lut.candidates_finish(cp, g.b.x, g.b.y, ayv, ex);
+            PreDrawn pre = h.pre;
             if (AI1) g.e.rng += computer_decide_predrawn<false>(g.p1, g.b, g.p2.x, pre, scan1, ex, in1);
             player_move<false>(g.p1, in1);
             if (AI2) {
@@ -1102,6 +1221,19 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
     }
     PZ_FRAME_STAMP(7);
     return reward;
+}
+
+// head and tail back to back: the single-frame launches
+template <bool AI1, bool AI2, int SCOUT = kNoScout, bool DEFER_BOLD = false>
+__device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
+                                          bool& frozen, int32_t* __restrict__ scratch, int lane,
+                                          const FlightLut& lut, const ScoutLink link = ScoutLink{nullptr, nullptr, nullptr},
+                                          bool* ex_pending = nullptr, const bool last_frame = true,
+                                          BoldDefer* bold = nullptr)
+{
+    FrameHead h = frame_head<AI1, AI2, SCOUT, DEFER_BOLD>(g, cfg, id, live, lane, lut, link, bold);
+    frozen = h.frozen;
+    return frame_tail<AI1, AI2, SCOUT, true>(g, cfg, id, a1, a2, live, h, scratch, lane, lut, link, ex_pending, last_frame);
 }
 
 // ---------------------------------------------------------------------------------------

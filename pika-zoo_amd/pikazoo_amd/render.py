@@ -223,8 +223,17 @@ def render(lib, state_ptr: int, device, n: int, stride: int, sprite_set: SpriteS
     ``int32[44, stride]`` columns on `device`.  With `scenery` (``int32[69, stride]``) the clouds / waves of the drawn
     games advance first (and with them the games' env RNG counters in the state) and are drawn."""
     m = n if lanes is None else int(lanes.numel())
-    if out is None or out.shape[0] != m:
+    if out is None:
         out = torch.empty((m, HEIGHT, WIDTH, 3), dtype=torch.uint8, device=device)
+    else:
+        # the kernel writes m * 304 * 432 * 3 bytes as dwords straight through this pointer: anything but exactly that
+        # buffer on this device would be overrun silently
+        want = (m, HEIGHT, WIDTH, 3)
+        if not isinstance(out, torch.Tensor) or tuple(out.shape) != want or out.dtype != torch.uint8 \
+                or out.device != torch.device(device) or not out.is_contiguous():
+            raise ValueError(f"render(out=): need a contiguous uint8 tensor of shape {want} on {device}, got "
+                             f"{getattr(out, 'dtype', type(out))} {tuple(getattr(out, 'shape', ()))} on "
+                             f"{getattr(out, 'device', None)}")
     _native.check(lib.pz_render(state_ptr, n, stride, cfg_ref, None if lanes is None else lanes.data_ptr(), m,
                                 sprite_set.atlas.data_ptr(), sprite_set.table.data_ptr(),
                                 sprite_set.background.data_ptr(), None if scenery is None else scenery.data_ptr(),

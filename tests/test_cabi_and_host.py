@@ -62,6 +62,8 @@ def test_library_carries_the_digest_of_the_sources_it_was_built_from(built_lib, 
     stale.write_bytes(built_lib.read_bytes().replace(b"pz_build_id:" + pz_build.source_id().encode(),
                                                      b"pz_build_id:" + b"0" * 16))
     assert pz_build.library_id(stale) == "0" * 16 != pz_build.source_id()
+    # extra compiler flags are part of the digest: a diagnostic variant written to the product path is not the product
+    assert pz_build.source_id(("-DPZ_ABLATE=1",)) != pz_build.source_id() == pz_build.source_id(())
     saved, _native._lib, _native.LIB_PATH = (_native._lib, _native.LIB_PATH), None, stale
     try:
         with pytest.raises(_native.PikazooNativeError, match="stale"):
@@ -223,11 +225,15 @@ def test_argument_validation_without_a_gpu(built_lib):
                               None) == -2
     assert lib.pz_observe(fake, 0, 0, 0, 0, C.c_void_p(4100), fake, None) == -4   # PZ_E_ALIGN
     assert lib.pz_step(fake, 0, 0, C.byref(cfg), fake, fake, fake, fake, fake, fake, fake, None, None, None) == 0
-    bad = _native.PzFlightTables(None, 4104)  # power-hit table not 16-byte aligned
-    assert lib.pz_step(fake, 8, 8, C.byref(cfg), fake, fake, fake, fake, fake, fake, fake, None, C.byref(bad),
-                       None) == -4
+    for bad in (_native.PzFlightTables(None, 4104),   # power-hit table not 16-byte aligned
+                _native.PzFlightTables(4098, 4096)):  # landing table not 4-byte aligned (it is read dword-wise)
+        assert lib.pz_step(fake, 8, 8, C.byref(cfg), fake, fake, fake, fake, fake, fake, fake, None, C.byref(bad),
+                           None) == -4
+        assert lib.pz_step_random(fake, 8, 8, C.byref(cfg), 1, 0, 1, fake, fake, fake, fake, fake, None, None,
+                                  C.byref(bad), None) == -4
     assert lib.pz_build_flight_tables(None, None, None) == -1
-    assert lib.pz_flight_table_bytes(0) == 2 * 193 * 23 * 253 * 413 and lib.pz_flight_table_bytes(1) == 16 * 65 * 192 * 413
+    # the landing table: its 2-byte entries (an odd number) + 2 bytes of padding -- the look-up loads whole dwords
+    assert lib.pz_flight_table_bytes(0) == 2 * 193 * 23 * 253 * 413 + 2 and lib.pz_flight_table_bytes(1) == 16 * 65 * 192 * 413
 
 
 def test_no_vmem_store_data_hazard_in_device_code(built_lib, tmp_path):

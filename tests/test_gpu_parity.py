@@ -822,9 +822,10 @@ def test_flight_tables_hold_the_iterative_predictors(oracle):
     _, landing, power_hit = flight_tables(dev)
     lib = _native.load()
     YV, HYV = 96, 64
-    assert landing.numel() == lib.pz_flight_table_bytes(0) == 2 * (2 * YV + 1) * 23 * 253 * 413
+    entries = (2 * YV + 1) * 23 * 253 * 413
+    assert landing.numel() == lib.pz_flight_table_bytes(0) == 2 * entries + 2  # (+ padding: read dword-wise)
     assert power_hit.numel() == lib.pz_flight_table_bytes(1) == 16 * (HYV + 1) * 192 * 413
-    land = landing.view(torch.int16).view(2 * YV + 1, 23, 253, 413)
+    land = landing.view(torch.int16)[:entries].view(2 * YV + 1, 23, 253, 413)
     xs = torch.arange(20, 433, dtype=torch.int32, device=dev)
     ys = torch.arange(0, 253, dtype=torch.int32, device=dev)
     xv_values = [-20] + list(range(-10, 11)) + [20]

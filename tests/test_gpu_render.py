@@ -79,6 +79,17 @@ def test_render_api_behaviour():
         big.render()
     assert big.render(lanes=[5, 4095]).shape == (2, 304, 432, 3)
     assert "rgb_array" in big.metadata["render_modes"]
+    # render(out=): the kernel writes m * 304 * 432 * 3 bytes through the pointer, so only exactly that buffer passes
+    good = torch.empty((2, 304, 432, 3), dtype=torch.uint8, device="cuda:0")
+    assert big.render(lanes=[5, 4095], out=good) is good
+    assert torch.equal(good, big.render(lanes=[5, 4095]))
+    for bad in (torch.empty((2, 304, 432), dtype=torch.uint8, device="cuda:0"),            # a channel short
+                torch.empty((3, 304, 432, 3), dtype=torch.uint8, device="cuda:0"),         # wrong frame count
+                torch.empty((2, 304, 432, 3), dtype=torch.int32, device="cuda:0"),         # wrong dtype
+                torch.empty((2, 304, 432, 3), dtype=torch.uint8),                          # host memory
+                torch.empty((2, 304, 432, 6), dtype=torch.uint8, device="cuda:0")[..., ::2]):  # not contiguous
+        with pytest.raises(ValueError):
+            big.render(lanes=[5, 4095], out=bad)
 
 
 @pytest.mark.parametrize("name,fmt", [("render_human_human", "int32"), ("render_p2_computer", "packed")])

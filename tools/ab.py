@@ -51,6 +51,7 @@ def main():
         n = int(args[args.index("--n") + 1])
     rollout = int(args[args.index("--rollout") + 1]) if "--rollout" in args else 0
     names = [a for a in args if not a.startswith("--") and not a.isdigit()]
+    no_check = "--no-check" in args  # variants that change the stored state legitimately
     if "base" not in names:
         names = ["base"] + names
     dev = torch.device("cuda:0")
@@ -160,7 +161,10 @@ def main():
         print(f"  {nm}: trajectory (observations, rewards, terminations) identical to base: {same}")
     # The K launches of a round are captured once per variant in a hipGraph and replayed: an eager ctypes launch
     # costs the host ~7 us, which would hide every kernel faster than that ("--eager" keeps the direct calls).
-    K, rounds = max(400, slices), 9
+    # (a k-frame round must be long enough for the clocks to settle: 12 launches = 1 ms was not -- 3 200 frames by default)
+    K, rounds = (3200 if rollout else max(400, slices)), 9
+    if "--frames" in args:
+        K = int(args[args.index("--frames") + 1])
     eager = "--eager" in args
     side = torch.cuda.Stream()
     graphs = {}
@@ -197,7 +201,8 @@ def main():
     print(f"n={n} p2_computer={ai} wrappers={wrappers} rollout={rollout} {'eager' if eager else 'hipGraph'}: us per "
           f"{'frame' if rollout else 'launch'}, median / min over {rounds} interleaved rounds of {K}")
     for nm in names:
-        print(f"  {nm:28s} {statistics.median(times[nm]):7.3f} {min(times[nm]):7.3f}")
+        print(f"  {nm:28s} {statistics.median(times[nm]):7.3f} {min(times[nm]):7.3f}"
+              + ("   [" + " ".join(f"{t:.3f}" for t in times[nm]) + "]" if "--samples" in args else ""))
 
 
 if __name__ == "__main__":

@@ -90,6 +90,40 @@ def stats_by_grid(trace_csv, out_path):
             w.writerow([k, grid, wg, grid // wg * 64, len(v), round(sum(v) / len(v), 1), v[len(v) // 2], v[0], v[-1]])
 
 
+def calibration(src, dst, tag):
+    """Known-byte kernels (tools/calib_traffic.hip) under --pmc FETCH_SIZE / WRITE_SIZE: counter value x 1024 over the
+    bytes the kernel moved, per access shape and buffer size.  -> TAG_calibration.json"""
+    import re
+
+    out = {}
+    for run, counter in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
+        cc = find(src / run, "_counter_collection.csv") if (src / run).is_dir() else None
+        log = src / f"{run}.log"
+        if cc is None or not log.exists():
+            continue
+        known = {}  # (kernel, lanes) -> (where, bytes)
+        for m in re.finditer(r"^calib (\S+) (\S+) grid=(\d+) bytes=(\d+)", log.read_text(), re.M):
+            known[(m.group(2), int(m.group(3)) * 64)] = (m.group(1), int(m.group(4)))
+        acc = defaultdict(list)
+        with open(cc) as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] == counter:
+                    acc[(short(row["Kernel_Name"]).split("<")[0], int(row["Grid_Size"]))].append(float(row["Counter_Value"]))
+        for (k, lanes), vals in sorted(acc.items()):
+            if (k, lanes) not in known:
+                continue
+            where, nbytes = known[(k, lanes)]
+            vals = vals[1:] or vals  # the first launch of a shape also pays for cold pages
+            mean = sum(vals) / len(vals)
+            out.setdefault(counter, {})[f"{k}@{where}"] = {
+                "known_bytes": nbytes, "counter_kb_mean": mean, "launches": len(vals),
+                "counter_bytes_over_known_bytes": mean * 1024.0 / nbytes}
+    if out:
+        (dst / f"{tag}_calibration.json").write_text(json.dumps(out, indent=1))
+        print(json.dumps(out, indent=1))
+    return out
+
+
 def find(run_dir, suffix):
     hits = sorted(Path(run_dir).rglob(f"*{suffix}"))
     return hits[0] if hits else None
@@ -101,8 +135,11 @@ def main():
     dst = src / "out"
     dst.mkdir(exist_ok=True)
     summary = {}
+    calibration(src, dst, tag)
     for run in sorted(p for p in src.iterdir() if p.is_dir() and p.name != "out"):
         name = run.name
+        if name.startswith("calib_"):
+            continue
         stats = find(run, "_kernel_stats.csv")
         if stats is not None:
             shutil.copy(stats, dst / f"{tag}_{name}_kernel_stats.csv")

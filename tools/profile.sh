@@ -7,6 +7,9 @@
 #   pmc_cfg3c the same passes on config 3 with the flight predictors computed in the kernel (scout-wave launch)
 #   pmc_big   FETCH_SIZE / WRITE_SIZE at 524 288 games (config 4's total size: past the Infinity Cache)
 #   kt_roll   --kernel-trace --stats of pz_rollout_random / pz_step_many (k = 32)
+#   pmc_roll  the four passes on the k-frame kernels (pz_rollout_random human and player 2 = computer, pz_step_many; k = 32)
+#   kt_hh     --kernel-trace --stats of the headline workload ALONE (no other config shares its kernel row)
+#   calib     FETCH_SIZE / WRITE_SIZE on known-byte kernels of the step kernels' access widths (tools/calib_traffic.hip)
 #   pmc_pk    the four passes on the headline workload with the packed state format (65 536 games)
 #   pmc_pkbig FETCH_SIZE / WRITE_SIZE / kernel stats at 524 288 games with the packed state format
 #   pmc_ph    FETCH_SIZE / WRITE_SIZE / kernel stats: packed state + int16 observations, 65 536 and 524 288 games
@@ -66,6 +69,13 @@ for s in $SECTIONS; do
         run phbig_kt --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --state-format packed --int16-obs --num-envs 524288 --steps 300 --warmup 50 --burn-in 256 --launch cabi || exit 1
         ;;
     kt_roll) run roll --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --rollouts || exit 1 ;;
+    pmc_roll) pmc_set roll --no-cpu --no-configs --rollouts || exit 1 ;;
+    kt_hh) run hh_kt --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs || exit 1 ;;
+    calib)
+        [ -x tools/bin/calib_traffic ] || { mkdir -p tools/bin && hipcc -O3 --offload-arch=gfx950 tools/calib_traffic.hip -o tools/bin/calib_traffic; } || exit 1
+        run calib_fetch --kernel-trace --pmc FETCH_SIZE -- tools/bin/calib_traffic || exit 1
+        run calib_write --kernel-trace --pmc WRITE_SIZE -- tools/bin/calib_traffic || exit 1
+        ;;
     *) echo "unknown section $s"; exit 2 ;;
     esac
 done
