@@ -339,7 +339,7 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     }
     res["frac"] = res["achieved_GBps"] / HBM_PEAK_GBPS
     res["frac_wall"] = alg / (res["wall_us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
-    if check_lanes and not args.no_cpu and dist.get_rank() == 0:
+    if check_lanes and not args.no_cpu:  # (the caller says which ranks check)
         seq = {"burn_in": burn, "warmup": warmup, "steps": steps, "passes": run["passes"]}
         res.update(oracle_parity(raw, seq, args.p1_computer, p2_computer, wrappers, check_lanes,
                                  usable_cores(args.cpu_threads)))
@@ -347,37 +347,99 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     return res
 
 
-def measure_rollout(args, shard, device, k, tape=False, p2_computer=False):
-    """pz_rollout_random (or, tape=True, pz_step_many on a pre-generated action tape): k frames per
-    launch, every frame's outputs written to trajectory tensors (state in registers, read/written once
-    per launch).  Honest bytes per game-step of THESE kernels: 297 (8 of them action words written
-    resp. read) + 352/k."""
+def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_time=0.25, check_lanes=0):
+    """pz_rollout_random (or, tape=True, pz_step_many on a pre-generated action tape): k frames per launch, every
+    frame's outputs written to [k][n]... trajectory tensors (state in registers, read / written once per launch).
+    Timed like the headline: the launches go through the C ABI into ONE hipGraph (>= 64 launches, each on its own
+    step indices t0), one untimed replay, then R replays until the timed region lasts >= min_time; HIP events on the
+    launch stream.  Algorithmic bytes per game-step of THESE kernels: 297 (8 of them the action words written resp.
+    read) + 352 / k.  `check_lanes`: the first lanes' final state against the CPU oracle replaying the same launches."""
     env = make_env(shard, device, num_envs=args.num_envs, p1_computer=args.p1_computer, p2_computer=p2_computer)
     raw = env.unwrapped
+    lib = _native.load()
     env.reset()
-    burn_in(raw, min(args.burn_in, 1024))
-    launches = max(1, 2048 // k)
-    tapes = None
-    if tape:
-        acts = pregenerate_actions(raw, (launches + 1) * k).view(launches + 1, k, 2, raw.num_envs)
-        tapes = [acts[j] for j in range(launches + 1)]
-        out = raw.step_many(tapes[0])
-    else:
-        out = raw.rollout_random(ACTION_SEED, k)          # allocate + warm up
-    torch.cuda.synchronize(device)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for j in range(launches):
-        out = raw.step_many(tapes[j + 1], out=out) if tape else raw.rollout_random(ACTION_SEED, k, out=out)
-    ev1.record()
-    torch.cuda.synchronize(device)
-    wall = time.perf_counter() - t0
-    us_per_frame = ev0.elapsed_time(ev1) * 1e3 / (launches * k)
+    burn = min(args.burn_in, 1024)
+    burn_in(raw, burn)
+    n = raw.num_envs
+    launches = max(64, 2048 // k)
+    out = raw.rollout_random(ACTION_SEED, k, t0=0)  # allocates the trajectory tensors; an untimed launch (frames 0..k-1)
+    tapes = pregenerate_actions(raw, launches * k).view(launches, k, 2, n) if tape else None
+    ptrs = (out["_obs"][0].data_ptr(), out["_obs"][1].data_ptr(), out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(),
+            out["_term"].data_ptr())
+    eps = raw._episodes.data_ptr()
+
+    def launch_all(stream):
+        s = stream.cuda_stream
+        for j in range(launches):
+            if tape:
+                rc = lib.pz_step_many(raw._state_ptr, n, raw._stride, raw._cfg_ref, tapes[j].data_ptr(), k, *ptrs, None, eps,
+                                      raw._tables_ref, s)
+            else:
+                rc = lib.pz_rollout_random(raw._state_ptr, n, raw._stride, raw._cfg_ref, ACTION_SEED, j * k, k,
+                                           out["actions"].data_ptr(), *ptrs, None, eps, raw._tables_ref, s)
+            if rc:
+                _native.check(rc, "k-frame launch")
+
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            launch_all(torch.cuda.current_stream(device))
+        t0 = time.perf_counter()
+        graph.replay()
+        stream.synchronize()
+        est = time.perf_counter() - t0
+        reps = max(1, math.ceil(min_time / max(est, 1e-6)))
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(reps):
+            graph.replay()
+        ev1.record(stream)
+        stream.synchronize()
+        wall = time.perf_counter() - t0
+    frames = reps * launches * k
+    us_per_frame = ev0.elapsed_time(ev1) * 1e3 / frames
     bytes_per_step = 297 + 352.0 / k
-    gbps = bytes_per_step * raw.num_envs / (us_per_frame * 1e-6) / 1e9
-    return {"value": raw.num_envs * launches * k / wall, "us_per_frame": us_per_frame, "k": k,
-            "bytes_per_game_step": bytes_per_step, "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS}
+    gbps = bytes_per_step * n / (us_per_frame * 1e-6) / 1e9
+    res = {"value": n * frames / wall, "us_per_frame": us_per_frame, "k": k, "launches_per_replay": launches,
+           "replays": reps, "timed_frames": frames, "timed_seconds": wall, "bytes_per_game_step": bytes_per_step,
+           "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS, "regime": "hbm-streaming, write-dominated"}
+    if check_lanes and not args.no_cpu:
+        from oracle import pz_oracle as po
+
+        po.build()
+        lanes = min(check_lanes, n)
+        chk = po.OracleEnv(lanes, oracle_config(po, raw, args.p1_computer, p2_computer, False, raw.env_id_base),
+                           nthreads=usable_cores(args.cpu_threads))
+        chk.reset()
+        chk.rollout_random(BURN_SEED, 0, burn)
+        chk.rollout_random(ACTION_SEED, 0, k)  # the allocating launch
+        for _ in range(reps + 1):
+            for j in range(launches):  # (the tape holds the policy stream's slices j * k ..: the same actions)
+                chk.rollout_random(ACTION_SEED, j * k, k)
+        res.update(parity_lanes_checked=lanes, parity_steps_checked=burn + k + (reps + 1) * launches * k,
+                   parity_bit_exact=bool((raw.state[:, :lanes].cpu().numpy() == chk.state).all()))
+    return res
+
+
+def write_ceiling(device, mib=1024):
+    """What this box takes for plain streaming writes: torch's fill of a 1 GiB tensor, best of 5 (GB/s).  The
+    trajectory kernels are write-dominated; their `frac` is quoted against the 8 TB/s HBM peak, this is the rate
+    a kernel that does nothing but write reaches here (tools/wstream.hip: the rollout's own store pattern reaches
+    the same)."""
+    buf = torch.empty(mib << 20, dtype=torch.uint8, device=device)
+    best = float("inf")
+    for _ in range(6):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for v in range(8):
+            buf.fill_(v)
+        ev1.record()
+        torch.cuda.synchronize(device)
+        best = min(best, ev0.elapsed_time(ev1) / 8)
+    return (mib << 20) / (best * 1e-3) / 1e9
 
 
 def measure_policy_in_the_loop(args, shard, device, launches=2048, fused=False):
@@ -430,28 +492,49 @@ def measure_policy_in_the_loop(args, shard, device, launches=2048, fused=False):
                      "policy kernel + step kernel per step, both inside the timed region")}
 
 
+_TRAFFIC = None
+
+
 def load_traffic(workload_key, num_envs):
-    """HBM bytes per launch from the committed PMC profile (profiles/traffic.json) of this workload at this batch
-    size, or None."""
-    p = REPO / "profiles" / "traffic.json"
-    if p.exists():
+    """Fabric-side bytes per launch from the committed PMC profile (profiles/traffic.json) of this workload at this
+    batch size, or None: FETCH_SIZE x 2 + WRITE_SIZE, both calibrated on known-byte kernels of the same access widths
+    (profiles/r03*_calibration.json)."""
+    global _TRAFFIC
+    if _TRAFFIC is None:
         try:
-            entry = json.loads(p.read_text()).get(workload_key, {})
-            return entry.get("hbm_bytes_per_launch") if entry.get("num_envs") == num_envs else None
+            _TRAFFIC = json.loads((REPO / "profiles" / "traffic.json").read_text())
         except Exception:  # noqa: BLE001
-            return None
-    return None
+            _TRAFFIC = {}
+    entry = _TRAFFIC.get(workload_key, {})
+    return entry.get("hbm_bytes_per_launch") if entry.get("num_envs") == num_envs else None
 
 
-def ensure_built():
+def traffic_key(num_envs, p2_computer=False, wrappers=False, flight_tables=True, state_format="int32", obs16=False):
+    """The profiles/traffic.json entry of a single-frame workload."""
+    wl = (("cfg3" if flight_tables else "cfg3_compute") if p2_computer else ("cfg5" if wrappers else "random_random"))
+    if num_envs != 65536:
+        wl += f"_{num_envs}"
+    if state_format == "packed":
+        wl = "packed_" + wl
+    if obs16:
+        wl += "_int16obs"
+    return wl
+
+
+def ensure_built(with_oracle=True):
     """(Re)build libpikazoo_hip.so when it is missing or was not built from the sources in this tree
-    (build.py compares the source hash baked into the library; hipcc is on every box of this image)."""
+    (build.py compares the source hash baked into the library; hipcc is on every box of this image) -- and the
+    checker, so that no two ranks ever compile it at the same time."""
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("pz_build", REPO / "pika-zoo_amd" / "build.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.build()
+    if with_oracle:
+        from oracle import pz_oracle as po
+
+        po.build()
 
 
 def kernel_name(num_envs, ai, tables, packed=False):
@@ -466,33 +549,74 @@ def kernel_name(num_envs, ai, tables, packed=False):
 
 
 def regime(num_envs):
-    """Where the per-step working set (state + both observation tensors + rewards, re-touched every launch)
-    lives: the 256 MiB Infinity Cache or HBM proper."""
+    """What a single-frame launch of this batch size runs against.  One launch per step is a chain of dependent
+    launches; with fewer workgroups than SIMDs it lasts as long as that chain's fixed latency.  From there on: does
+    the per-step working set (state + both observation tensors + rewards, re-touched every launch) stay in the
+    256 MiB Infinity Cache, or stream from / to HBM?"""
+    if num_envs < 16384:  # < 256 workgroups: not one per CU
+        return "launch-latency"
     ws = num_envs * (44 * 4 + 2 * 35 * 4 + 8 + 1 + 8)
     return "infinity-cache-resident" if ws < INFINITY_CACHE_BYTES // 2 else "hbm-streaming"
 
 
-def config_entry(r, workload, num_envs):
+BOUND_DETAIL = {
+    "launch-latency": "fewer workgroups than CUs: the launch lasts as long as the dependent-launch chain "
+                      "(dispatch + load latency + frame + store acknowledge), not as long as its bytes",
+    "infinity-cache-resident": "working set re-touched every launch out of the 256 MiB Infinity Cache: bound by the "
+                               "time to the first stores plus each XCD's write drain (DESIGN 4.4), not by HBM",
+    "hbm-streaming": "working set past the Infinity Cache: the launch streams HBM (6.3 TB/s of counted bytes is what "
+                     "the memory system delivers, MI355X_MICROARCH.md)",
+}
+
+
+def fractions(r, num_envs, key):
+    """The roofline figures of one single-frame measurement: on the algorithmic (contract) bytes and on the
+    counter-measured bytes of profiles/traffic.json."""
+    traffic = load_traffic(key, num_envs)
+    launch_s = r["launch_us"] * 1e-6
+    reg = regime(num_envs)
+    return {"frac": r["frac"], "frac_wall": r["frac_wall"], "traffic": traffic,
+            "frac_traffic": (traffic / launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+            "traffic_key": key, "regime": reg, "bound_detail": BOUND_DETAIL[reg]}
+
+
+def config_entry(r, workload, num_envs, key):
     e = {"workload": workload, "num_envs": num_envs, "value": r["value"], "launch_us": r["launch_us"],
-         "wall_us_per_step": r["wall_us_per_step"], "frac": r["frac"], "frac_wall": r["frac_wall"],
-         "timed_steps": r["timed_steps"]}
+         "wall_us_per_step": r["wall_us_per_step"], "timed_steps": r["timed_steps"],
+         "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], **fractions(r, num_envs, key)}
     for k in ("parity_bit_exact", "parity_lanes_checked", "parity_steps_checked"):
         if k in r:
             e[k] = r[k]
     return e
 
 
+def relaunch_with_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (one rank per
+    GPU), pass its output through and return its exit code.  Nothing in this process has touched the GPU yet, and it
+    never replaces itself with another program."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
     if int(os.environ.get("RANK", "0")) == 0:
-        ensure_built()
+        ensure_built(with_oracle=not args.no_cpu)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_with_ranks(args))
     one_device = os.environ.get("PZ_BENCH_ONE_DEVICE") == "1"  # rehearsal: every rank on cuda:0 of a 1-GPU box
     rank, world, local_rank = dist.init_from_env(args.dist_backend, device_index=0 if one_device else None)
     if one_device:
         local_rank = 0
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -502,6 +626,7 @@ def main():
     shard = dist.weak_shard(args.num_envs, rank, world)
     tables = not args.no_flight_tables
     single = rank == 0 and world == 1
+    cdev = dist.collective_device(device)
 
     if args.rollouts:
         out = {"rollout_k32": measure_rollout(args, shard, device, k=32),
@@ -510,16 +635,38 @@ def main():
         print(json.dumps(out), flush=True)
         return
 
+    # the in-run oracle replay: all of it with one rank; with N ranks the first and the last rank check 1 024 lanes each
+    check_lanes = args.check_lanes if single else (min(1024, args.check_lanes) if rank in (0, world - 1) else 0)
     main_res = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers,
-                       check_lanes=args.check_lanes if single else 0, flight_tables=tables,
-                       state_format=args.state_format, obs16=args.int16_obs)
+                       check_lanes=check_lanes, flight_tables=tables, state_format=args.state_format, obs16=args.int16_obs)
     raw_main = main_res.pop("raw")
+    # every rank's own figures (a straggler GPU is invisible in the MAX-over-ranks wall clock alone)
+    parity = main_res.get("parity_bit_exact")
+    rows = dist.all_gather_rows([rank, main_res["launch_us"], raw_main.num_envs * main_res["timed_steps"] /
+                                 (main_res["event_ms"] * 1e-3), -1.0 if parity is None else float(parity)], device=cdev)
+    per_rank = [{"rank": int(r[0]), "launch_us": r[1], "value": r[2],
+                 "parity_bit_exact": None if r[3] < 0 else bool(r[3])} for r in rows]
     cpu = None
     if single and not args.no_cpu:
         cpu = cpu_baseline(args, raw_main, args.p2_computer, args.wrappers)
         for k in ("parity_bit_exact", "parity_lanes_checked", "parity_steps_checked"):
             cpu[k] = main_res.get(k)
     del raw_main
+
+    # the same workload on the other kind of action tape: K + W distinct slices streamed from HBM (cold: 2 000 slices
+    # = 1 GB) vs a few slices re-used out of the caches (hot: what a policy that has just written its actions presents)
+    tape_bytes = (args.steps + args.warmup) * 2 * 4 * args.num_envs
+    tape_kind = "hot" if tape_bytes <= INFINITY_CACHE_BYTES // 4 else "cold"
+    other_tape = None
+    if single and not args.no_configs:
+        o_steps, o_warm = (2000, 200) if tape_kind == "hot" else (20, 5)
+        r = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers, flight_tables=tables,
+                    state_format=args.state_format, obs16=args.int16_obs, steps=o_steps, warmup=o_warm, burn=512,
+                    min_time=0.1)
+        r.pop("raw")
+        other_tape = {"action_tape": "cold" if tape_kind == "hot" else "hot", "steps": o_steps, "warmup": o_warm,
+                      "action_tape_bytes": (o_steps + o_warm) * 2 * 4 * args.num_envs, "value": r["value"],
+                      "launch_us": r["launch_us"], "frac": r["frac"]}
 
     configs = {}
     if single and not args.no_configs:
@@ -564,17 +711,39 @@ def main():
         for key, (wl, kw) in specs.items():
             r = measure(args, dist.weak_shard(kw["num_envs"], rank, world), device, **{**sub, **kw})
             r.pop("raw")
-            configs[key] = config_entry(r, wl, kw["num_envs"])
-            configs[key]["algorithmic_bytes_per_launch"] = r["algorithmic_bytes_per_launch"]
+            tk = traffic_key(kw["num_envs"], kw.get("p2_computer", False), kw.get("wrappers", False),
+                             kw.get("flight_tables", True), kw.get("state_format", "int32"), kw.get("obs16", False))
+            configs[key] = config_entry(r, wl, kw["num_envs"], tk)
         configs["cfg3"]["flight_tables"] = table_info
+        # the k-frame launches (state in registers, every frame's outputs to [k][N]... tensors), on
+        # their own 297 + 352 / k algorithmic bytes per game-step; write-dominated, so the rate a pure fill reaches
+        # on this box is printed beside them
+        ceiling = write_ceiling(device)
+        traj = {
+            "rollout_k32": ("pz_rollout_random, k = 32: 65 536 games, random policy drawn in the kernel", dict()),
+            "step_many_k32": ("pz_step_many, k = 32: 65 536 games, actions from a tape in HBM", dict(tape=True)),
+            "rollout_k32_p2_computer": ("pz_rollout_random, k = 32, player 2 = rule-based computer (flight tables)",
+                                        dict(p2_computer=True)),
+        }
+        for key, (wl, kw) in traj.items():
+            r = measure_rollout(args, shard, device, k=32, check_lanes=1024, **kw)
+            r.update(workload=wl, num_envs=args.num_envs, write_ceiling_GBps=ceiling,
+                     frac_of_write_ceiling=r["achieved_GBps"] / ceiling,
+                     bound_detail="every frame's outputs stream to HBM (623 MB per 32-frame launch): bound by the "
+                                  "memory system's write rate, which a kernel that only writes reaches at "
+                                  "write_ceiling_GBps on this box (tools/wstream.hip: the same for this store pattern)")
+            configs[key] = r
+        # the reference's own loop, literally -- sample both agents' actions, then step -- as ONE launch per step
+        r = measure_policy_in_the_loop(args, shard, device, fused=True)
+        r.update(workload="pz_step_random(k = 1): the uniform random policy drawn inside the step launch",
+                 num_envs=args.num_envs, launch_us=r["us_per_step"],
+                 frac=BYTES_PER_ENV_STEP * args.num_envs / (r["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                 regime=regime(args.num_envs))
+        configs["policy_fused_into_the_step"] = r
 
     extra = {}
     if args.extra and world == 1:
         extra["policy_in_the_loop"] = measure_policy_in_the_loop(args, shard, device)
-        extra["policy_fused_into_the_step"] = measure_policy_in_the_loop(args, shard, device, fused=True)
-        extra["rollout_k32"] = measure_rollout(args, shard, device, k=32)
-        extra["step_many_k32"] = measure_rollout(args, shard, device, k=32, tape=True)
-        extra["rollout_k32_p2_computer"] = measure_rollout(args, shard, device, k=32, p2_computer=True)
         # the same kernel at larger batches (more waves per SIMD hide each other's latency)
         sweep = {}
         for n_big in (262144, 524288, 1048576):
@@ -584,24 +753,21 @@ def main():
             sweep[str(n_big)] = {"value": r["value"], "launch_us": r["launch_us"], "achieved_GBps": r["achieved_GBps"],
                                  "frac_of_8TBps": r["frac"], "regime": regime(n_big)}
         extra["batch_sweep_random_random"] = sweep
-        for mode in ("cabi", "api"):
-            r = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers, launch=mode,
-                        burn=512, min_time=0.1)
-            r.pop("raw")
-            extra[f"launch_{mode}"] = {"value": r["value"], "launch_us": r["launch_us"]}
+        # what the host costs per step: direct C-ABI calls and env.step() (eager and through the bound entry point),
+        # for the three formats whose kernels differ most in duration
+        for fmt, kw in (("int32", {}), ("packed", dict(state_format="packed")),
+                        ("packed_int16obs", dict(state_format="packed", obs16=True))):
+            for mode in ("cabi", "api"):
+                r = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers, launch=mode,
+                            burn=512, min_time=0.1, **kw)
+                r.pop("raw")
+                extra[f"launch_{mode}_{fmt}"] = {"value": r["value"], "launch_us": r["launch_us"],
+                                                 "wall_us_per_step": r["wall_us_per_step"]}
 
     if rank == 0:
         alg_bytes = main_res["algorithmic_bytes_per_launch"]
-        wl = (("cfg3" if tables else "cfg3_compute") if args.p2_computer
-              else ("cfg5" if args.wrappers else "random_random"))
-        if args.num_envs != 65536 and wl == "random_random":
-            wl = f"random_random_{args.num_envs}"
-        if args.state_format == "packed":
-            wl = "packed_" + wl
-        if args.int16_obs:
-            wl += "_int16obs"
-        traffic = load_traffic(wl, args.num_envs)
-        launch_s = main_res["launch_us"] * 1e-6
+        wl = traffic_key(args.num_envs, args.p2_computer, args.wrappers, tables, args.state_format, args.int16_obs)
+        fr = fractions(main_res, args.num_envs, wl)
         out = {
             "metric": "env-steps/sec (random policy, 65 536 envs per GPU)",
             "value": main_res["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -612,7 +778,10 @@ def main():
             "timed_steps": main_res["timed_steps"], "replays": main_res["replays"],
             "launches_per_replay": main_res["launches_per_replay"], "timed_seconds": main_res["wall_s"],
             "burn_in_frames": args.burn_in,
-            "rccl_ranks": dist.world_size(), "dist_backend": dist.backend_name(), "dist_note": dist.fallback_note(),
+            # ranks = processes in the job; rccl_ranks = ranks of the RCCL group the counters travelled over (0: they
+            # went over gloo -- see dist_note -- which does not touch the measurement: no collective on the step path)
+            "ranks": dist.world_size(), "rccl_ranks": dist.rccl_ranks(), "dist_backend": dist.backend_name(),
+            "dist_note": dist.fallback_note(), "per_rank": per_rank,
             "build_id": _native.build_id(),
             "config": {
                 "workload": f"{args.num_envs} games per GPU, both players uniform-random actions "
@@ -622,23 +791,33 @@ def main():
                 "num_envs_per_gpu": args.num_envs, "num_envs_total": main_res["n_total"],
                 # the K + W action slices are distinct and streamed from HBM: a long tape (default 1.2 GB) is read cold,
                 # a short one (--steps 20: 13 MB) stays in the caches like actions a policy has just written
-                "action_tape_bytes": (args.steps + args.warmup) * 2 * 4 * args.num_envs,
+                "action_tape_bytes": tape_bytes, "action_tape": tape_kind,
                 "launch": args.launch,
                 "kernel": kernel_name(args.num_envs, args.p2_computer or args.p1_computer, tables,
                                       args.state_format == "packed"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": main_res["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": main_res["frac"], "traffic": traffic,
+                # `frac` is a CONTRACT-bytes figure: the algorithmic 649 B/game-step over the HIP-event
+                # launch duration over 8 TB/s -- not achieved HBM bandwidth: the changed-only write-back moves fewer
+                # bytes (`traffic`, `frac_traffic`: PMC counters), and at this batch size they move through the
+                # Infinity Cache (`regime`, `bound_detail`)
+                "frac": fr["frac"], "frac_basis": "algorithmic bytes (649 B per game-step) / HIP-event launch time / peak",
+                "traffic": fr["traffic"], "traffic_key": fr["traffic_key"],
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_us": main_res["launch_us"],
                 # the same fraction on the wall clock `value` is computed from (launch gaps included)
-                "frac_wall": main_res["frac_wall"],
+                "frac_wall": fr["frac_wall"],
                 # ... and with the PMC-measured bytes instead of the 649 B/game-step contract figure
-                "frac_traffic": (traffic / launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                "regime": regime(args.num_envs),
+                "frac_traffic": fr["frac_traffic"],
+                "regime": fr["regime"], "bound_detail": fr["bound_detail"],
             },
         }
+        if other_tape is not None:
+            out["other_action_tape"] = other_tape
         if cpu is not None:
+            # the reference itself never travels to the GPU box; its own Python step, measured in the survey container
+            cpu["reference_python"] = {"value": 55100, "unit": "env-steps/s/core", "hardware": "Xeon 2.1 GHz, survey "
+                                       "container (1 of 8 vCPU)", "source": "BASELINE.md section 2"}
             out["cpu_baseline"] = cpu
         if configs:
             out["configs"] = configs

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PZ_ABI_VERSION 5
+#define PZ_ABI_VERSION 6
 #define PZ_STATE_WORDS 44
 #define PZ_OBS_DIM 35
 
@@ -137,6 +137,10 @@ int64_t pz_packed_state_bytes(int64_t stride);
 /* int32 columns -> packed; *misfits (int64, device, may be NULL) += games with a value outside its field */
 int pz_pack_state(const int32_t *state, int64_t n, int64_t stride, void *packed, int64_t packed_stride,
                   int64_t *misfits, void *stream);
+/* *flagged (int64, device) += games whose sticky misfit flag is set: reads 8 bytes per game -- what a training loop
+ * on the packed format polls now and then (the step kernels raise the flag, nothing else reports it until the state
+ * is unpacked) */
+int pz_count_packed_misfits(const void *packed, int64_t n, int64_t packed_stride, int64_t *flagged, void *stream);
 /* packed -> int32 columns; *flagged (int64, device, may be NULL) += games whose misfit flag is set */
 int pz_unpack_state(const void *packed, int64_t n, int64_t packed_stride, int32_t *state, int64_t stride,
                     int64_t *flagged, void *stream);
@@ -208,6 +212,20 @@ int pz_step(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
             int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
             uint8_t *terminated, void *episode_stats, const pz_flight_tables *tables,
             void *stream);
+
+/* ---- pz_step with its arguments prepared once ---------------------------------------------
+ * A per-step caller (raw_env.step, pikazoo_env.py:175-240, is called once per frame) hands over the same twelve
+ * buffers and the same configuration every time; only the two action vectors and the stream change.  pz_step_bind
+ * validates and records everything else in a caller-provided HOST block of pz_step_bound_bytes() bytes (plain data:
+ * it may be copied or freed at will, the library keeps no reference and allocates nothing), pz_step_bound is then
+ * exactly pz_step on the recorded arguments.  What it saves is host time per step (an FFI call marshals 4 instead
+ * of 14 arguments and nothing is re-validated): where the launch lasts 5-7 us that is what decides whether the
+ * host or the GPU sets the step rate.  `cfg` and `tables` are copied at bind time: re-bind after changing them. */
+int64_t pz_step_bound_bytes(void);
+int pz_step_bind(void *bound, int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
+                 int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
+                 uint8_t *terminated, void *episode_stats, const pz_flight_tables *tables);
+int pz_step_bound(const void *bound, const int32_t *act_p1, const int32_t *act_p2, void *stream);
 
 /* ---- the same frame with the uniform random policy drawn on device ----------------------
  * actions of game g at step t come from Philox4x32-10(key=action_seed,

@@ -296,7 +296,7 @@ __device__ __forceinline__ void store_game_packed(const Game& g, const PackedIO&
 __device__ __forceinline__ RngId make_rng_id(const pz_config& cfg, int64_t lane_index)
 {
     const uint64_t gid = (uint64_t)(cfg.env_id_base + lane_index);
-    return RngId{(uint32_t)gid, (uint32_t)(gid >> 32), make_schedule(cfg.seed)};
+    return RngId{(uint32_t)gid, (uint32_t)(gid >> 32), make_rolling_key(cfg.seed)};
 }
 
 // ---- observation pack: _get_obs (pikazoo_env.py:576-624) ------------------------------------
@@ -717,8 +717,8 @@ struct TrajOut {
         // the rows are read back by this wave only: its LDS instructions execute in issue order
         wave_lds_handover<false>();
     }
-    // both tensors' pieces requested from LDS at once, `between()` (independent work of the caller), then the stores
-    // (no SGPR offset on the 16-byte stores: see flush_rows).  The row format is a compile-time parameter here.  As a
+    // the pieces requested from LDS at once, independent work of the caller (`between`), then the stores (no SGPR
+    // offset on the 16-byte stores: see flush_rows).  The row format is a compile-time parameter here.  As a
     // run-time branch it cost either way: with a store sequence per format the compiler sees a path through the frame
     // with no row store at all (the two branches are lowered through a flag it cannot correlate) and sizes the wait
     // for the computer player's loop-carried gathers for that path -- vmcnt(0), a full drain of the previous frame's
@@ -728,29 +728,13 @@ struct TrajOut {
     {
         const u32x4* src1 = reinterpret_cast<const u32x4*>(lds_obs[0]);
         const u32x4* src2 = reinterpret_cast<const u32x4*>(lds_obs[1]);
-        if constexpr (OBS16) {  // five pieces per tensor, each narrowed from two staged ones
-            u32x4 lo1[5], hi1[5], lo2[5], hi2[5];
-#pragma unroll
-            for (int pass = 0; pass < 5; ++pass) {
-                const int v = min(pass * kLanes + lane, kWaveObsVecs16 - 1);
-                lo1[pass] = src1[2 * v];
-                hi1[pass] = src1[2 * v + 1];
-                lo2[pass] = src2[2 * v];
-                hi2[pass] = src2[2 * v + 1];
-            }
-            between();
-            auto narrow = [](const u32x4 lo, const u32x4 hi) {
-                return u32x4{(lo.x & 0xFFFFu) | (lo.y << 16), (lo.z & 0xFFFFu) | (lo.w << 16),
-                             (hi.x & 0xFFFFu) | (hi.y << 16), (hi.z & 0xFFFFu) | (hi.w << 16)};
-            };
-            const Rsrc s1 = make_rsrc(obs1, obs_span_bytes), s2 = make_rsrc(obs2, obs_span_bytes);
-#pragma unroll
-            for (int pass = 0; pass < 5; ++pass)
-                __builtin_amdgcn_raw_buffer_store_b128(narrow(lo1[pass], hi1[pass]), s1, piece_off[pass], 0, PZ_OBS_AUX);
-#pragma unroll
-            for (int pass = 0; pass < 5; ++pass)
-                __builtin_amdgcn_raw_buffer_store_b128(narrow(lo2[pass], hi2[pass]), s2, piece_off[pass], 0, PZ_OBS_AUX);
+        if constexpr (OBS16) {
+            flush_tensor(src1, obs1, lane, between);
+            flush_tensor(src2, obs2, lane, [] {});
         } else {
+            // both tensors' 18 pieces in flight from LDS together (72 VGPRs: the wave has the register file to itself;
+            // tensor by tensor with the next frame's head under the second read batch was no faster,
+            // profiles/r03_experiments/ab_rollout_p2_computer_head_orderings.log)
             u32x4 p1[9], p2[9];
 #pragma unroll
             for (int pass = 0; pass < 9; ++pass) p1[pass] = src1[min(pass * kLanes + lane, kWaveObsVecs - 1)];
@@ -764,6 +748,37 @@ struct TrajOut {
 #pragma unroll
             for (int pass = 0; pass < 9; ++pass)
                 __builtin_amdgcn_raw_buffer_store_b128(p2[pass], s2, piece_off[pass], 0, PZ_OBS_AUX);
+        }
+    }
+    // one tensor's pieces requested from LDS at once (36 VGPRs), `between()`, their stores back to back
+    template <class Between>
+    __device__ __forceinline__ void flush_tensor(const u32x4* __restrict__ src, char* slab, int lane, Between&& between)
+    {
+        if constexpr (OBS16) {  // five pieces, each narrowed from two staged ones
+            u32x4 lo[5], hi[5];
+#pragma unroll
+            for (int pass = 0; pass < 5; ++pass) {
+                const int v = min(pass * kLanes + lane, kWaveObsVecs16 - 1);
+                lo[pass] = src[2 * v];
+                hi[pass] = src[2 * v + 1];
+            }
+            between();
+            const Rsrc span = make_rsrc(slab, obs_span_bytes);
+#pragma unroll
+            for (int pass = 0; pass < 5; ++pass) {
+                const u32x4 w = {(lo[pass].x & 0xFFFFu) | (lo[pass].y << 16), (lo[pass].z & 0xFFFFu) | (lo[pass].w << 16),
+                                 (hi[pass].x & 0xFFFFu) | (hi[pass].y << 16), (hi[pass].z & 0xFFFFu) | (hi[pass].w << 16)};
+                __builtin_amdgcn_raw_buffer_store_b128(w, span, piece_off[pass], 0, PZ_OBS_AUX);
+            }
+        } else {
+            u32x4 piece[9];
+#pragma unroll
+            for (int pass = 0; pass < 9; ++pass) piece[pass] = src[min(pass * kLanes + lane, kWaveObsVecs - 1)];
+            between();
+            const Rsrc span = make_rsrc(slab, obs_span_bytes);
+#pragma unroll
+            for (int pass = 0; pass < 9; ++pass)
+                __builtin_amdgcn_raw_buffer_store_b128(piece[pass], span, piece_off[pass], 0, PZ_OBS_AUX);
         }
     }
     static constexpr int kStores = OBS16 ? 10 : 18;  // row stores per frame
@@ -860,7 +875,8 @@ template <bool AI1, bool AI2, int MODE, bool SPARSE, int SCOUT = kNoScout, bool 
 // (trajectory modes: one wave per SIMD by design -- two with a scout wave -- so the wave may have its share of the whole
 //  register file: a frame's 18 row pieces are in flight from LDS together)
 __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes)
-__attribute__((amdgpu_waves_per_eu(1, (MODE == kRollout || MODE == kTape) ? (SCOUT != kNoScout ? 2 : PZ_TRAJ_WAVES) : 8)))
+__attribute__((amdgpu_waves_per_eu((MODE == kRollout || MODE == kTape) && SCOUT != kNoScout ? 2 : 1,
+                                   (MODE == kRollout || MODE == kTape) ? (SCOUT != kNoScout ? 2 : PZ_TRAJ_WAVES) : 8)))
 void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
 {
     const HotArgs hot{state, n, stride, act_p1, act_p2};
@@ -911,10 +927,10 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
 
     Game g{};
     RngId id = make_rng_id(a.cfg, live ? i : 0);
-    KeySchedule policy = make_schedule(a.action_seed);
+    KeySchedule policy = make_rolling_key(a.action_seed);
     if (MODE != kActions) {  // the frame loop's two key schedules live in VGPRs (see KeySchedule)
-        park_in_vgprs(id.ks);
-        if (MODE != kTape) park_in_vgprs(policy);
+        id.ks = make_parked_schedule(a.cfg.seed);
+        if (MODE != kTape) policy = make_parked_schedule(a.action_seed);
     }
     const FlightLut lut = make_lut(a.tables);
     int reward = 0;
@@ -949,15 +965,15 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
     if (MODE != kActions) {
         const uint32_t n_actions = a.cfg.simplify_action ? 13u : 18u;
         constexpr bool kTraj = MODE == kRollout || MODE == kTape;
-        // Human vs human: computer_boldness is drawn at every round start (physics.py:218) and read by nothing, so only
+        // A human player's computer_boldness is drawn at every round start (physics.py:218) and read by nothing, so only
         // the LAST draw of a launch is observable (in the state written back): the frames remember that draw's
-        // counter and the two Philox blocks run once, behind the loop, instead of on three frames out of four.
+        // counter and the Philox block runs once, behind the loop, instead of on three frames out of four.
 #ifndef PZ_NO_DEFER_BOLD
-        constexpr bool kDeferBold = !AI1 && !AI2;
+        constexpr bool kDefer1 = !AI1, kDefer2 = !AI2;
 #else
-        constexpr bool kDeferBold = false;
+        constexpr bool kDefer1 = false, kDefer2 = false;
 #endif
-        BoldDefer bold{false, 0u};
+        BoldDefer bold{false, false, 0u, 0u};
         TrajOut<OBS16> out;
         if (kTraj) out.init(a, i, lane, live);
         if (MODE != kTape) policy_actions(id.id_lo, id.id_hi, policy, a.t0, n_actions, a1, a2);
@@ -975,7 +991,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
 #ifdef PZ_NO_HEAD_PIPELINE
         FrameHead head{};
 #else
-        FrameHead head = frame_head<AI1, AI2, SCOUT, kDeferBold>(g, a.cfg, id, live, lane, lut, link, &bold);
+        FrameHead head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold);
         // The compiler sizes the tail's wait for the head's gathers for the worst path into the loop: from here
         // nothing would follow them (vmcnt(0): every frame drains its predecessor's row stores after all), around the
         // back edge a frame's 18 row stores do.  Eighteen dropped stores make the two paths look alike: vmcnt(18).
@@ -984,7 +1000,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
         for (int32_t s = 0; s < a.k; ++s) {
 #ifdef PZ_NO_HEAD_PIPELINE
             resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
-            head = frame_head<AI1, AI2, SCOUT, kDeferBold>(g, a.cfg, id, live, lane, lut, link, &bold);
+            head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold);
 #endif
             if (MODE == kTape) {
                 // The tape is fetched kTapeChunk frames at a time and parked in LDS: a per-frame global load
@@ -1022,25 +1038,27 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
                 if (MODE != kTape)
                     policy_actions(id.id_lo, id.id_hi, policy, a.t0 + (uint64_t)s + 1u, n_actions, a1, a2);
             };
-            if (kTraj) out.stage(a, g, rw, as_float, live, a1, a2, MODE == kRollout && a.act_out != nullptr, lane, lds_obs);
+            auto next_head = [&]() {  // this frame's outputs are staged: the game may move on
 #ifndef PZ_NO_HEAD_PIPELINE
-            if (s + 1 < a.k) {  // (this frame's outputs are staged: the game may move on)
-                resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
-                head = frame_head<AI1, AI2, SCOUT, kDeferBold>(g, a.cfg, id, live, lane, lut, link, &bold);
-            }
+                if (s + 1 < a.k) {
+                    resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
+                    head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold);
+                }
 #endif
+            };
             if (kTraj) {
+                out.stage(a, g, rw, as_float, live, a1, a2, MODE == kRollout && a.act_out != nullptr, lane, lds_obs);
+                next_head();
                 out.flush(lds_obs, lane, next_policy);
                 out.advance();
             } else {
                 next_policy();
+                next_head();
             }
         }
-        if (kDeferBold && bold.pending) {  // draws number `counter`, `counter + 1` of the env stream (physics.py:218)
-            uint32_t counter = bold.counter;
-            g.p1.bold = rng_integers(id, counter, 5u);
-            g.p2.bold = rng_integers(id, counter, 5u);
-        }
+        // the launch's last recorded boldness draws (physics.py:218)
+        if (kDefer1 && bold.pending1) g.p1.bold = rng_integers(id, bold.counter1, 5u);
+        if (kDefer2 && bold.pending2) g.p2.bold = rng_integers(id, bold.counter2, 5u);
     } else if (!PZ_SKIP_FRAME) {
         const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
         reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane, lut,
@@ -1151,7 +1169,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         if (with_stats) sio.load(st);
     }
     if (RANDOM)  // (issued behind the loads: the block runs while they are in flight)
-        policy_actions(id.id_lo, id.id_hi, make_schedule(a.action_seed), a.t0, a.cfg.simplify_action ? 13u : 18u, a1, a2);
+        policy_actions(id.id_lo, id.id_hi, make_rolling_key(a.action_seed), a.t0, a.cfg.simplify_action ? 13u : 18u, a1, a2);
     const Game loaded = g;  // what the columns held before the frame
     const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     bool frozen = false;
@@ -1406,7 +1424,7 @@ __global__ __launch_bounds__(256) void random_actions_kernel(int32_t* act_p1, in
     if (i >= n) return;
     const uint64_t gid = (uint64_t)(env_id_base + i);
     int a1, a2;
-    policy_actions((uint32_t)gid, (uint32_t)(gid >> 32), make_schedule(action_seed), t, n_actions, a1, a2);
+    policy_actions((uint32_t)gid, (uint32_t)(gid >> 32), make_rolling_key(action_seed), t, n_actions, a1, a2);
     act_p1[i] = a1;
     act_p2[i] = a2;
 }
@@ -1424,6 +1442,18 @@ __global__ __launch_bounds__(kLanes) void pack_state_kernel(const int32_t* state
     PackedWords flagged{};
     flagged.a.y = fits ? 0u : kPackedOverflowBit;  // a misfit stays visible in the packed state
     AnyIO<true>(packed, packed_stride, i).store(g, flagged);
+}
+
+__global__ __launch_bounds__(256) void count_misfits_kernel(const void* packed, int64_t n, int64_t packed_stride,
+                                                            unsigned long long* flagged)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // word 1 of group A and of group B carry the sticky flags (pz_packed.hpp)
+    const uint32_t* a = static_cast<const uint32_t*>(packed);
+    const uint32_t* b = a + packed_stride * 4;
+    const bool bad = i < n && ((a[i * 4 + 1] | b[i * 4 + 1]) & kPackedOverflowBit) != 0;
+    const unsigned long long votes = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && votes != 0ull) atomicAdd(flagged, (unsigned long long)__popcll(votes));
 }
 
 __global__ __launch_bounds__(kLanes) void unpack_state_kernel(const void* packed, int64_t n, int64_t packed_stride,
@@ -1958,6 +1988,17 @@ int pz_pack_state(const int32_t* state, int64_t n, int64_t stride, void* packed,
     return (int)hipGetLastError();
 }
 
+int pz_count_packed_misfits(const void* packed, int64_t n, int64_t packed_stride, int64_t* flagged, void* stream)
+{
+    if (packed == nullptr || flagged == nullptr) return PZ_E_NULL;
+    if (n < 0 || packed_stride < n || packed_stride > kMaxLanesPerLaunch) return PZ_E_SIZE;
+    if (misaligned16(packed)) return PZ_E_ALIGN;
+    if (n == 0) return PZ_OK;
+    hipLaunchKernelGGL(count_misfits_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, packed, n,
+                       packed_stride, reinterpret_cast<unsigned long long*>(flagged));
+    return (int)hipGetLastError();
+}
+
 int pz_unpack_state(const void* packed, int64_t n, int64_t packed_stride, int32_t* state, int64_t stride, int64_t* flagged,
                     void* stream)
 {
@@ -1982,6 +2023,42 @@ int pz_step(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, con
     if (tables_misaligned(tables)) return PZ_E_ALIGN;
     StepArgs a{state,  n,          stride,        act_p1,  act_p2, 0, 0, 1, nullptr, obs_p1, obs_p2, rew_p1,
                rew_p2, terminated, episode_stats, nullptr, tables_of(tables), *cfg};
+    return launch_step<kActions>(a, (hipStream_t)stream);
+}
+
+// pz_step with its arguments prepared once: the block holds the StepArgs pz_step would build
+struct BoundStep {
+    uint64_t magic;
+    StepArgs args;
+};
+constexpr uint64_t kBoundMagic = 0x70696b617a6f6f36ull;  // "pikazoo6"
+
+int64_t pz_step_bound_bytes(void) { return (int64_t)sizeof(BoundStep); }
+
+int pz_step_bind(void* bound, int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, int32_t* obs_p1,
+                 int32_t* obs_p2, void* rew_p1, void* rew_p2, uint8_t* terminated, void* episode_stats,
+                 const pz_flight_tables* tables)
+{
+    if (bound == nullptr) return PZ_E_NULL;
+    if (int e = check_common(state, n, stride, cfg)) return e;
+    if (!obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
+    if (misaligned16(obs_p1) || misaligned16(obs_p2) || tables_misaligned(tables)) return PZ_E_ALIGN;
+    BoundStep* b = static_cast<BoundStep*>(bound);
+    b->args = StepArgs{state,  n,          stride,        nullptr, nullptr, 0, 0, 1, nullptr, obs_p1, obs_p2, rew_p1,
+                       rew_p2, terminated, episode_stats, nullptr, tables_of(tables), *cfg};
+    b->magic = kBoundMagic;
+    return PZ_OK;
+}
+
+int pz_step_bound(const void* bound, const int32_t* act_p1, const int32_t* act_p2, void* stream)
+{
+    const BoundStep* b = static_cast<const BoundStep*>(bound);
+    if (b == nullptr || !act_p1 || !act_p2) return PZ_E_NULL;
+    if (b->magic != kBoundMagic) return PZ_E_CONFIG;  // not a block pz_step_bind has filled
+    if (b->args.n == 0) return PZ_OK;
+    StepArgs a = b->args;
+    a.act_p1 = act_p1;
+    a.act_p2 = act_p2;
     return launch_step<kActions>(a, (hipStream_t)stream);
 }
 

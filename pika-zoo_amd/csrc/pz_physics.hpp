@@ -76,34 +76,42 @@ struct Game {
 struct Input {
     int xd, yd, hit;
 };
-// The ten round keys of a Philox key (k + r * Weyl constant).  Wave-uniform values; as plain scalars the compiler
-// either recomputes them at every block (straight-line kernels: fine) or, in a frame loop, hoists all of them and then
-// spills them -- two key schedules are 40 SGPRs of the 102, and every spilled key comes back through a v_readlane in
-// front of its xor.  The k-frame kernels therefore park their schedules in VGPRs (park_in_vgprs), of which a lone wave
-// per SIMD has hundreds to spare.
+// A Philox key and how its ten round keys (k + r * Weyl constant) are held.  They are wave-uniform values:
+//   rolling  (straight-line kernels) only the key itself is kept, every block steps through its round keys with
+//            scalar adds -- what the compiler schedules best there (materialising the twenty of them once costs the
+//            pair kernel 26 more SGPRs and 1.5-4 % per launch);
+//   parked   (the k-frame kernels) in a frame loop the compiler hoists all twenty and then spills them -- two keys
+//            are 40 SGPRs of the 102, and every spilled round key comes back through a v_readlane in front of its
+//            xor -- so the loop kernels hold their schedules in VGPRs (park_in_vgprs), of which a lone wave per SIMD
+//            has hundreds to spare.
+// `rolling` is a compile-time constant wherever it is read (everything here is inlined).
 struct KeySchedule {
-    uint32_t k0[10], k1[10];
+    bool rolling;
+    uint32_t k0[10], k1[10];  // rolling: only [0] is set
 };
 
-__device__ __forceinline__ KeySchedule make_schedule(uint32_t k0, uint32_t k1)
+__device__ __forceinline__ KeySchedule make_rolling_key(uint64_t key)
 {
-    KeySchedule ks;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        ks.k0[r] = k0 + (uint32_t)r * 0x9E3779B9u;
-        ks.k1[r] = k1 + (uint32_t)r * 0xBB67AE85u;
-    }
+    KeySchedule ks{};
+    ks.rolling = true;
+    ks.k0[0] = (uint32_t)key;
+    ks.k1[0] = (uint32_t)(key >> 32);
     return ks;
 }
-__device__ __forceinline__ KeySchedule make_schedule(uint64_t key) { return make_schedule((uint32_t)key, (uint32_t)(key >> 32)); }
 
-__device__ __forceinline__ void park_in_vgprs(KeySchedule& ks)
+__device__ __forceinline__ KeySchedule make_parked_schedule(uint64_t key)
 {
+    KeySchedule ks{};
+    ks.rolling = false;
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        asm("v_mov_b32 %0, %1" : "=v"(ks.k0[r]) : "s"(ks.k0[r]));
-        asm("v_mov_b32 %0, %1" : "=v"(ks.k1[r]) : "s"(ks.k1[r]));
+        asm("v_mov_b32 %0, %1" : "=v"(ks.k0[r]) : "s"(k0));
+        asm("v_mov_b32 %0, %1" : "=v"(ks.k1[r]) : "s"(k1));
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
     }
+    return ks;
 }
 
 // per-lane RNG identity (Philox counter words 0,1) and the env stream's key
@@ -117,21 +125,28 @@ struct RngId {
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
 {
+#ifdef PZ_NO_BITOP3
+    return a ^ b ^ c;
+#else
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // one v_bitop3_b32 (gfx950) instead of two v_xor_b32
+#endif
 }
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               const KeySchedule& ks, uint32_t& o0, uint32_t& o1)
 {
+    uint32_t r0 = ks.k0[0], r1 = ks.k1[0];
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         // one 32x32->64 multiply per lane pair (v_mad_u64_u32) instead of separate hi/lo products
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        c0 = xor3((uint32_t)(p1 >> 32), c1, ks.k0[r]);
+        c0 = xor3((uint32_t)(p1 >> 32), c1, ks.rolling ? r0 : ks.k0[r]);
         c1 = (uint32_t)p1;
-        c2 = xor3((uint32_t)(p0 >> 32), c3, ks.k1[r]);
+        c2 = xor3((uint32_t)(p0 >> 32), c3, ks.rolling ? r1 : ks.k1[r]);
         c3 = (uint32_t)p0;
+        r0 += 0x9E3779B9u;
+        r1 += 0xBB67AE85u;
     }
     o0 = c0;
     o1 = c1;
@@ -550,14 +565,23 @@ struct FlightLut {
         uint32_t e = __umul24((uint32_t)(yv + PZ_FT_YV_MAX), (uint32_t)kFtXvCount) + (uint32_t)xi;
         e = __umul24(e, (uint32_t)kFtYCount) + (uint32_t)y;
         e = __umul24(e, (uint32_t)kFtXCount) + (uint32_t)(x - kBallRadius);
+#ifdef PZ_LANDING_B16
+        offset = in ? e * 2u : 0u;
+        return LandingProbe{in, wanted, 0u, 0u};
+#else
         offset = in ? (e * 2u) & ~3u : 0u;
         return LandingProbe{in, wanted, (e & 1u) * 16u, 0u};
+#endif
     }
     __device__ __forceinline__ LandingProbe landing_issue(bool wanted, int x, int y, int xv, int yv) const
     {
         uint32_t offset;
         LandingProbe p = landing_locate(wanted, x, y, xv, yv, offset);
+#ifdef PZ_LANDING_B16
+        p.value = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(landing, offset, 0, 0);
+#else
         p.value = __builtin_amdgcn_raw_buffer_load_b32(landing, offset, 0, 0);
+#endif
         return p;
     }
     __device__ __forceinline__ int landing_finish(const LandingProbe& p, int x, int y, int xv, int yv, int keep) const
@@ -592,7 +616,9 @@ struct FlightLut {
     {
         // the row's fourth dword is padding: keep its register reserved until here all the same -- handed out as a
         // temporary while the load is in flight, the first write to it would have to wait for the whole gather
+#ifndef PZ_NO_W_KEEPALIVE
         asm volatile("" ::"v"(p.value.w));
+#endif
         ex[0] = (int)(p.value.x & 0xFFFFu);
         ex[1] = (int)(p.value.x >> 16);
         ex[2] = (int)(p.value.y & 0xFFFFu);
@@ -991,25 +1017,29 @@ struct ScoutLink {
     int32_t* posts;       // LDS [64][kPostPitch]  (kScoutPosted)
 };
 
-// DEFER_BOLD (human vs human, k-frame launches): a round start records the counter of its two boldness draws in
-// `*bold` instead of drawing them -- computer_boldness is read by the computer player's decision only, so the caller
-// makes the launch's last recorded draw once, behind its frame loop.
+// Deferred boldness draws (k-frame launches): computer_boldness is drawn for every player at every round start
+// (physics.py:218) but read by the computer player's decision only.  For a HUMAN player a round start therefore just
+// records the draw's counter; the caller makes the launch's last recorded draw once, behind its frame loop, instead of
+// a Philox block on three frames out of four (a wave of 64 games almost always has a round starting somewhere).
 struct BoldDefer {
-    bool pending;
-    uint32_t counter;
+    bool pending1, pending2;
+    uint32_t counter1, counter2;
 };
 
 // The frame comes in two halves, so that a k-frame launch can run the head of frame t+1 BEFORE it stores frame t's
 // observation rows (pz_kernels.hip, step_kernel): the head ends by issuing the computer player's table gathers, and
 // gfx9 counts loads and stores in one in-order vmcnt -- gathers issued behind a frame's 18 row stores are not back
-// before those have drained, gathers issued in front of them are (5.5 -> 4.3 us per frame was the drain).
+// before those have drained, gathers issued in front of them are.
 //   frame_head  [auto-reset / new round (its draws)] -> ball-world step -> [scout post] -> gathers + pre-drawn decision
 //               words issued;
 //   frame_tail  action decode -> decisions -> player moves -> ball-player collisions -> scoring.
 // Nothing between the two may touch the game: the caller stages frame t's outputs before head(t+1).
 // Only what cannot be re-derived crosses from head to tail (in a k-frame launch: around the loop's back edge) -- the
 // ball-world step's result and the registers the gathers land in, untouched; everything else the tail recomputes from
-// the game, which nothing moves in between.
+// the game, which nothing moves in between.  (Issuing the gathers earlier still -- the next ball computed on a copy
+// before the outputs are staged, the round start committed afterwards -- was built and lost: twelve more live
+// registers and the duplicated restart logic cost more than the extra latency hiding bought,
+// profiles/r03_experiments/ab_rollout_p2_computer_head_orderings.log.)
 struct FrameHead {
     bool frozen, ground;
     uint32_t landing_word;    // LandingProbe::value
@@ -1017,11 +1047,12 @@ struct FrameHead {
     PreDrawn pre;
 };
 
-template <bool AI1, bool AI2, int SCOUT = kNoScout, bool DEFER_BOLD = false>
+// DEFER1 / DEFER2: player 1's / 2's boldness draw is recorded in *bold instead of made (human players, k-frame launches)
+template <bool AI1, bool AI2, int SCOUT = kNoScout, bool DEFER1 = false, bool DEFER2 = false>
 __device__ __forceinline__ FrameHead frame_head(Game& g, const pz_config& cfg, const RngId& id, bool live, int lane,
                                                 const FlightLut& lut, const ScoutLink link, BoldDefer* bold)
 {
-    static_assert(!DEFER_BOLD || (!AI1 && !AI2), "a computer player reads its boldness");
+    static_assert(!(DEFER1 && AI1) && !(DEFER2 && AI2), "a computer player reads its boldness");
     // The reference empties `agents` on termination (:237-238) and expects reset() before the
     // next step; auto_reset applies reset() (:149-164) in place.  Both that and the new-round
     // branch (:176-180) end in the same per-round initialisation, kept at one call site so the
@@ -1039,16 +1070,24 @@ __device__ __forceinline__ FrameHead frame_head(Game& g, const pz_config& cfg, c
                 g.e.s2 = 0;
             }
             g.e.round_ended = 0;
-            if (DEFER_BOLD) {
+            // draw order of the reference: player 1's boldness, player 2's [, the serve]
+            if (DEFER1) {
                 player_new_round_undrawn(g.p1, 36);
-                player_new_round_undrawn(g.p2, kGroundWidth - 36);
-                bold->pending = true;
-                bold->counter = g.e.rng;
-                g.e.rng += 2u;
-                ball_new_round(g.b, get_server(cfg, g.e, id));
+                bold->pending1 = true;
+                bold->counter1 = g.e.rng;
+                g.e.rng += 1u;
             } else {
-                start_round(g, cfg, id);
+                player_new_round(g.p1, 36, id, g.e.rng);
             }
+            if (DEFER2) {
+                player_new_round_undrawn(g.p2, kGroundWidth - 36);
+                bold->pending2 = true;
+                bold->counter2 = g.e.rng;
+                g.e.rng += 1u;
+            } else {
+                player_new_round(g.p2, kGroundWidth - 36, id, g.e.rng);
+            }
+            ball_new_round(g.b, get_server(cfg, g.e, id));
         }
         PZ_FRAME_STAMP(1);
         // physics_engine
@@ -1224,14 +1263,13 @@ __device__ __forceinline__ int frame_tail(Game& g, const pz_config& cfg, const R
 }
 
 // head and tail back to back: the single-frame launches
-template <bool AI1, bool AI2, int SCOUT = kNoScout, bool DEFER_BOLD = false>
+template <bool AI1, bool AI2, int SCOUT = kNoScout>
 __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
                                           bool& frozen, int32_t* __restrict__ scratch, int lane,
                                           const FlightLut& lut, const ScoutLink link = ScoutLink{nullptr, nullptr, nullptr},
-                                          bool* ex_pending = nullptr, const bool last_frame = true,
-                                          BoldDefer* bold = nullptr)
+                                          bool* ex_pending = nullptr, const bool last_frame = true)
 {
-    FrameHead h = frame_head<AI1, AI2, SCOUT, DEFER_BOLD>(g, cfg, id, live, lane, lut, link, bold);
+    FrameHead h = frame_head<AI1, AI2, SCOUT>(g, cfg, id, live, lane, lut, link, nullptr);
     frozen = h.frozen;
     return frame_tail<AI1, AI2, SCOUT, true>(g, cfg, id, a1, a2, live, h, scratch, lane, lut, link, ex_pending, last_frame);
 }

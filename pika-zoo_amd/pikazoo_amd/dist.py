@@ -41,11 +41,51 @@ def weak_shard(n_per_gpu: int, rank: int, world_size: int) -> Shard:
     return Shard(rank, world_size, int(n_per_gpu), rank * int(n_per_gpu), world_size * int(n_per_gpu))
 
 
+_COUNTERS = None       # the RCCL group the counters travel over (None: the gloo control group / no group at all)
+_FALLBACK_NOTE = None
+
+
+def _shares_a_gpu(rank: int, world: int, index: int):
+    """Collective over the control group: do two ranks of one host use the same GPU?  (RCCL refuses that --
+    "Duplicate GPU detected" -- so every rank learns it here, before any of them has touched RCCL.)"""
+    import socket
+
+    mine = (socket.gethostname(), os.environ.get("ROCR_VISIBLE_DEVICES"), os.environ.get("HIP_VISIBLE_DEVICES"),
+            os.environ.get("CUDA_VISIBLE_DEVICES"), int(index))
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    return len(set(everyone)) < world
+
+
+def _start_rccl(rank: int, world: int, index: int):
+    """This rank's attempt at an RCCL group over all ranks: (group or None, why not)."""
+    try:
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible")
+        torch.cuda.set_device(index)
+        dev = torch.device("cuda", index)
+        group = dist.new_group(backend="nccl", timeout=timedelta(seconds=120))
+        probe = torch.ones(1, dtype=torch.int64, device=dev)  # the communicator works before anything is timed
+        dist.all_reduce(probe, group=group)
+        if int(probe.item()) != world:
+            raise RuntimeError(f"RCCL all-reduce of ones gave {int(probe.item())}, expected {world}")
+        return group, None
+    except Exception as exc:  # noqa: BLE001 - RCCL only carries the aggregate counters: keep the job alive
+        return None, f"{type(exc).__name__}: {exc}"[:300]
+
+
 def init_from_env(backend: str | None = None, device_index: int | None = None) -> tuple[int, int, int]:
     """Join the process group described by RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun).
 
     Returns (rank, world_size, local_rank).  Single-process runs (no WORLD_SIZE) skip the group.
-    `device_index`: the GPU this rank uses when it is not LOCAL_RANK (rehearsals with several ranks on one GPU)."""
+    `device_index`: the GPU this rank uses when it is not LOCAL_RANK (rehearsals with several ranks on one GPU).
+
+    The default group is ALWAYS gloo (barriers, and every decision the ranks have to take together); with
+    `backend` "nccl" (the default on a GPU box) an RCCL group over all ranks is added for the counters.  Whether
+    RCCL is used is decided COLLECTIVELY: every rank reports over gloo whether its communicator came up and its
+    probe all-reduce gave the world size, and if any rank failed, all of them leave the counters on gloo and say
+    so (`fallback_note`, `rccl_ranks() == 0`) -- no rank is ever left waiting in a rendezvous the others skipped."""
+    global _COUNTERS, _FALLBACK_NOTE
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -56,53 +96,59 @@ def init_from_env(backend: str | None = None, device_index: int | None = None) -
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=180))
         if backend == "nccl":
-            try:
-                index = local_rank if device_index is None else int(device_index)
-                torch.cuda.set_device(index)
-                dev = torch.device("cuda", index)
-                dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
-                probe = torch.ones(1, dtype=torch.int64, device=dev)  # the communicator works before anything is timed
-                dist.all_reduce(probe)
-                if int(probe.item()) != world:
-                    raise RuntimeError(f"RCCL all-reduce of ones gave {int(probe.item())}, expected {world}")
-            except Exception as exc:  # noqa: BLE001 - RCCL only carries the aggregate counters: keep the job alive
-                global _FALLBACK_NOTE
-                _FALLBACK_NOTE = f"nccl (RCCL) unavailable: {type(exc).__name__}: {exc}"[:300]
-                print(f"[pikazoo_amd.dist] {_FALLBACK_NOTE}; the counters fall back to gloo", file=sys.stderr, flush=True)
-                if dist.is_initialized():
-                    try:
-                        dist.destroy_process_group()
-                    except Exception:  # noqa: BLE001
-                        pass
-                # same rendezvous (under torchrun the store is served by the launcher's agent, not by rank 0)
-                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=180))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            index = local_rank if device_index is None else int(device_index)
+            if _shares_a_gpu(rank, world, index):
+                group, why = None, "two ranks share one GPU (RCCL refuses duplicate GPUs)"
+            else:
+                group, why = _start_rccl(rank, world, index)
+            verdict = torch.tensor([1 if group is not None else 0], dtype=torch.int64)
+            dist.all_reduce(verdict, op=dist.ReduceOp.MIN)  # over gloo: one failure anywhere moves everybody
+            if int(verdict.item()) == 1:
+                _COUNTERS = group
+            else:
+                _COUNTERS = None  # (a communicator that did come up on this rank is left alone: tearing it down may block)
+                _FALLBACK_NOTE = ("nccl (RCCL) unavailable: " + (why or "another rank could not start it"))[:300]
+                if rank == 0:
+                    print(f"[pikazoo_amd.dist] {_FALLBACK_NOTE}; the counters stay on gloo", file=sys.stderr, flush=True)
+        elif backend != "gloo":
+            raise ValueError(f"backend must be 'nccl' or 'gloo', got {backend!r}")
     return rank, world, local_rank
 
 
-_FALLBACK_NOTE = None
-
-
 def fallback_note():
-    """Why the process group is not on the requested nccl backend (None when it is, or was never asked for)."""
+    """Why the counters are not on the requested nccl backend (None when they are, or when it was never asked for)."""
     return _FALLBACK_NOTE
 
 
+def _on_counters_device(t: torch.Tensor, device):
+    return t.to(device) if (_COUNTERS is not None and device is not None) else t
+
+
 def all_reduce_sum(values, device=None) -> list[int]:
-    """SUM over ranks of a short list of integer counters (one tiny all-reduce)."""
-    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    """SUM over ranks of a short list of integer counters (one tiny all-reduce: RCCL when it is up, else gloo)."""
+    t = _on_counters_device(torch.tensor([int(v) for v in values], dtype=torch.int64), device)
     if dist.is_initialized():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_COUNTERS)
     return [int(v) for v in t.tolist()]
 
 
 def all_reduce_max(value: float, device=None) -> float:
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = _on_counters_device(torch.tensor([float(value)], dtype=torch.float64), device)
     if dist.is_initialized():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_COUNTERS)
     return float(t.item())
+
+
+def all_gather_rows(row, device=None) -> list[list[float]]:
+    """Every rank's short list of floats, in rank order (one all-gather)."""
+    t = _on_counters_device(torch.tensor([float(v) for v in row], dtype=torch.float64), device)
+    if not dist.is_initialized():
+        return [t.tolist()]
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t, group=_COUNTERS)
+    return [o.tolist() for o in out]
 
 
 def get_rank() -> int:
@@ -115,8 +161,15 @@ def world_size() -> int:
 
 
 def backend_name() -> str:
-    """"nccl" (= RCCL on ROCm), "gloo", or "none" for a single process without a group."""
-    return str(dist.get_backend()) if dist.is_initialized() else "none"
+    """What carries the counters: "nccl" (= RCCL on ROCm), "gloo", or "none" for a single process without a group."""
+    if not dist.is_initialized():
+        return "none"
+    return "nccl" if _COUNTERS is not None else "gloo"
+
+
+def rccl_ranks() -> int:
+    """Ranks in the RCCL group the counters travel over; 0 when they travel over gloo (or there is no group)."""
+    return dist.get_world_size(group=_COUNTERS) if _COUNTERS is not None else 0
 
 
 def barrier():
@@ -126,6 +179,4 @@ def barrier():
 
 def collective_device(gpu_device):
     """Device the counters of all_reduce_* must live on: the GPU under nccl (RCCL), the CPU under gloo."""
-    if dist.is_initialized() and dist.get_backend() == "nccl":
-        return gpu_device
-    return None
+    return gpu_device if _COUNTERS is not None else None

@@ -76,6 +76,22 @@ def flight_tables(device: torch.device):
     return hit
 
 
+class _OutputSet:
+    """One set of the buffers a step writes (observations, rewards, terminations) with what is cached per set: the raw
+    pointers, the `pz_step_bind` block and the result tuple ``step()`` returns (its dicts hold views of these buffers)."""
+
+    __slots__ = ("obs", "rew", "term_u8", "term", "ptrs", "bound", "bound_key", "result")
+
+    def __init__(self, obs, rew, term_u8, state_ptr):
+        self.obs, self.rew, self.term_u8 = obs, rew, term_u8
+        self.term = term_u8.view(torch.bool)
+        self.ptrs = (state_ptr, obs[0].data_ptr(), obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(),
+                     term_u8.data_ptr())
+        self.bound = None       # ctypes block filled by pz_step_bind
+        self.bound_key = None   # the configuration it was bound for (_result_key)
+        self.result = None
+
+
 class raw_env:
     """``pikazoo_v0.raw_env`` for ``num_envs`` games at once.
 
@@ -110,8 +126,13 @@ class raw_env:
     the punch effect is drawn too: its two ball attributes are tracked after every ``step()``, a k-frame
     launch clears it; off by default, which keeps ``render()`` free of side effects and ``step()`` a single launch).
 
-    Returned tensors are views of env-owned buffers that the next ``step`` overwrites;
-    ``clone()`` what must outlive it.
+    ``output_ring`` (k >= 1 rotating sets of the observation / reward / termination buffers: the reference returns
+    FRESH arrays from every ``step`` (pikazoo_env.py:215-235), this env returns views of env-owned buffers -- with
+    the default ring of 1 the next ``step`` overwrites them, with ``output_ring=k`` the results of the last k
+    ``step`` / ``reset`` calls stay intact, e.g. 2 for a loop that still reads the previous observation).
+
+    Returned tensors are views of env-owned buffers that the ``output_ring``-th next ``step`` overwrites;
+    ``clone()`` what must outlive that.
     """
 
     metadata = {"render_modes": ["rgb_array"], "name": "pikazoo_v0", "render_fps": 20, "is_parallelizable": True}
@@ -121,7 +142,7 @@ class raw_env:
                  device="cuda", seed: int = 0, env_id_base: int = 0, auto_reset: Optional[bool] = None,
                  validate_actions: bool = True, scalar_api: bool = False, flight_tables: bool = True,
                  sprite_dir=None, sprites=None, state_format: str = "int32", scenery: bool = False,
-                 observation_dtype=torch.int32):
+                 observation_dtype=torch.int32, output_ring: int = 1):
         assert serve in ("winner", "alternate", "random")  # pikazoo_env.py:104
         if render_mode not in (None, "rgb_array"):
             raise NotImplementedError('render_mode must be None or "rgb_array" (no "human" window on a GPU batch)')
@@ -139,6 +160,8 @@ class raw_env:
             raise ValueError('scenery=True needs render_mode="rgb_array"')
         if state_format == "packed" and int(winning_score) > 32767:
             raise ValueError("the packed state format holds scores up to 32767")
+        if int(output_ring) < 1:
+            raise ValueError("output_ring must be >= 1")
         self._lib = _native.load()  # raises when the HIP library has not been built
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -183,6 +206,7 @@ class raw_env:
         cfg.env_id_base = self.env_id_base
         self._cfg = cfg
         self._cfg_ref = C.byref(cfg)
+        self._cfg_version = 0  # bumped by every _fuse_* method
         self._tables = None
         self._tables_ref = None  # `const pz_flight_tables*` of every step call (None: compute in the kernel)
         if flight_tables and (cfg.p1_computer or cfg.p2_computer):
@@ -204,20 +228,20 @@ class raw_env:
             self._state_view = self._state_buf[:, :n]
             self._scores = self._state_view[_E_SCORE_P1:_E_SCORE_P1 + 2].t()  # live [n, 2] view of the state
         self._state_ptr = self._state_buf.data_ptr()
-        self._obs = [torch.zeros((n, _native.OBS_DIM), dtype=torch.int32, device=dev) for _ in range(2)]
-        # one 4-byte word per lane and agent; viewed as int32 or float32 (RewardByBallPosition)
-        self._rew_raw = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
-        self._term_u8 = torch.zeros(n, dtype=torch.uint8, device=dev)
-        self._term = self._term_u8.view(torch.bool)
+        # the output buffers: `output_ring` sets, used in rotation (one set: every step overwrites the last results)
+        self._ring = []
+        for _ in range(int(output_ring)):
+            obs = [torch.zeros((n, _native.OBS_DIM), dtype=torch.int32, device=dev) for _ in range(2)]
+            # one 4-byte word per lane and agent; viewed as int32 or float32 (RewardByBallPosition)
+            rew = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
+            term = torch.zeros(n, dtype=torch.uint8, device=dev)
+            self._ring.append(_OutputSet(obs, rew, term, self._state_ptr))
+        self._ring_pos = 0
+        self._use_outputs(self._ring[0])
         self._trunc = torch.zeros(n, dtype=torch.bool, device=dev)  # always False (pikazoo_env.py:234)
         self._episodes = torch.zeros(1, dtype=torch.int64, device=dev)
         self._stats = None  # RecordEpisodeStatistics buffer (20 bytes per game), allocated when the wrapper is fused
         self._ep_returns = self._ep_lengths = None
-        # raw pointers of the env-owned buffers (fixed for the env's lifetime) and the cached result tuple:
-        # the dicts returned by step() hold views of those buffers, so they can be reused between steps
-        self._ptrs = (self._state_ptr, self._obs[0].data_ptr(), self._obs[1].data_ptr(),
-                      self._rew_raw[0].data_ptr(), self._rew_raw[1].data_ptr(), self._term_u8.data_ptr())
-        self._step_result = None
         self.steps_done = 0  # frames stepped by this env (per lane)
 
         self.action_spaces = {a: Discrete(18) for a in self.possible_agents}
@@ -233,6 +257,30 @@ class raw_env:
                 "pz_scenery_init"))
 
     # ------------------------------------------------------------------------------------------
+    def _use_outputs(self, out):
+        """Make `out` (an _OutputSet of the ring) the set the next launch writes."""
+        self._out = out
+        self._obs, self._rew_raw, self._term_u8, self._term, self._ptrs = out.obs, out.rew, out.term_u8, out.term, out.ptrs
+
+    def _next_outputs(self):
+        """Rotate to the ring's next output set (a no-op with the default ring of one)."""
+        if len(self._ring) > 1:
+            self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+            self._use_outputs(self._ring[self._ring_pos])
+
+    def _bound_step(self):
+        """The current output set's `pz_step_bind` block for the current configuration (bound on first use; a wrapper
+        fused later, or statistics switched on, re-binds)."""
+        out, key = self._out, self._result_key()
+        if out.bound is None or out.bound_key != key:
+            if out.bound is None:
+                out.bound = C.create_string_buffer(int(self._lib.pz_step_bound_bytes()))
+            p = out.ptrs
+            _native.check(self._lib.pz_step_bind(out.bound, p[0], self.num_envs, self._stride, self._cfg_ref, p[1], p[2],
+                                                 p[3], p[4], p[5], self._stats_ptr(), self._tables_ref), "pz_step_bind")
+            out.bound_key = key
+        return out.bound
+
     def _stream(self):
         """Raw handle of the caller's current stream on this env's device (every launch goes there)."""
         return _raw_stream(self._dev_index)
@@ -315,6 +363,21 @@ class raw_env:
         self._state_buf.copy_(staged)
 
     @property
+    def packed_misfits(self) -> int:
+        """Games of a ``state_format="packed"`` env whose sticky misfit flag is set: a value left its field (never
+        seen in 1.3e11 game-steps of play; a planted, unreachable state can do it).  The step kernels raise the flag
+        and keep stepping -- nothing else reports it until the state is unpacked (:attr:`state`, :meth:`state_dict`,
+        which raise) -- so a loop that never reads the state should poll this now and then (one small launch reading
+        8 bytes per game, and a sync).  Always 0 for the int32 format."""
+        if self._state_view is not None:
+            return 0
+        flagged = torch.zeros(1, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.pz_count_packed_misfits(self._state_ptr, self.num_envs, self._stride,
+                                                            flagged.data_ptr(), self._stream()), "pz_count_packed_misfits")
+        return int(flagged.item())
+
+    @property
     def episodes_done(self) -> int:
         """Games finished inside ``step_random`` launches (device counter; syncs)."""
         return int(self._episodes.item())
@@ -325,6 +388,7 @@ class raw_env:
         if self._cfg.simplify_action:
             raise RuntimeError("SimplifyAction is already applied")
         self._cfg.simplify_action = 1
+        self._cfg_version += 1
         self.action_spaces = {a: Discrete(13) for a in self.possible_agents}
 
     def _fuse_ballpos_reward(self, additional_reward, x_line: int, y_line: int):
@@ -341,6 +405,7 @@ class raw_env:
         self._cfg.x_line, self._cfg.y_line = int(x_line), int(y_line)
         for i, v in enumerate(additional_reward):
             self._cfg.additional_reward[i] = float(v)
+        self._cfg_version += 1
 
     def _fuse_normal_state_reward(self, reward):
         """wrappers/reward_in_normal_state.py:10-15 inside the kernel; remembers whether it was applied
@@ -351,6 +416,7 @@ class raw_env:
             raise NotImplementedError("RecordEpisodeStatistics between two reward wrappers cannot be fused")
         self._cfg.normal_state_mode = 2 if self._cfg.ballpos_reward else 1
         self._cfg.normal_state_reward = float(reward)
+        self._cfg_version += 1
 
     def _fuse_normalize_obs(self):
         """wrappers/normalize_observation.py:18-35 inside the kernel: observations become float32."""
@@ -359,6 +425,7 @@ class raw_env:
         if self._cfg.normalize_obs == 2:
             raise NotImplementedError("NormalizeObservation emits float32: create the env with observation_dtype=torch.int32")
         self._cfg.normalize_obs = 1
+        self._cfg_version += 1
 
     def _fuse_episode_stats(self):
         """wrappers/record_episode_statistics.py:27-40 inside the kernel (three words per game)."""
@@ -370,6 +437,7 @@ class raw_env:
         self._stats = torch.zeros(20 * self._stride, dtype=torch.uint8, device=self.device)
         self._ep_returns = self._stats[:16 * self._stride].view(torch.float64).view(2, self._stride)[:, :self.num_envs]
         self._ep_lengths = self._stats[16 * self._stride:].view(torch.int32)[:self.num_envs]
+        self._cfg_version += 1
 
     @property
     def episode_returns(self) -> Optional[torch.Tensor]:
@@ -448,8 +516,9 @@ class raw_env:
         return None if self._stats is None else self._stats.data_ptr()
 
     def _result_key(self):
-        c = self._cfg
-        return (c.ballpos_reward, c.normal_state_mode, c.normalize_obs, c.episode_stats_mode)
+        """Changes whenever the configuration does (a wrapper fused, statistics switched on): what a `pz_step_bind`
+        block and a cached result tuple were made for."""
+        return self._cfg_version
 
     def _pack_step(self):
         rew = self._rewards()
@@ -480,6 +549,7 @@ class raw_env:
         ``seed`` and ``options`` are accepted and ignored, like the reference (it never re-seeds,
         pikazoo_env.py:149-173); the env stream continues from each lane's draw counter."""
         self.agents = self.possible_agents[:]
+        self._next_outputs()
         m = None
         if mask is not None:
             m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
@@ -537,15 +607,17 @@ class raw_env:
             if int(lo.item()) < 0 or int(hi.item()) >= n_act:
                 # the reference's table lookup raises IndexError (pikazoo_env.py:182)
                 raise IndexError(f"action out of range [0, {n_act})")
-        p = self._ptrs
-        if torch.cuda.current_device() == self.device.index:
-            rc = self._lib.pz_step(p[0], n, self._stride, self._cfg_ref, a1.data_ptr(), a2.data_ptr(), p[1], p[2],
-                                   p[3], p[4], p[5], self._stats_ptr(), self._tables_ref,
-                                   _raw_stream(self._dev_index))
+        if len(self._ring) > 1:
+            self._next_outputs()
+        out = self._out
+        # pz_step through its prepared-argument form: one FFI call with four scalars (the twelve buffers and the
+        # configuration were bound once) -- the host side of a step stays below the duration of the launch it issues
+        bound = out.bound if out.bound_key == self._result_key() else self._bound_step()
+        if torch.cuda.current_device() == self._dev_index:
+            rc = self._lib.pz_step_bound(bound, a1.data_ptr(), a2.data_ptr(), _raw_stream(self._dev_index))
         else:
             with torch.cuda.device(self.device):
-                rc = self._lib.pz_step(p[0], n, self._stride, self._cfg_ref, a1.data_ptr(), a2.data_ptr(), p[1], p[2],
-                                       p[3], p[4], p[5], self._stats_ptr(), self._tables_ref, self._stream())
+                rc = self._lib.pz_step_bound(bound, a1.data_ptr(), a2.data_ptr(), self._stream())
         if rc:
             _native.check(rc, "pz_step")
         if self._scenery is not None:
@@ -553,10 +625,10 @@ class raw_env:
         self.steps_done += 1
         if self.scalar_api:
             return self._pack_step()
-        out = self._step_result
-        if out is None or out[0] != self._result_key():
-            out = self._step_result = (self._result_key(), self._pack_step())
-        return out[1]
+        res = out.result
+        if res is None or res[0] != out.bound_key:
+            res = out.result = (out.bound_key, self._pack_step())
+        return res[1]
 
     def step_random(self, action_seed: int, t0: Optional[int] = None, k: int = 1):
         """``k`` frames under the uniform random policy drawn on device (Philox stream
@@ -564,6 +636,7 @@ class raw_env:
         launch.  Returns the last frame's step tuple."""
         if t0 is None:
             t0 = self.steps_done
+        self._next_outputs()
         with torch.cuda.device(self.device):
             _native.check(self._lib.pz_step_random(self._state_ptr, self.num_envs, self._stride,
                                                    self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0),
@@ -647,6 +720,7 @@ class raw_env:
         return torch.int16 if self._cfg.normalize_obs == 2 else torch.int32
 
     def _finish_trajectory(self, out):
+        self._next_outputs()
         dt, odt = self.reward_dtype, self.obs_dtype
         rew = [r if dt == torch.int32 else r.view(torch.float32) for r in out["_rew"]]
         out["obs"] = dict(zip(self.possible_agents, [o if o.dtype == odt else o.view(odt) for o in out["_obs"]]))

@@ -43,7 +43,7 @@ def test_binding_matches_library_layout(built_lib):
     from pikazoo_amd import _native
 
     lib = _native.load()
-    assert lib.pz_abi_version() == 5 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
+    assert lib.pz_abi_version() == 6 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
     assert lib.pz_config_bytes() == C.sizeof(_native.PzConfig) == 104
     assert lib.pz_error_string(0) == b"ok" and b"NULL" in lib.pz_error_string(-1)
     assert C.sizeof(_native.PzFlightTables) == 16
@@ -164,12 +164,14 @@ from pikazoo_amd import dist
 rank, world, _ = dist.init_from_env("nccl")   # no GPU in this container: RCCL cannot come up
 total, = dist.all_reduce_sum([rank + 1])
 if rank == 0:
-    open(os.path.join(sys.argv[2], "fallback.txt"), "w").write(f"{dist.backend_name()} {world} {total} {dist.fallback_note()}")
+    open(os.path.join(sys.argv[2], "fallback.txt"), "w").write(
+        f"{dist.backend_name()} {world} {total} {dist.rccl_ranks()} {dist.fallback_note()}")
 '''
 
 
 def test_counters_fall_back_to_gloo_when_rccl_cannot_start(tmp_path):
-    """RCCL only carries the aggregate counters; if it cannot start, the ranks agree on gloo and say so."""
+    """RCCL only carries the aggregate counters; if it cannot start, the ranks agree -- collectively, over the gloo
+    control group -- on leaving them there and say so: `rccl_ranks` is then 0, not the world size."""
     import torch
 
     if torch.cuda.is_available():
@@ -180,8 +182,8 @@ def test_counters_fall_back_to_gloo_when_rccl_cannot_start(tmp_path):
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                            "--master-addr", "127.0.0.1", "--master-port", "29543", str(script), str(REPO),
                            str(tmp_path)], env=env, timeout=600)
-    backend, world, total, note = (tmp_path / "fallback.txt").read_text().split(" ", 3)
-    assert (backend, world, total) == ("gloo", "2", "3") and "unavailable" in note
+    backend, world, total, rccl, note = (tmp_path / "fallback.txt").read_text().split(" ", 4)
+    assert (backend, world, total, rccl) == ("gloo", "2", "3", "0") and "unavailable" in note
 
 
 def test_two_rank_sharding_equals_single_process(tmp_path, oracle):
@@ -232,6 +234,16 @@ def test_argument_validation_without_a_gpu(built_lib):
         assert lib.pz_step_random(fake, 8, 8, C.byref(cfg), 1, 0, 1, fake, fake, fake, fake, fake, None, None,
                                   C.byref(bad), None) == -4
     assert lib.pz_build_flight_tables(None, None, None) == -1
+    # the prepared-argument form of pz_step: a host block the caller owns, validated at bind time
+    block = C.create_string_buffer(int(lib.pz_step_bound_bytes()))
+    assert lib.pz_step_bound(block, fake, fake, None) == -3                                        # not bound yet
+    assert lib.pz_step_bind(None, fake, 8, 8, C.byref(cfg), fake, fake, fake, fake, fake, None, None) == -1
+    assert lib.pz_step_bind(block, fake, 8, 4, C.byref(cfg), fake, fake, fake, fake, fake, None, None) == -2
+    assert lib.pz_step_bind(block, fake, 8, 8, C.byref(cfg), C.c_void_p(4100), fake, fake, fake, fake, None, None) == -4
+    assert lib.pz_step_bind(block, fake, 0, 0, C.byref(cfg), fake, fake, fake, fake, fake, None, None) == 0
+    assert lib.pz_step_bound(block, fake, fake, None) == 0                                         # n == 0: no launch
+    assert lib.pz_step_bound(block, None, fake, None) == -1
+    assert lib.pz_count_packed_misfits(None, 8, 8, fake, None) == -1 and lib.pz_count_packed_misfits(fake, 8, 4, fake, None) == -2
     # the landing table: its 2-byte entries (an odd number) + 2 bytes of padding -- the look-up loads whole dwords
     assert lib.pz_flight_table_bytes(0) == 2 * 193 * 23 * 253 * 413 + 2 and lib.pz_flight_table_bytes(1) == 16 * 65 * 192 * 413
 

@@ -288,6 +288,89 @@ def test_graph_replay_equals_eager_launches():
     assert torch.equal(term["player_1"], want_term)
 
 
+def test_output_ring_keeps_the_previous_results_intact():
+    """The reference returns fresh arrays from every step (pikazoo_env.py:215-235); this env returns views of its own
+    buffers -- by default one set, overwritten by the next step; with output_ring=k the last k results stay intact."""
+    from pikazoo_amd import pikazoo_v0
+
+    one = pikazoo_v0.env(num_envs=300, seed=5, validate_actions=False)
+    two = pikazoo_v0.env(num_envs=300, seed=5, validate_actions=False, output_ring=2)
+    with pytest.raises(ValueError):
+        pikazoo_v0.env(num_envs=4, output_ring=0)
+    o1, _ = one.reset()
+    o2, _ = two.reset()
+    prev1 = prev2 = kept = None
+    for t in range(8):
+        a = one.random_actions(3, t)
+        r1, r2 = one.step(a), two.step(a)
+        for x, y in zip(r1[:3], r2[:3]):  # observations, rewards, terminations: the same trajectory either way
+            for agent in one.possible_agents:
+                assert torch.equal(x[agent], y[agent])
+        if prev2 is not None:
+            # ring of two: the previous step's tensors are other tensors and still hold the previous step's values
+            assert r2[0]["player_1"].data_ptr() != prev2[0]["player_1"].data_ptr()
+            for got, want in zip((prev2[0]["player_1"], prev2[0]["player_2"], prev2[1]["player_1"], prev2[2]["player_1"]), kept):
+                assert torch.equal(got, want)
+            # default: one set of buffers, the same tensors every step
+            assert r1[0]["player_1"].data_ptr() == prev1[0]["player_1"].data_ptr()
+        prev1, prev2 = r1, r2
+        kept = [r2[0]["player_1"].clone(), r2[0]["player_2"].clone(), r2[1]["player_1"].clone(), r2[2]["player_1"].clone()]
+    # reset() rotates too: the first observations of a ring env survive the first step
+    three = pikazoo_v0.env(num_envs=64, seed=1, validate_actions=False, output_ring=3)
+    first, _ = three.reset()
+    snap = first["player_2"].clone()
+    three.step(three.random_actions(1, 0))
+    three.step(three.random_actions(1, 1))
+    assert torch.equal(first["player_2"], snap)
+
+
+def test_step_through_the_bound_entry_point_equals_pz_step():
+    """raw_env.step goes through pz_step_bind / pz_step_bound (the arguments prepared once per output set and
+    configuration); the trajectory must be the one direct pz_step calls produce, wrappers fused later re-bind."""
+    from pikazoo_amd import _native, pikazoo_v0
+    from pikazoo_amd.wrappers import RewardByBallPosition, SimplifyAction
+
+    lib = _native.load()
+    n = 1000
+    env = pikazoo_v0.env(num_envs=n, seed=9, is_player2_computer=True, validate_actions=False)
+    ref = pikazoo_v0.env(num_envs=n, seed=9, is_player2_computer=True, validate_actions=False)
+    env.reset()
+    ref.reset()
+    raw = ref.unwrapped
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def direct(a):  # the twelve-argument call on ref's own buffers
+        p = raw._ptrs
+        assert lib.pz_step(p[0], n, raw._stride, raw._cfg_ref, a["player_1"].data_ptr(), a["player_2"].data_ptr(), p[1], p[2],
+                           p[3], p[4], p[5], raw._stats_ptr(), raw._tables_ref, stream) == 0
+
+    for t in range(40):
+        a = env.random_actions(2, t)
+        obs, rew, term, _, _ = env.step(a)
+        direct(a)
+    assert torch.equal(env.state, ref.state) and torch.equal(obs["player_1"], raw._obs[0])
+    # a wrapper fused after the first steps changes the configuration: the next step must not use the stale block
+    env = RewardByBallPosition(SimplifyAction(env), (0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01), 216, 176)
+    raw._fuse_simplify_action()
+    raw._fuse_ballpos_reward((0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01), 216, 176)
+    for t in range(40, 80):
+        a = env.unwrapped.random_actions(2, t)
+        obs, rew, term, _, _ = env.step(a)
+        direct(a)
+    assert rew["player_1"].dtype == torch.float32
+    assert torch.equal(env.unwrapped.state, ref.state) and torch.equal(rew["player_1"].view(torch.int32), raw._rew_raw[0])
+    # the block is plain data the library validates: an unbound one is refused, bad arguments fail at bind time
+    import ctypes as C
+
+    blank = C.create_string_buffer(int(lib.pz_step_bound_bytes()))
+    a = env.unwrapped.random_actions(2, 0)
+    assert lib.pz_step_bound(blank, a["player_1"].data_ptr(), a["player_2"].data_ptr(), stream) == -3  # PZ_E_CONFIG
+    p = raw._ptrs
+    assert lib.pz_step_bind(blank, p[0], n, raw._stride, raw._cfg_ref, p[1] + 4, p[2], p[3], p[4], p[5], None, None) == -4
+    assert lib.pz_step_bind(blank, p[0], n, raw._stride, raw._cfg_ref, p[1], p[2], p[3], p[4], p[5], None, None) == 0
+    assert lib.pz_step_bound(blank, None, a["player_2"].data_ptr(), stream) == -1
+
+
 def test_scalar_api_default_loop_terminates_like_the_reference():
     """`while env.agents:` around a scalar_api env must end at the game's end without any extra kwarg
     (auto_reset defaults to False there; the reference empties `agents`, pikazoo_env.py:237-238)."""

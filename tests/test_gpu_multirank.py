@@ -97,19 +97,40 @@ def test_two_ranks_through_the_hip_path_equal_the_single_batch(tmp_path):
 
 
 def test_bench_with_two_ranks_prints_the_aggregate_line():
-    """`bench.py --gpus 2` under torch.distributed.run as the driver launches it; both ranks share cuda:0
-    (PZ_BENCH_ONE_DEVICE) and gloo stands in for RCCL.  value must be the whole-job aggregate."""
+    """Plain `python bench.py --gpus 2`: bench.py starts its two ranks itself (a child torch.distributed.run, what the
+    driver would have started); both share cuda:0 (PZ_BENCH_ONE_DEVICE) and gloo stands in for RCCL.  value must be
+    the whole-job aggregate, every rank reports its own figures, and the first and the last rank replay their games
+    on the oracle."""
     env = dict(os.environ, PZ_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), str(REPO / "bench.py"), "--gpus", "2", "--steps", "64",
-           "--warmup", "8", "--burn-in", "128", "--min-time", "0.05", "--dist-backend", "gloo", "--no-cpu"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=str(REPO))
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "64", "--warmup", "8", "--burn-in", "128",
+           "--min-time", "0.05", "--dist-backend", "gloo", "--cpu-threads", "4"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(REPO))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["dist_backend"] == "gloo"
+    # gloo carried the counters: that is said, and not counted as RCCL ranks
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["rccl_ranks"] == 0 and out["dist_backend"] == "gloo"
     assert out["config"]["num_envs_total"] == 2 * 65536 and out["scaling"] == "weak"
     assert out["timed_steps"] >= 64 and out["timed_seconds"] >= 0.05
     per_step_s = out["ms_per_step"] * 1e-3
     assert np.isclose(out["value"], 2 * 65536 / per_step_s, rtol=1e-6)
     assert "configs" not in out and "cpu_baseline" not in out  # single-GPU extras stay off for N > 1
+    assert [p["rank"] for p in out["per_rank"]] == [0, 1]
+    for p in out["per_rank"]:
+        assert p["launch_us"] > 0 and p["value"] > 0 and p["parity_bit_exact"] is True  # both ends of the job checked
+
+
+def test_bench_under_the_drivers_launcher_and_rccl_request_on_one_gpu():
+    """The driver's own launch line (torch.distributed.run around bench.py), asking for RCCL: two ranks on one GPU is
+    what RCCL refuses, so all ranks agree -- before any of them touches RCCL -- to leave the counters on gloo, and the
+    line says so instead of claiming two RCCL ranks."""
+    env = dict(os.environ, PZ_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(REPO / "bench.py"), "--gpus", "2", "--steps", "32",
+           "--warmup", "4", "--burn-in", "64", "--min-time", "0.05", "--no-cpu"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(REPO))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["ranks"] == 2 and out["rccl_ranks"] == 0 and out["dist_backend"] == "gloo"
+    assert "share one GPU" in out["dist_note"]
+    assert all(p["parity_bit_exact"] is None for p in out["per_rank"])  # --no-cpu: nothing was replayed

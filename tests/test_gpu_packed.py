@@ -110,7 +110,9 @@ def test_pack_counts_states_that_do_not_fit_and_the_flag_survives():
     penv = make_env(num_envs=256, seed=1, state_format="packed")
     with pytest.raises(ValueError, match="outside the packed format"):
         penv.unwrapped.set_state(bad)
+    assert penv.unwrapped.packed_misfits == 0
     penv.unwrapped._state_buf.copy_(packed)
+    assert penv.unwrapped.packed_misfits == 6  # the poll a loop that never unpacks the state should make now and then
     with pytest.raises(RuntimeError, match="misfit flag"):
         penv.unwrapped.state
     lib = _lib()
@@ -387,10 +389,13 @@ def test_unreachable_player_state_raises_the_misfit_flag():
     st[14, 9], st[15, 9], st[16, 9] = 112, -16, 1    # player 2 of game 9
     env.unwrapped.set_state(st)                      # every field fits: accepted
     noop = torch.zeros(128, dtype=torch.int32, device="cuda:0")
+    assert env.unwrapped.packed_misfits == 0
     for _ in range(12):
         env.step({"player_1": noop, "player_2": noop})
+    assert env.unwrapped.packed_misfits == 2  # visible without unpacking anything (pz_count_packed_misfits)
     with pytest.raises(_native.PikazooNativeError, match="2 games carry"):
         env.unwrapped.state
+    assert make_env(num_envs=8).unwrapped.packed_misfits == 0  # (int32 columns: nothing to flag)
 
 
 @pytest.mark.parametrize("fmt", ["int32", "packed"])

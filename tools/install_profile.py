@@ -17,16 +17,20 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
 PROFILES = REPO / "profiles"
 
-# traffic.json key -> (section prefix of profile.sh, kernel)
+# traffic.json key (bench.py: traffic_key) -> (section prefix of profile.sh, kernel, games)
 TRAFFIC = {
-    "random_random": ("hh", "pz::step_pair_kernel<false, false, false, false>"),
-    "cfg3": ("cfg3", "pz::step_pair_kernel<false, true, false, false>"),
-    "cfg3_compute": ("cfg3c", "pz::step_kernel<false, true, 0, true, 1, false>"),
-    "random_random_524288": ("big", "pz::step_kernel<false, false, 0, true, 0, false>"),
-    "packed_random_random": ("pk", "pz::step_pair_kernel<false, false, true, false>"),
-    "packed_random_random_524288": ("pkbig", "pz::step_pair_kernel<false, false, true, false>"),
-    "packed_random_random_int16obs": ("ph", "pz::step_pair_kernel<false, false, true, false>"),
-    "packed_random_random_524288_int16obs": ("phbig", "pz::step_pair_kernel<false, false, true, false>"),
+    "random_random": ("hh", "pz::step_pair_kernel<false, false, false, false>", 65536),
+    "random_random_4096": ("cfg2", "pz::step_pair_kernel<false, false, false, false>", 4096),
+    "cfg3": ("cfg3", "pz::step_pair_kernel<false, true, false, false>", 65536),
+    "cfg3_compute": ("cfg3c", "pz::step_kernel<false, true, 0, true, 1, false, false>", 65536),
+    "cfg5": ("cfg5", "pz::step_pair_kernel<false, false, false, false>", 65536),
+    "random_random_524288": ("big", "pz::step_kernel<false, false, 0, true, 0, false, false>", 524288),
+    "random_random_int16obs": ("i16", "pz::step_pair_kernel<false, false, false, false>", 65536),
+    "packed_random_random": ("pk", "pz::step_pair_kernel<false, false, true, false>", 65536),
+    "packed_cfg3": ("pkcfg3", "pz::step_pair_kernel<false, true, true, false>", 65536),
+    "packed_random_random_524288": ("pkbig", "pz::step_pair_kernel<false, false, true, false>", 524288),
+    "packed_random_random_int16obs": ("ph", "pz::step_pair_kernel<false, false, true, false>", 65536),
+    "packed_random_random_524288_int16obs": ("phbig", "pz::step_pair_kernel<false, false, true, false>", 524288),
 }
 
 
@@ -46,14 +50,14 @@ def main():
     derived = json.loads((src / f"{tag}_pmc_summary.json").read_text())["derived"]
     tpath = PROFILES / "traffic.json"
     traffic = json.loads(tpath.read_text())
-    for key, (prefix, kernel) in TRAFFIC.items():
+    for key, (prefix, kernel, games) in TRAFFIC.items():
         e = derived.get(prefix, {}).get(kernel)
         if e is None or "hbm_bytes_per_launch" not in e:
             print(f"  (no counters for {key}: section {prefix} missing)")
             continue
         traffic.setdefault(key, {}).update(hbm_bytes_per_launch=e["hbm_bytes_per_launch"],
                                            fetch_size_kb_raw=e["fetch_size_kb_raw"], write_size_kb=e["write_size_kb"],
-                                           kernel=kernel, round=tag)
+                                           kernel=kernel, round=tag, num_envs=games)
         print(f"  traffic {key}: {e['hbm_bytes_per_launch'] / 1e6:.2f} MB = 2 x {e['fetch_size_kb_raw']:.0f} KB read + "
               f"{e['write_size_kb']:.0f} KB written")
     tpath.write_text(json.dumps(traffic, indent=1))
@@ -79,8 +83,9 @@ def main():
                 print(f"  bench: build {d['build_id']}: {d['value'] / 1e9:.2f} G, {r['launch_us']:.2f} us, frac {r['frac']:.3f}, "
                       f"frac_wall {r['frac_wall']:.3f}, frac_traffic {r['frac_traffic']}, cpu {d['cpu_baseline']['value'] / 1e6:.0f} M")
                 for k, v in d.get("configs", {}).items():
-                    print(f"    {k}: {v['value'] / 1e9:.2f} G, {v['launch_us']:.2f} us, frac {v['frac']:.3f}, "
-                          f"parity {v.get('parity_bit_exact')}")
+                    us = v.get("launch_us", v.get("us_per_frame"))
+                    print(f"    {k}: {v['value'] / 1e9:.2f} G, {us:.2f} us, frac {v['frac']:.3f}, "
+                          f"frac_traffic {v.get('frac_traffic')}, {v.get('regime')}, parity {v.get('parity_bit_exact')}")
             else:
                 for k, v in d.get("extra", {}).items():
                     if isinstance(v, dict) and "us_per_frame" in v:

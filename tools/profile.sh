@@ -10,6 +10,8 @@
 #   pmc_roll  the four passes on the k-frame kernels (pz_rollout_random human and player 2 = computer, pz_step_many; k = 32)
 #   kt_hh     --kernel-trace --stats of the headline workload ALONE (no other config shares its kernel row)
 #   calib     FETCH_SIZE / WRITE_SIZE on known-byte kernels of the step kernels' access widths (tools/calib_traffic.hip)
+#   pmc_more  FETCH_SIZE / WRITE_SIZE of the remaining bench entries: config 2 (4 096 games), config 5 (fused wrappers),
+#             config 3 on the packed format, int32 state + int16 observations
 #   pmc_pk    the four passes on the headline workload with the packed state format (65 536 games)
 #   pmc_pkbig FETCH_SIZE / WRITE_SIZE / kernel stats at 524 288 games with the packed state format
 #   pmc_ph    FETCH_SIZE / WRITE_SIZE / kernel stats: packed state + int16 observations, 65 536 and 524 288 games
@@ -20,7 +22,7 @@
 set -u
 TAG=${1:?tag}
 shift
-SECTIONS=${*:-kt pmc_hh pmc_cfg3 pmc_cfg3c pmc_big kt_roll pmc_pk pmc_pkbig pmc_ph}
+SECTIONS=${*:-kt kt_hh pmc_hh pmc_cfg3 pmc_cfg3c pmc_big pmc_more kt_roll pmc_roll pmc_pk pmc_pkbig pmc_ph calib}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -33,6 +35,13 @@ run() {  # name, rocprof args..., -- , program args
     shift
     echo "== $name" | tee -a "$OUT/log.txt"
     rocprofv3 -d "$OUT/$name" -o run -f csv "$@" > "$OUT/$name.log" 2>&1 || { echo "rocprofv3 failed: $name (see $OUT/$name.log)" | tee -a "$OUT/log.txt"; tail -5 "$OUT/$name.log"; return 1; }
+}
+
+pmc_fw() {  # prefix, bench args...: the two traffic passes only
+    local p=$1
+    shift
+    run "${p}_fetch" --kernel-trace --pmc FETCH_SIZE -- $PY bench.py "$@" || return 1
+    run "${p}_write" --kernel-trace --pmc WRITE_SIZE -- $PY bench.py "$@" || return 1
 }
 
 pmc_set() {  # prefix, bench args...
@@ -67,6 +76,12 @@ for s in $SECTIONS; do
         run phbig_fetch --kernel-trace --pmc FETCH_SIZE -- $PY bench.py --no-cpu --no-configs --state-format packed --int16-obs --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
         run phbig_write --kernel-trace --pmc WRITE_SIZE -- $PY bench.py --no-cpu --no-configs --state-format packed --int16-obs --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
         run phbig_kt --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --state-format packed --int16-obs --num-envs 524288 --steps 300 --warmup 50 --burn-in 256 --launch cabi || exit 1
+        ;;
+    pmc_more)
+        pmc_fw cfg2 --no-cpu --no-configs --num-envs 4096 --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1
+        pmc_fw cfg5 --no-cpu --no-configs --wrappers --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1
+        pmc_fw pkcfg3 --no-cpu --no-configs --p2-computer --state-format packed --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1
+        pmc_fw i16 --no-cpu --no-configs --int16-obs --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1
         ;;
     kt_roll) run roll --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --rollouts || exit 1 ;;
     pmc_roll) pmc_set roll --no-cpu --no-configs --rollouts || exit 1 ;;

@@ -167,6 +167,19 @@ int main(int argc, char** argv)
                (long long)n, k);
         fflush(stdout);
     };
+    if (argc > 3) {  // cache-policy sweep of the trajectory pattern (aux bits: 1 = sc0, 2 = nt, 16 = sc1)
+        for (int round = 0; round < 2; ++round) {
+            report("traj aux=0 plain", time_us([&] { hipLaunchKernelGGL(traj<0>, dim3(waves), dim3(64), 0, 0, o); }, reps));
+            report("traj aux=1 sc0", time_us([&] { hipLaunchKernelGGL(traj<1>, dim3(waves), dim3(64), 0, 0, o); }, reps));
+            report("traj aux=2 nt", time_us([&] { hipLaunchKernelGGL(traj<2>, dim3(waves), dim3(64), 0, 0, o); }, reps));
+            report("traj aux=3 nt sc0", time_us([&] { hipLaunchKernelGGL(traj<3>, dim3(waves), dim3(64), 0, 0, o); }, reps));
+            report("traj aux=16 sc1", time_us([&] { hipLaunchKernelGGL(traj<16>, dim3(waves), dim3(64), 0, 0, o); }, reps));
+            report("traj aux=17 sc0 sc1", time_us([&] { hipLaunchKernelGGL(traj<17>, dim3(waves), dim3(64), 0, 0, o); }, reps));
+            report("traj aux=18 nt sc1", time_us([&] { hipLaunchKernelGGL(traj<18>, dim3(waves), dim3(64), 0, 0, o); }, reps));
+            report("traj aux=19 nt sc0 sc1", time_us([&] { hipLaunchKernelGGL(traj<19>, dim3(waves), dim3(64), 0, 0, o); }, reps));
+        }
+        return 0;
+    }
     for (int round = 0; round < 2; ++round) {
         report("traj nt", time_us([&] { hipLaunchKernelGGL(traj<2>, dim3(waves), dim3(64), 0, 0, o); }, reps));
         report("traj plain", time_us([&] { hipLaunchKernelGGL(traj<0>, dim3(waves), dim3(64), 0, 0, o); }, reps));
