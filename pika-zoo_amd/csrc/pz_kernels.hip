@@ -728,7 +728,12 @@ struct TrajOut {
     {
         const u32x4* src1 = reinterpret_cast<const u32x4*>(lds_obs[0]);
         const u32x4* src2 = reinterpret_cast<const u32x4*>(lds_obs[1]);
-        if constexpr (OBS16) {
+#ifdef PZ_FLUSH_SPLIT
+        constexpr bool kSplit = true;
+#else
+        constexpr bool kSplit = OBS16;
+#endif
+        if constexpr (kSplit) {
             flush_tensor(src1, obs1, lane, between);
             flush_tensor(src2, obs2, lane, [] {});
         } else {
@@ -868,15 +873,17 @@ __device__ __forceinline__ void scout_candidates_posted(const int32_t* __restric
 // (scout_candidates_posted).  The scout executes exactly the workgroup barriers of the main wave.
 // PACKED: the state buffer holds the packed format (pz_packed.hpp); the whole groups are written back (no scout wave).
 // OBS16 (trajectory modes only): int16 observation rows (cfg.normalize_obs == 2), compile-time there.
+// The compiler's occupancy target for the kernel (it steers its scheduling, not only its register budget; measured,
+// tools/ab.py, us per frame at k = 32): the rollout of the on-device policy is at its best told that one wave per
+// SIMD is all there will be (4.23 vs 4.27 with a computer player), the tape kernel -- same register count either way
+// -- left alone (3.63 vs 3.96); with a scout wave two waves per SIMD must fit.
 #ifndef PZ_TRAJ_WAVES
 #define PZ_TRAJ_WAVES 1
 #endif
 template <bool AI1, bool AI2, int MODE, bool SPARSE, int SCOUT = kNoScout, bool PACKED = false, bool OBS16 = false>
-// (trajectory modes: one wave per SIMD by design -- two with a scout wave -- so the wave may have its share of the whole
-//  register file: a frame's 18 row pieces are in flight from LDS together)
 __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes)
 __attribute__((amdgpu_waves_per_eu((MODE == kRollout || MODE == kTape) && SCOUT != kNoScout ? 2 : 1,
-                                   (MODE == kRollout || MODE == kTape) ? (SCOUT != kNoScout ? 2 : PZ_TRAJ_WAVES) : 8)))
+                                   MODE == kRollout ? (SCOUT != kNoScout ? 2 : PZ_TRAJ_WAVES) : (MODE == kTape && SCOUT != kNoScout ? 2 : 8))))
 void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
 {
     const HotArgs hot{state, n, stride, act_p1, act_p2};
@@ -1005,7 +1012,9 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
             if (MODE == kTape) {
                 // The tape is fetched kTapeChunk frames at a time and parked in LDS: a per-frame global load
                 // would put a full memory latency on every frame of a lone wave, and its wait (vmcnt is
-                // in-order) would also drain that frame's stores; LDS reads only touch lgkmcnt.
+                // in-order) would also drain that frame's stores; LDS reads only touch lgkmcnt.  (Requesting a
+                // chunk half a chunk ahead into registers was tried: the loads pending around the loop's back edge
+                // make the compiler wait at every copy of those registers, every frame.)
                 const int slot = s % kTapeChunk;
                 if (slot == 0) {
                     const int frames = min(kTapeChunk, a.k - s);
@@ -1048,8 +1057,15 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
             };
             if (kTraj) {
                 out.stage(a, g, rw, as_float, live, a1, a2, MODE == kRollout && a.act_out != nullptr, lane, lds_obs);
+#ifdef PZ_HEAD_IN_FLUSH
+                out.flush(lds_obs, lane, [&]() {
+                    next_policy();
+                    next_head();
+                });
+#else
                 next_head();
                 out.flush(lds_obs, lane, next_policy);
+#endif
                 out.advance();
             } else {
                 next_policy();

@@ -45,6 +45,7 @@ def _ptr(t: Optional[torch.Tensor]):
 # torch.cuda.current_stream(...).cuda_stream builds a Stream object per call (2.8 us); the raw getter behind it
 # costs 0.08 us, which keeps env.step()'s host side (about 5.5 us) below the duration of the launch it issues
 _get_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device  # (the raw getter: 0.1 us instead of 0.3)
 
 
 def _raw_stream(device_index: int) -> int:
@@ -163,6 +164,7 @@ class raw_env:
         if int(output_ring) < 1:
             raise ValueError("output_ring must be >= 1")
         self._lib = _native.load()  # raises when the HIP library has not been built
+        self._step_bound = self._lib.pz_step_bound
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError(f"pikazoo_amd runs on MI355X only (got device {self.device}); no CPU fallback")
@@ -207,6 +209,7 @@ class raw_env:
         self._cfg = cfg
         self._cfg_ref = C.byref(cfg)
         self._cfg_version = 0  # bumped by every _fuse_* method
+        self._a1_seen = self._a2_seen = None  # the action tensors step() saw last (already validated)
         self._tables = None
         self._tables_ref = None  # `const pz_flight_tables*` of every step call (None: compute in the kernel)
         if flight_tables and (cfg.p1_computer or cfg.p2_computer):
@@ -592,14 +595,21 @@ class raw_env:
         a1 = actions["player_1"]  # KeyError on a missing agent
         a2 = actions["player_2"]
         n = self.num_envs
-        # fast path: int32 device tensors of the right size need no conversion (keeps the per-step host
-        # cost below the kernel's duration)
-        if not (type(a1) is torch.Tensor and a1.dtype is torch.int32 and a1.device == self.device
-                and a1.dim() == 1 and a1.shape[0] == n and a1.is_contiguous()):
-            a1 = self._action_tensor(a1)
-        if not (type(a2) is torch.Tensor and a2.dtype is torch.int32 and a2.device == self.device
-                and a2.dim() == 1 and a2.shape[0] == n and a2.is_contiguous()):
-            a2 = self._action_tensor(a2)
+        # fast path: an int32 device tensor of the right size needs no conversion, and a tensor OBJECT that passed
+        # once (a policy writing its actions into the same buffers every step) is not looked at again -- the checks
+        # are a sixth of the host time of a step, which has to stay below the duration of the launch it issues
+        if a1 is not self._a1_seen or a1.numel() != n:  # (numel: the one checked property an object can change in place)
+            if not (type(a1) is torch.Tensor and a1.dtype is torch.int32 and a1.get_device() == self._dev_index
+                    and a1.numel() == n and a1.is_contiguous()):
+                a1 = self._action_tensor(a1)
+            else:
+                self._a1_seen = a1
+        if a2 is not self._a2_seen or a2.numel() != n:
+            if not (type(a2) is torch.Tensor and a2.dtype is torch.int32 and a2.get_device() == self._dev_index
+                    and a2.numel() == n and a2.is_contiguous()):
+                a2 = self._action_tensor(a2)
+            else:
+                self._a2_seen = a2
         if self.validate_actions:
             n_act = self.n_actions
             lo = torch.minimum(a1.min(), a2.min())
@@ -612,9 +622,9 @@ class raw_env:
         out = self._out
         # pz_step through its prepared-argument form: one FFI call with four scalars (the twelve buffers and the
         # configuration were bound once) -- the host side of a step stays below the duration of the launch it issues
-        bound = out.bound if out.bound_key == self._result_key() else self._bound_step()
-        if torch.cuda.current_device() == self._dev_index:
-            rc = self._lib.pz_step_bound(bound, a1.data_ptr(), a2.data_ptr(), _raw_stream(self._dev_index))
+        bound = out.bound if out.bound_key == self._cfg_version else self._bound_step()
+        if _get_device() == self._dev_index:
+            rc = self._step_bound(bound, a1.data_ptr(), a2.data_ptr(), _raw_stream(self._dev_index))
         else:
             with torch.cuda.device(self.device):
                 rc = self._lib.pz_step_bound(bound, a1.data_ptr(), a2.data_ptr(), self._stream())

@@ -50,6 +50,7 @@ def main():
     if "--n" in args:
         n = int(args[args.index("--n") + 1])
     rollout = int(args[args.index("--rollout") + 1]) if "--rollout" in args else 0
+    tape = "--tape" in args  # with --rollout K: pz_step_many on an action tape instead of pz_rollout_random
     names = [a for a in args if not a.startswith("--") and not a.isdigit()]
     no_check = "--no-check" in args  # variants that change the stored state legitimately
     if "base" not in names:
@@ -69,6 +70,8 @@ def main():
         lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P, P, P]
         lib.pz_rollout_random.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), C.c_uint64, C.c_uint64,
                                           C.c_int32, P, P, P, P, P, P, P, P, P, P]
+        lib.pz_step_many.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, C.c_int32, P, P, P, P, P, P, P,
+                                     P, P]
         lib.pz_flight_table_bytes.restype = C.c_int64
         lib.pz_flight_table_bytes.argtypes = [C.c_int32]
         lib.pz_build_flight_tables.argtypes = [P, P, P]
@@ -120,6 +123,7 @@ def main():
         t_rew = [torch.zeros((k, n), dtype=torch.int32, device=dev) for _ in range(2)]
         t_term = torch.zeros((k, n), dtype=torch.uint8, device=dev)
         t_act = torch.zeros((k, 2, n), dtype=torch.int32, device=dev)
+        tapes = torch.randint(0, 13 if wrappers else 18, (16, k, 2, n), dtype=torch.int32, device=dev) if tape else None
 
     def run(nm, steps):
         lib = libs[nm]
@@ -129,6 +133,12 @@ def main():
         obs = obs16 if "h" in mods(nm) else obs32
         if rollout:
             for j in range(max(1, steps // rollout)):
+                if tape:
+                    rc = lib.pz_step_many(state.data_ptr(), n, n, C.byref(cfg), tapes[j % 16].data_ptr(), rollout,
+                                          t_obs[0].data_ptr(), t_obs[1].data_ptr(), t_rew[0].data_ptr(), t_rew[1].data_ptr(),
+                                          t_term.data_ptr(), None, None, tb, stream)
+                    assert rc == 0, rc
+                    continue
                 rc = lib.pz_rollout_random(state.data_ptr(), n, n, C.byref(cfg), 7, j * rollout, rollout,
                                            t_act.data_ptr(), t_obs[0].data_ptr(), t_obs[1].data_ptr(),
                                            t_rew[0].data_ptr(), t_rew[1].data_ptr(), t_term.data_ptr(), None, None,
