@@ -19,20 +19,30 @@ Sequence of one measurement (every part replayed by the CPU oracle for the in-ru
   least --min-time seconds whatever K is.  `steps` in the JSON line is K as given; `timed_steps` = the
   launches actually timed; value = games * timed_steps / wall.
 
-Multi-GPU (torchrun, one rank per GPU): weak scaling, rank r owns global games
-[r*65536, (r+1)*65536); no collective on the step path, one SUM all-reduce of the counters after
-the timed region (RCCL).  Timing: barrier + synchronize on both sides, MAX over ranks.
+Multi-GPU (one rank per GPU; under torch.distributed.run as the driver launches it, or plain
+`python bench.py --gpus N`, which starts that launcher as a child process): weak scaling, rank r owns
+global games [r*65536, (r+1)*65536); no collective on the step path, the counters are summed / gathered
+after the timed region (RCCL; `rccl_ranks` = 0 and `dist_note` says why when they had to travel over
+gloo).  Timing: barrier + synchronize on both sides, MAX over ranks; `per_rank` lists every rank's own
+launch duration and rate, and the first and the last rank replay 1 024 of their games on the oracle.
 
 The single JSON line also carries
   roofline     -- algorithmic HBM bytes per launch (649 B/game-step) / average launch
                   duration measured with HIP events on the launch stream over the timed region, against
-                  8 TB/s (`frac`); the same from the wall clock `value` is computed from (`frac_wall`);
-                  and from the PMC-measured bytes of profiles/traffic.json (`frac_traffic`);
+                  8 TB/s (`frac`: a CONTRACT-bytes figure, see `frac_basis`); the same from the wall clock
+                  `value` is computed from (`frac_wall`); and from the PMC-measured bytes of
+                  profiles/traffic.json (`traffic`, `frac_traffic`); `regime` / `bound_detail`: what the
+                  launch actually runs against at this batch size;
+  other_action_tape -- the same workload on the other kind of action tape (hot <-> cold);
   cpu_baseline -- the CPU oracle (oracle/pz_oracle.c, a C port of the reference's Python step,
                   kind="port") timed on this host's cores on a bounded sample of the same workload,
-                  and used to check the GPU trajectories bit-for-bit on a lane subset;
+                  and used to check the GPU trajectories bit-for-bit on a lane subset; the reference's
+                  own Python step as measured in the survey container beside it;
   configs      -- the other single-GPU BASELINE configs (2: 4 096 games, 3: player 2 = computer,
-                  5: fused wrappers), each timed the same way and oracle-checked.
+                  5: fused wrappers), the packed / int16 formats and the 524 288-game batch, each timed the
+                  same way, oracle-checked, with `regime`, `traffic`, `frac_traffic`; the k-frame
+                  launches (pz_rollout_random, pz_step_many, k = 32; on their own 297 + 352 / k bytes,
+                  beside the box's measured write ceiling) and the policy-in-the-step launch.
 """
 from __future__ import annotations
 

@@ -3,7 +3,10 @@
 launch (`pz_step`: the pair kernel / scout kernel, actions from HBM) for tens of thousands of frames per
 configuration, full state compared with the CPU oracle every `--every` frames on EVERY lane.
 
-    python tests/soak.py [--frames 20000] [--every 2000] [--n 65536] [--packed]
+    python tests/soak.py [--frames 20000] [--every 2000] [--n 65536] [--packed] [--rollout K [--tape]]
+
+--rollout K: the same frames through the k-frame launches instead (`pz_rollout_random`: the policy drawn in the
+kernel, every frame's outputs to trajectory tensors; with --tape `pz_step_many` on the same actions as a tape).
 
 --packed: the same on the packed state format (36 bytes per game); its sticky misfit flags are checked with every unpack.
 Every run also tracks, frame by frame on the device, the extremes of the values the packed format stores in narrow
@@ -33,6 +36,8 @@ def main():
     every = int(args[args.index("--every") + 1]) if "--every" in args else 2000
     n = int(args[args.index("--n") + 1]) if "--n" in args else 65536
     fmt = "packed" if "--packed" in args else "int32"
+    rollout = int(args[args.index("--rollout") + 1]) if "--rollout" in args else 0
+    tape = "--tape" in args
     configs = [
         ("human_vs_human", dict(), dict(), None),
         ("config 3: p2 computer, flight tables", dict(is_player2_computer=True), dict(is_player2_computer=True), None),
@@ -60,9 +65,19 @@ def main():
         # ball y velocity is observation word 33, the players' y velocities words 2 and 15 (raw observations only)
         track = not raw._cfg.normalize_obs
         ext = torch.zeros(2, dtype=torch.int32, device=raw.device)
+        traj = None
         for start in range(0, frames, every):
-            for t in range(start, start + every):
-                obs = env.step(raw.random_actions(77, t))[0]["player_1"]
+            for t in range(start, start + every, rollout or 1):
+                if rollout:
+                    k = min(rollout, start + every - t)
+                    if tape:
+                        acts = torch.stack([torch.stack(tuple(raw.random_actions(77, t + j).values())) for j in range(k)])
+                        traj = raw.step_many(acts, out=traj)
+                    else:
+                        traj = raw.rollout_random(77, k, t0=t, out=traj)
+                    obs = traj["obs"]["player_1"].reshape(-1, 35)
+                else:
+                    obs = env.step(raw.random_actions(77, t))[0]["player_1"]
                 if track:
                     ext = torch.maximum(ext, torch.stack((obs[:, 33].abs().max(), obs[:, [2, 15]].abs().max())))
             eps += ref.rollout_random(77, start, every)
@@ -76,7 +91,9 @@ def main():
                 break
         print(f"{name}: {n} games x {start + every} frames = {n * (start + every) / 1e9:.2f} G game-steps bit-exact vs oracle "
               f"on every lane: {same}; {eps} episodes finished; max |ball y velocity| {int(ext[0])}, max |player y velocity| "
-              f"{int(ext[1])} over every frame; state format {fmt}; {time.perf_counter() - t0:.0f} s", flush=True)
+              f"{int(ext[1])} over every frame; state format {fmt}; launches: "
+              f"{('pz_step_many' if tape else 'pz_rollout_random') + f' k={rollout}' if rollout else 'pz_step'}; "
+              f"{time.perf_counter() - t0:.0f} s", flush=True)
     print("SOAK", "PASSED" if ok else "FAILED")
     sys.exit(0 if ok else 1)
 
