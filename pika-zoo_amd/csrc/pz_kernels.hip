@@ -1347,6 +1347,195 @@ __global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(PZ_HOT_PARAMS, co
         pair_body<1, AI1, AI2, PACKED, RANDOM>(a, hot, lds_obs, xchg, lane);
 }
 
+// ---- the k-frame pair kernel: pz_rollout_random on two waves per 64 games ------------------------------------------
+// With a computer player the single-wave rollout issues ~1 050 VALU instructions plus a third as many scalar ones per
+// frame from ONE wave per SIMD: 9 800 cycles, 4.3 us -- a third more than the memory system needs for the frame's
+// bytes (section 4.8 of DESIGN.md).  Split by player like the single-frame pair kernel, each wave carries half of
+// the frame (its player's decision and move, its agent's rows and reward; the cheap shared parts twice), and the
+// launch is left with the write rate as its bound: 3.8 us per frame, what the human-vs-human rollout takes.  One LDS exchange + one workgroup barrier per frame (two with two computer players);
+// the frame in two halves as in the single-wave loop (pair_frame_head / pair_frame_tail), for the gathers' sake.
+template <int ROLE, bool AI1, bool AI2, bool PACKED, bool OBS16>
+__device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotArgs hot,
+                                                  int32_t (*lds_obs)[kLanes * PZ_OBS_DIM], int32_t* __restrict__ xchg, int lane)
+{
+    constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
+    constexpr bool kKeepsEx = (AI1 || AI2) && (ROLE == 1 ? AI2 : !AI2);
+    constexpr int kOwn = ROLE * PZ_P_WORDS, kOther = (1 - ROLE) * PZ_P_WORDS;
+    const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
+    const bool live = i < hot.n;
+    const uint32_t n32 = (uint32_t)hot.n;
+    const StateIO io{make_rsrc(hot.state, PACKED ? 0u : (uint32_t)(hot.stride * (PZ_STATE_WORDS * 4))),
+                     (uint32_t)hot.stride * 4u, (uint32_t)i * 4u};
+    const PackedIO pio = make_packed_io(hot.state, PACKED ? hot.stride : 0, i);
+    const bool as_float = a.cfg.ballpos_reward != 0 || a.cfg.normal_state_mode != 0;
+    const bool with_stats = ROLE == 0 && a.episode_stats != nullptr && a.cfg.episode_stats_mode != 0;
+    const StatsIO sio = make_stats_io(a.episode_stats, with_stats, a.stride, i);
+
+    Game g{};
+    RngId id = make_rng_id(a.cfg, live ? i : 0);
+    id.ks = make_parked_schedule(a.cfg.seed);  // the frame loop's key schedules live in VGPRs (KeySchedule)
+    const KeySchedule policy = make_parked_schedule(a.action_seed);
+    const FlightLut lut = make_lut(a.tables);
+    Player& own = ROLE == 0 ? g.p1 : g.p2;
+    Player& other = ROLE == 0 ? g.p2 : g.p1;
+    EpisodeStats st{0.0, 0.0, 0};
+    uint32_t sticky = 0;  // PACKED: the own group's overflow flag, kept
+    if (PACKED && live) {
+        const pk_u32x4 ga = pio.ld_a(), gb = pio.ld_b();
+        const uint32_t tail = kOwnAI ? pio.ld_tail() : 0u;  // computer_boldness / the landing point: the computer's wave only
+        unpack_group_a(g, ga);
+        unpack_group_b(g, gb);
+        unpack_tail(g, tail);
+        sticky = (ROLE == 0 ? ga.y : gb.y) & kPackedOverflowBit;
+    }
+    if (!PACKED && live) {
+        g.e.round_ended = io.ld(PZ_E_ROUND_ENDED);
+        g.e.game_ended = io.ld(PZ_E_GAME_ENDED);
+        g.e.rng = (uint32_t)io.ld(PZ_E_RNG_DRAW_COUNTER);
+        g.e.s1 = io.ld(PZ_E_SCORE_P1);
+        g.e.s2 = io.ld(PZ_E_SCORE_P2);
+        g.e.p2serve = io.ld(PZ_E_IS_PLAYER2_SERVE);
+        g.b.x = io.ld(PZ_B_X);
+        g.b.y = io.ld(PZ_B_Y);
+        g.b.xv = io.ld(PZ_B_X_VELOCITY);
+        g.b.yv = io.ld(PZ_B_Y_VELOCITY);
+        g.b.power = io.ld(PZ_B_IS_POWER_HIT);
+        g.b.px = io.ld(PZ_B_PREVIOUS_X);
+        g.b.py = io.ld(PZ_B_PREVIOUS_Y);
+        g.b.ppx = io.ld(PZ_B_PREVIOUS_PREVIOUS_X);
+        g.b.ppy = io.ld(PZ_B_PREVIOUS_PREVIOUS_Y);
+        g.b.rot = io.ld(PZ_B_FINE_ROTATION);
+        if (kKeepsEx) g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);
+        g.b.punch = io.ld(PZ_B_PUNCH_EFFECT_X);
+        load_player(own, io, kOwn);
+        // of the partner: what an exchange hands over (its state before its next move) and the collision flag
+        other.x = io.ld(kOther + PZ_P_X);
+        other.y = io.ld(kOther + PZ_P_Y);
+        other.yv = io.ld(kOther + PZ_P_Y_VELOCITY);
+        other.state = io.ld(kOther + PZ_P_STATE);
+        other.frame = io.ld(kOther + PZ_P_FRAME_NUMBER);
+        other.delay = io.ld(kOther + PZ_P_DELAY_BEFORE_NEXT_FRAME);
+        other.dive = io.ld(kOther + PZ_P_DIVING_DIRECTION);
+        other.lying = io.ld(kOther + PZ_P_LYING_DOWN_DURATION_LEFT);
+        other.hitprev = io.ld(kOther + PZ_P_POWER_HIT_KEY_IS_DOWN_PREVIOUS);
+        other.coll = io.ld(kOther + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED);
+    }
+    if (with_stats && live) sio.load(st);
+    const int own_bold_loaded = own.bold;
+
+    const uint32_t n_actions = a.cfg.simplify_action ? 13u : 18u;
+    BoldDefer bold{false, false, 0u, 0u};
+    TrajOut<OBS16> out;
+    out.init(a, i, lane, live);
+    char*& own_rows = ROLE == 0 ? out.obs1 : out.obs2;
+    int a1 = 0, a2 = 0;
+    unsigned int finished = 0;
+    bool any_round_started = false;
+    policy_actions(id.id_lo, id.id_hi, policy, a.t0, n_actions, a1, a2);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // every state load lands before the frame loop (see step_kernel)
+    bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
+    any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
+    PairHead head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold);
+    if (kOwnAI) issue_dropped_stores<TrajOut<OBS16>::kStores / 2>();  // (the gathers' wait: see step_kernel's frame loop)
+    for (int32_t s = 0; s < a.k; ++s) {
+        const bool last_frame = s == a.k - 1;
+        const bool frozen = head.frozen;
+        const int reward = pair_frame_tail<ROLE, AI1, AI2>(g, a.cfg, id, a1, a2, live, head,
+                                                           xchg + (s & 1) * (2 * kLoopXchgRegion), lane, lut, last_frame);
+        finished += (unsigned int)(live && g.e.game_ended && !frozen);
+        const Rewards rw = shape_rewards(a.cfg, g, reward, frozen);
+        if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
+        // this wave's share of the frame's outputs: its agent's reward and rows; player 1's wave also the flag and the actions
+        {
+            const unsigned int bits = as_float ? __float_as_uint(ROLE == 0 ? rw.f1 : rw.f2)
+                                               : (unsigned int)(ROLE == 0 ? rw.i1 : rw.i2);
+            __builtin_amdgcn_raw_buffer_store_b32(bits, make_rsrc(ROLE == 0 ? out.rew1 : out.rew2, n32 * 4u), out.voff, 0, 0);
+            if (ROLE == 0) {
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, make_rsrc(out.term, n32), out.ioff, 0, 0);
+                if (a.act_out != nullptr) {
+                    const Rsrc ao = make_rsrc(out.act, n32 * 8u);
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a1, ao, out.voff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, out.voff, n32 * 4u, 0);
+                }
+            }
+            if (live) {
+                if (a.cfg.normalize_obs == 1)
+                    stage_one_obs_t<true>(own, other, g.b, lds_obs[ROLE], lane);
+                else
+                    stage_one_obs_t<false>(own, other, g.b, lds_obs[ROLE], lane);
+            }
+            wave_lds_handover<false>();  // the rows are read back by this wave only
+        }
+        if (s + 1 < a.k) {  // this frame's outputs are staged: the game may move on
+            resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
+            any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
+            head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold);
+        }
+        out.flush_tensor(reinterpret_cast<const u32x4*>(lds_obs[ROLE]), own_rows, lane, [&]() {
+            policy_actions(id.id_lo, id.id_hi, policy, a.t0 + (uint64_t)s + 1u, n_actions, a1, a2);
+        });
+        out.advance();
+    }
+    if (!kOwnAI && bold.pending1) own.bold = rng_integers(id, bold.counter1, 5u);  // the launch's last recorded draw
+
+    // ---- the state back: every wave its player, its half of the ball; player 1's wave the env words
+    if (live) {
+        if constexpr (PACKED) {
+            if (ROLE == 0)
+                pio.st_a(pack_group_a(g, sticky));
+            else
+                pio.st_b(pack_group_b(g, sticky));
+            if (kOwnAI ? any_round_started : bold.pending1) pio.st_bold(ROLE, own.bold);
+            if (kKeepsEx) pio.st_ex(g.b.ex);
+        } else {
+            store_player(own, io, kOwn);
+            if (ROLE == 0) {
+                io.st(PZ_B_X, g.b.x);
+                io.st(PZ_B_Y, g.b.y);
+                io.st(PZ_B_X_VELOCITY, g.b.xv);
+                io.st(PZ_B_Y_VELOCITY, g.b.yv);
+                io.st(PZ_B_IS_POWER_HIT, g.b.power);
+                io.st(PZ_B_PUNCH_EFFECT_X, g.b.punch);
+                io.st(PZ_E_SCORE_P1, g.e.s1);
+                io.st(PZ_E_SCORE_P2, g.e.s2);
+                io.st(PZ_E_IS_PLAYER2_SERVE, g.e.p2serve);
+                io.st(PZ_E_ROUND_ENDED, g.e.round_ended);
+                io.st(PZ_E_GAME_ENDED, g.e.game_ended);
+                io.st(PZ_E_RNG_DRAW_COUNTER, (int32_t)g.e.rng);
+            } else {
+                io.st(PZ_B_PREVIOUS_X, g.b.px);
+                io.st(PZ_B_PREVIOUS_Y, g.b.py);
+                io.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
+                io.st(PZ_B_PREVIOUS_PREVIOUS_Y, g.b.ppy);
+                io.st(PZ_B_FINE_ROTATION, g.b.rot);
+            }
+            if (kKeepsEx) io.st(PZ_B_EXPECTED_LANDING_POINT_X, g.b.ex);
+        }
+        if (with_stats) sio.store(st);
+    }
+    (void)own_bold_loaded;
+    if (ROLE == 0 && a.episodes_done != nullptr) {
+        unsigned int total = finished;
+        for (int off = kLanes / 2; off > 0; off >>= 1) total += __shfl_down(total, off, kLanes);
+        if (lane == 0 && total != 0) atomicAdd(a.episodes_done, (unsigned long long)total);
+    }
+}
+
+template <bool AI1, bool AI2, bool PACKED = false, bool OBS16 = false>
+__global__ __launch_bounds__(2 * kLanes) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void rollout_pair_kernel(PZ_HOT_PARAMS, const StepArgs a)
+{
+    const HotArgs hot{state, n, stride, act_p1, act_p2};
+    __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
+    __shared__ int32_t xchg[kLoopXchgWords];  // the players' exchange: LDS of its own, double-buffered by frame parity
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & (kLanes - 1);
+    if (role == 0)
+        rollout_pair_body<0, AI1, AI2, PACKED, OBS16>(a, hot, lds_obs, xchg, lane);
+    else
+        rollout_pair_body<1, AI1, AI2, PACKED, OBS16>(a, hot, lds_obs, xchg, lane);
+}
+
 // ---- constructor / reset / observe / policy kernels --------------------------------------------
 // One game in either format, for the kernels outside the step path.
 template <bool PACKED>
@@ -1870,6 +2059,34 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
         if (ai1) return launch_pair<true, false, true>(a, stream);
         if (ai2) return launch_pair<false, true, true>(a, stream);
         return launch_pair<false, false, true>(a, stream);
+    }
+#endif
+#if !defined(PZ_NO_ROLLOUT_PAIR) && !defined(PZ_ABLATE) && !defined(PZ_STAMPS)
+    // pz_rollout_random with a computer player on the flight tables: two waves per 64 games below the size switch
+    // (interleaved A/B, us per frame at k = 32: 3.80 vs 4.34 on one wave; human vs human the single wave is at the
+    // write ceiling already and the split only adds instructions: 3.76 vs 3.67)
+    if (MODE == kRollout && a.n < PZ_TWO_WAVE_MAX_LANES && tables && (ai1 || ai2)) {
+        const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
+        const bool packed = is_packed(a.cfg), obs16 = a.cfg.normalize_obs == 2;
+#define PZ_LAUNCH_ROLLOUT_PAIR(A1, A2)                                                                                    \
+    do {                                                                                                                  \
+        if (packed && obs16)                                                                                              \
+            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, true, true>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);      \
+        else if (packed)                                                                                                  \
+            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, true, false>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);     \
+        else if (obs16)                                                                                                   \
+            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, false, true>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);     \
+        else                                                                                                              \
+            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, false, false>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);    \
+    } while (0)
+        if (ai1 && ai2)
+            PZ_LAUNCH_ROLLOUT_PAIR(true, true);
+        else if (ai1)
+            PZ_LAUNCH_ROLLOUT_PAIR(true, false);
+        else
+            PZ_LAUNCH_ROLLOUT_PAIR(false, true);
+#undef PZ_LAUNCH_ROLLOUT_PAIR
+        return (int)hipGetLastError();
     }
 #endif
     // the packed format: pair kernel above, else one wave per workgroup (a computer player without tables computes its

@@ -1501,4 +1501,209 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     return reward;
 }
 
+// ---------------------------------------------------------------------------------------
+// The pair frame in two halves, for the k-frame pair kernel (pz_kernels.hip, rollout_pair_kernel): the same split by
+// player as step_games_pair, looped -- the game stays in the two waves' registers for k frames -- and cut where
+// frame_head / frame_tail cut the single-wave frame, for the same reason: the head of frame t+1 (round start, ball
+// step, the own computer player's gathers issued) runs before frame t's row stores, so that the gathers are not
+// queued behind them in the in-order vmcnt.  Between the frames every wave holds: its own player complete, the
+// partner's nine exchanged words + collision flag (what the last exchange left: the partner's state before its next
+// move), ball and env complete.
+// The exchange lives in LDS of its own, DOUBLE-BUFFERED by frame parity: a wave posts into the partner's region
+// before the frame's barrier and reads its own behind it; with one barrier per frame the partner may still be reading
+// frame t's words when this wave posts frame t+1's only if they shared a buffer.
+// ---------------------------------------------------------------------------------------
+constexpr int kLoopXchgEarlyAt = 10 * kXchgPitch;            // the early post {x, draws} behind the ten exchange words
+constexpr int kLoopXchgRegion = kLoopXchgEarlyAt + 2 * 64;   // words per region (one per wave)
+constexpr int kLoopXchgWords = 2 * 2 * kLoopXchgRegion;      // two regions, two frame parities
+
+struct PairHead {
+    bool frozen, ground;
+    uint32_t rng_base;        // the env stream's counter before this frame's decisions
+    uint32_t landing_word;    // own computer player: LandingProbe::value
+    lut_u32x4 candidate_row;  //                      CandidateProbe::value
+    PreDrawn pre;
+};
+
+// DEFER_OWN: the own (human) player's boldness draw is recorded in *bold (counter1 / pending1) instead of made
+template <int ROLE, bool AI1, bool AI2, bool DEFER_OWN>
+__device__ __forceinline__ PairHead pair_frame_head(Game& g, const pz_config& cfg, const RngId& id, bool live,
+                                                    const FlightLut& lut, BoldDefer* bold)
+{
+    constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
+    static_assert(!(DEFER_OWN && kOwnAI), "a computer player reads its boldness");
+    Player& own = ROLE == 0 ? g.p1 : g.p2;
+    Player& other = ROLE == 0 ? g.p2 : g.p1;
+    PairHead h{};
+    h.frozen = live && g.e.game_ended && !cfg.auto_reset;
+    const bool active = live && !h.frozen;
+    if (active) {
+        if (g.e.round_ended) {  // reset (:149-164) or new round (:176-180); game_ended implies round_ended
+            if (g.e.game_ended) {
+                g.e.game_ended = 0;
+                g.e.p2serve = 0;
+                g.e.s1 = 0;
+                g.e.s2 = 0;
+            }
+            g.e.round_ended = 0;
+            // draw order of the reference: player 1 boldness, player 2 boldness [, serve]; each wave handles its own
+            // player's draw (index rng + ROLE)
+            if (DEFER_OWN) {
+                player_new_round_undrawn(own, ROLE == 0 ? 36 : kGroundWidth - 36);
+                bold->pending1 = true;
+                bold->counter1 = g.e.rng + (uint32_t)ROLE;
+            } else {
+                uint32_t own_draw = g.e.rng + (uint32_t)ROLE;
+                player_new_round(own, ROLE == 0 ? 36 : kGroundWidth - 36, id, own_draw);
+            }
+            other.x = ROLE == 0 ? kGroundWidth - 36 : 36;
+            other.y = kPlayerGroundY;
+            other.yv = 0;
+            other.coll = 0;
+            other.state = 0;
+            other.frame = 0;
+            other.delay = 0;
+            g.e.rng += 2u;
+            ball_new_round(g.b, get_server(cfg, g.e, id));  // a random serve is drawn by both waves
+        }
+        h.ground = ball_world_step(g.b);
+    }
+    h.rng_base = g.e.rng;
+    if (kOwnAI && active) {
+        const bool scan = power_hit_scan_needed(own, g.b);
+        h.landing_word = lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv).value;
+        h.candidate_row = lut.candidates_issue(scan, g.b.x, g.b.y, abs(g.b.yv)).value;
+        // (player 2 behind a computer player 1 learns the counter of its first draw from player 1's early post: tail)
+        if (!(ROLE == 1 && AI1)) h.pre = predraw3(id, h.rng_base);
+    }
+    return h;
+}
+
+// xchg: this frame's exchange buffer (kLoopXchgRegion words per wave's region); returns player 1's reward
+template <int ROLE, bool AI1, bool AI2>
+__device__ __forceinline__ int pair_frame_tail(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
+                                               PairHead& h, int32_t* __restrict__ xchg, int lane, const FlightLut& lut,
+                                               const bool last_frame)
+{
+    constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
+    constexpr bool kOtherAI = ROLE == 0 ? AI2 : AI1;
+    constexpr bool kKeepsEx = (AI1 || AI2) && (ROLE == 1 ? AI2 : !AI2);
+    Player& own = ROLE == 0 ? g.p1 : g.p2;
+    Player& other = ROLE == 0 ? g.p2 : g.p1;
+    const bool active = live && !h.frozen, ground = h.ground;
+    Input in1{0, 0, 0}, in2{0, 0, 0};
+    if (active) {
+        int other_prev = 0;  // the partner's key edge is only needed by the partner
+        if (cfg.simplify_action) {
+            in1 = decode_action(kSimpleTablesP1, a1, ROLE == 0 ? g.p1.hitprev : other_prev);
+            in2 = decode_action(kSimpleTablesP2, a2, ROLE == 1 ? g.p2.hitprev : other_prev);
+        } else {
+            in1 = decode_action(kFullTables, a1, ROLE == 0 ? g.p1.hitprev : other_prev);
+            in2 = decode_action(kFullTables, a2, ROLE == 1 ? g.p2.hitprev : other_prev);
+        }
+    }
+    const uint32_t rng_base = h.rng_base;
+    uint32_t draws_own = 0, draws_other = 0;
+    Input& in_own = ROLE == 0 ? in1 : in2;
+    Input& in_other = ROLE == 0 ? in2 : in1;
+    int32_t* mine = xchg + (1 - ROLE) * kLoopXchgRegion;         // what this wave posts: into the partner's region
+    const int32_t* theirs = xchg + ROLE * kLoopXchgRegion;       // what the partner posted for this wave
+
+    if (ROLE == 1 && AI1 && AI2) {
+        __syncthreads();  // player 1's early post is in place
+        if (active) {
+            other.x = theirs[kLoopXchgEarlyAt + lane * 2];
+            draws_other = (uint32_t)theirs[kLoopXchgEarlyAt + lane * 2 + 1];
+        }
+    }
+    if (kOwnAI && active) {
+        const bool scan = power_hit_scan_needed(own, g.b);  // (as in the head: nobody has moved since)
+        const int ayv = abs(g.b.yv);
+        int ex[6] = {0, 0, 0, 0, 0, 0};
+        const PreDrawn pre = (ROLE == 1 && AI1) ? predraw3(id, rng_base + draws_other) : h.pre;
+        if (ROLE == 1 && !AI1) {
+            // player 1 (human) has moved when player 2 decides: its new x as player_move computes it
+            const int vx = (other.state < 3) ? in1.xd * 6 : other.dive * 8;
+            const int nx = min(max(other.x + vx, kPlayerHalfLength), kGroundHalfWidth - kPlayerHalfLength);
+            other.x = (other.state == 4) ? other.x : nx;
+        }
+        uint32_t unused;
+        LandingProbe lp = lut.landing_locate(true, g.b.x, g.b.y, g.b.xv, g.b.yv, unused);
+        lp.value = h.landing_word;
+        CandidateProbe cp = lut.candidates_locate(scan, g.b.x, g.b.y, ayv, unused);
+        cp.value = h.candidate_row;
+        g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, 0);  // :314-315
+        lut.candidates_finish(cp, g.b.x, g.b.y, ayv, ex);
+        draws_own = computer_decide_predrawn<ROLE == 1>(own, g.b, other.x, pre, scan, ex, in_own);
+    }
+    if (active) player_move<ROLE == 1>(own, in_own);
+    if (ROLE == 0 && AI1 && AI2) {
+        if (active) {
+            mine[kLoopXchgEarlyAt + lane * 2] = own.x;
+            mine[kLoopXchgEarlyAt + lane * 2 + 1] = (int32_t)draws_own;
+        }
+        __syncthreads();
+    }
+    // hand the own player to the partner wave: everything the collisions, the observations and the partner's next
+    // decision read (frozen games exchange their unchanged players)
+    if (live) {
+        int32_t* w = mine + lane;
+        w[0 * kXchgPitch] = own.x;
+        w[1 * kXchgPitch] = own.y;
+        w[2 * kXchgPitch] = own.yv;
+        w[3 * kXchgPitch] = own.state;
+        w[4 * kXchgPitch] = own.frame;
+        w[5 * kXchgPitch] = own.delay;
+        w[6 * kXchgPitch] = own.dive;
+        w[7 * kXchgPitch] = own.lying;
+        w[8 * kXchgPitch] = own.hitprev;
+        if (kOwnAI) w[9 * kXchgPitch] = (in_own.xd + 1) | ((in_own.yd + 1) << 2) | (int32_t)(draws_own << 4);
+    }
+    __syncthreads();
+    if (live) {
+        const int32_t* r = theirs + lane;
+        other.x = r[0 * kXchgPitch];
+        other.y = r[1 * kXchgPitch];
+        other.yv = r[2 * kXchgPitch];
+        other.state = r[3 * kXchgPitch];
+        other.frame = r[4 * kXchgPitch];
+        other.delay = r[5 * kXchgPitch];
+        other.dive = r[6 * kXchgPitch];
+        other.lying = r[7 * kXchgPitch];
+        other.hitprev = r[8 * kXchgPitch];
+        if (kOtherAI) {
+            const int32_t w = r[9 * kXchgPitch];
+            if (active) {
+                in_other.xd = (w & 3) - 1;
+                in_other.yd = ((w >> 2) & 3) - 1;
+                draws_other = (uint32_t)w >> 4;
+            }
+        }
+    }
+    int reward = 0;
+    if (active) {
+        g.e.rng = rng_base + draws_own + draws_other;
+        // physics.py:319-335: player 1 first, then player 2 against the possibly changed velocities
+        const bool touch1 = ball_touches_player(g.b, g.p1), hit1 = touch1 & (g.p1.coll == 0);
+        ball_player_collision(g.b, hit1, g.p1.x, in1, g.p1.state, id, g.e.rng);
+        g.p1.coll = touch1;
+        const bool touch2 = ball_touches_player(g.b, g.p2), hit2 = touch2 & (g.p2.coll == 0);
+        ball_player_collision(g.b, hit2, g.p2.x, in2, g.p2.state, id, g.e.rng);
+        g.p2.coll = touch2;
+        // scoring / round end / game end (:190-210)
+        const bool p2_scores = ground & (g.b.punch < kGroundHalfWidth), p1_scores = ground & !p2_scores;
+        g.e.s1 += p1_scores;
+        g.e.s2 += p2_scores;
+        g.e.p2serve = ground ? (int)p2_scores : g.e.p2serve;
+        g.e.game_ended = ground & ((p2_scores ? g.e.s2 : g.e.s1) >= cfg.winning_score);
+        g.e.round_ended = ground;
+        reward = ground ? (p2_scores ? -1 : 1) : 0;
+        // :331-332 -- between the frames of one launch the value after a processed collision is overwritten by the
+        // next frame's prediction before anything reads it: evaluated on the last frame and for a game that freezes
+        const bool ex_observable = last_frame | (g.e.game_ended != 0 && cfg.auto_reset == 0);
+        if (kKeepsEx && (hit1 | hit2) && ex_observable) g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
+    }
+    return reward;
+}
+
 }  // namespace pz
