@@ -735,8 +735,10 @@ def main():
             "rollout_k32_p2_computer": ("pz_rollout_random, k = 32, player 2 = rule-based computer (flight tables)",
                                         dict(p2_computer=True)),
         }
+        traj["rollout_k128"] = ("pz_rollout_random, k = 128 (the launch's fixed costs -- state in and out, the first frame's "
+                                "latency before the first store -- over four times as many frames)", dict(k=128))
         for key, (wl, kw) in traj.items():
-            r = measure_rollout(args, shard, device, k=32, check_lanes=1024, **kw)
+            r = measure_rollout(args, shard, device, check_lanes=1024, **{"k": 32, **kw})
             r.update(workload=wl, num_envs=args.num_envs, write_ceiling_GBps=ceiling,
                      frac_of_write_ceiling=r["achieved_GBps"] / ceiling,
                      bound_detail="every frame's outputs stream to HBM (623 MB per 32-frame launch): bound by the "

@@ -728,12 +728,7 @@ struct TrajOut {
     {
         const u32x4* src1 = reinterpret_cast<const u32x4*>(lds_obs[0]);
         const u32x4* src2 = reinterpret_cast<const u32x4*>(lds_obs[1]);
-#ifdef PZ_FLUSH_SPLIT
-        constexpr bool kSplit = true;
-#else
-        constexpr bool kSplit = OBS16;
-#endif
-        if constexpr (kSplit) {
+        if constexpr (OBS16) {
             flush_tensor(src1, obs1, lane, between);
             flush_tensor(src2, obs2, lane, [] {});
         } else {
@@ -975,11 +970,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
         // A human player's computer_boldness is drawn at every round start (physics.py:218) and read by nothing, so only
         // the LAST draw of a launch is observable (in the state written back): the frames remember that draw's
         // counter and the Philox block runs once, behind the loop, instead of on three frames out of four.
-#ifndef PZ_NO_DEFER_BOLD
         constexpr bool kDefer1 = !AI1, kDefer2 = !AI2;
-#else
-        constexpr bool kDefer1 = false, kDefer2 = false;
-#endif
         BoldDefer bold{false, false, 0u, 0u};
         TrajOut<OBS16> out;
         if (kTraj) out.init(a, i, lane, live);
@@ -989,26 +980,16 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
         // that the gathers are not queued behind those 18 stores in the in-order vmcnt.
         const ScoutLink link{cand, hits, posts};
         bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
-#ifndef PZ_NO_PRELOOP_DRAIN
         // Every state load lands BEFORE the frame loop: left to itself the compiler waits for the 44 columns where the
         // first frame reads them -- inside the loop body, counting down to vmcnt(0) -- where on every later frame
         // those waits drain the previous frame's 18 row stores instead (and the gathers queued behind them).
         if (kTraj) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
-#endif
-#ifdef PZ_NO_HEAD_PIPELINE
-        FrameHead head{};
-#else
         FrameHead head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold);
         // The compiler sizes the tail's wait for the head's gathers for the worst path into the loop: from here
         // nothing would follow them (vmcnt(0): every frame drains its predecessor's row stores after all), around the
         // back edge a frame's 18 row stores do.  Eighteen dropped stores make the two paths look alike: vmcnt(18).
         if (kTraj && (AI1 || AI2)) issue_dropped_stores<TrajOut<OBS16>::kStores>();
-#endif
         for (int32_t s = 0; s < a.k; ++s) {
-#ifdef PZ_NO_HEAD_PIPELINE
-            resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
-            head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold);
-#endif
             if (MODE == kTape) {
                 // The tape is fetched kTapeChunk frames at a time and parked in LDS: a per-frame global load
                 // would put a full memory latency on every frame of a lone wave, and its wait (vmcnt is
@@ -1048,24 +1029,15 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
                     policy_actions(id.id_lo, id.id_hi, policy, a.t0 + (uint64_t)s + 1u, n_actions, a1, a2);
             };
             auto next_head = [&]() {  // this frame's outputs are staged: the game may move on
-#ifndef PZ_NO_HEAD_PIPELINE
                 if (s + 1 < a.k) {
                     resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
                     head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold);
                 }
-#endif
             };
             if (kTraj) {
                 out.stage(a, g, rw, as_float, live, a1, a2, MODE == kRollout && a.act_out != nullptr, lane, lds_obs);
-#ifdef PZ_HEAD_IN_FLUSH
-                out.flush(lds_obs, lane, [&]() {
-                    next_policy();
-                    next_head();
-                });
-#else
                 next_head();
                 out.flush(lds_obs, lane, next_policy);
-#endif
                 out.advance();
             } else {
                 next_policy();
@@ -1421,7 +1393,6 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         other.coll = io.ld(kOther + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED);
     }
     if (with_stats && live) sio.load(st);
-    const int own_bold_loaded = own.bold;
 
     const uint32_t n_actions = a.cfg.simplify_action ? 13u : 18u;
     BoldDefer bold{false, false, 0u, 0u};
@@ -1513,7 +1484,6 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         }
         if (with_stats) sio.store(st);
     }
-    (void)own_bold_loaded;
     if (ROLE == 0 && a.episodes_done != nullptr) {
         unsigned int total = finished;
         for (int off = kLanes / 2; off > 0; off >>= 1) total += __shfl_down(total, off, kLanes);

@@ -125,11 +125,7 @@ struct RngId {
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
 {
-#ifdef PZ_NO_BITOP3
-    return a ^ b ^ c;
-#else
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // one v_bitop3_b32 (gfx950) instead of two v_xor_b32
-#endif
 }
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -565,23 +561,14 @@ struct FlightLut {
         uint32_t e = __umul24((uint32_t)(yv + PZ_FT_YV_MAX), (uint32_t)kFtXvCount) + (uint32_t)xi;
         e = __umul24(e, (uint32_t)kFtYCount) + (uint32_t)y;
         e = __umul24(e, (uint32_t)kFtXCount) + (uint32_t)(x - kBallRadius);
-#ifdef PZ_LANDING_B16
-        offset = in ? e * 2u : 0u;
-        return LandingProbe{in, wanted, 0u, 0u};
-#else
         offset = in ? (e * 2u) & ~3u : 0u;
         return LandingProbe{in, wanted, (e & 1u) * 16u, 0u};
-#endif
     }
     __device__ __forceinline__ LandingProbe landing_issue(bool wanted, int x, int y, int xv, int yv) const
     {
         uint32_t offset;
         LandingProbe p = landing_locate(wanted, x, y, xv, yv, offset);
-#ifdef PZ_LANDING_B16
-        p.value = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(landing, offset, 0, 0);
-#else
         p.value = __builtin_amdgcn_raw_buffer_load_b32(landing, offset, 0, 0);
-#endif
         return p;
     }
     __device__ __forceinline__ int landing_finish(const LandingProbe& p, int x, int y, int xv, int yv, int keep) const
@@ -616,9 +603,7 @@ struct FlightLut {
     {
         // the row's fourth dword is padding: keep its register reserved until here all the same -- handed out as a
         // temporary while the load is in flight, the first write to it would have to wait for the whole gather
-#ifndef PZ_NO_W_KEEPALIVE
         asm volatile("" ::"v"(p.value.w));
-#endif
         ex[0] = (int)(p.value.x & 0xFFFFu);
         ex[1] = (int)(p.value.x >> 16);
         ex[2] = (int)(p.value.y & 0xFFFFu);

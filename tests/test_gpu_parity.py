@@ -771,6 +771,40 @@ def test_two_wave_and_single_wave_kernels_agree_across_the_size_switch(kw, steps
             assert np.array_equal(cpu(term["player_1"][lo:lo + 1024]).astype(np.uint8), rterm), (n, lo)
 
 
+@pytest.mark.parametrize("fmt,obs_dtype", [("int32", torch.int32), ("packed", torch.int32), ("int32", torch.int16)])
+@pytest.mark.parametrize("kw", [dict(winning_score=1, is_player2_computer=True),
+                                dict(winning_score=1, is_player1_computer=True),
+                                dict(winning_score=2, is_player1_computer=True, is_player2_computer=True, serve="random")])
+def test_rollout_pair_and_single_wave_kernels_agree_across_the_size_switch(kw, fmt, obs_dtype, oracle):
+    """pz_rollout_random with a computer player on the flight tables runs two waves per 64 games below 393 216 games
+    (rollout_pair_kernel: the frame split by player, looped) and one from there on: both sides of the switch, every
+    frame's outputs and the final state against the oracle on the first and the last 512 games; two launches, so the
+    second starts from what the first wrote back."""
+    k, m = 20, 512
+    for n in (393216 - 64, 393216):
+        env = make_env(num_envs=n, seed=45, env_id_base=11, state_format=fmt, observation_dtype=obs_dtype, **kw)
+        raw = env.unwrapped
+        env.reset()
+        refs = {}
+        for lo in (0, n - m):
+            refs[lo] = oracle.OracleEnv(m, oracle.make_config(seed=45, env_id_base=11 + lo, **kw), nthreads=4)
+            refs[lo].reset()
+        out = None
+        for launch in range(2):
+            out = raw.rollout_random(23, k, t0=launch * k, out=out)
+            for lo, ref in refs.items():
+                for f in range(k):
+                    a1, a2 = oracle.random_actions(m, 11 + lo, 23, launch * k + f)
+                    robs, rrew, rterm = ref.step(a1, a2)
+                    ctx = (n, lo, launch, f)
+                    assert np.array_equal(cpu(out["actions"][f, 0, lo:lo + m]), a1), ctx
+                    assert np.array_equal(cpu(out["obs"]["player_1"][f, lo:lo + m]).astype(np.int32), robs[0]), ctx
+                    assert np.array_equal(cpu(out["obs"]["player_2"][f, lo:lo + m]).astype(np.int32), robs[1]), ctx
+                    assert np.array_equal(cpu(out["rewards"]["player_2"][f, lo:lo + m]), rrew[1]), ctx
+                    assert np.array_equal(cpu(out["terminations"][f, lo:lo + m]).astype(np.uint8), rterm), ctx
+                assert np.array_equal(cpu(raw.state[:, lo:lo + m]), ref.state), (n, lo, launch)
+
+
 # ------------------------------------------------------------------------------------------------
 # 9. the headline size against the oracle on EVERY lane (BASELINE configs 3, 4-shard and 5 at 65 536 games)
 # ------------------------------------------------------------------------------------------------

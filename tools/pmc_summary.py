@@ -21,7 +21,7 @@ from collections import defaultdict
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
-STEP_KERNELS = ("pz::step_pair_kernel", "pz::step_kernel")
+STEP_KERNELS = ("pz::step_pair_kernel", "pz::step_kernel", "pz::rollout_pair_kernel")
 
 
 def short(name):
