@@ -1323,8 +1323,10 @@ __global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(PZ_HOT_PARAMS, co
 // With a computer player the single-wave rollout issues ~1 050 VALU instructions plus a third as many scalar ones per
 // frame from ONE wave per SIMD: 9 800 cycles, 4.3 us -- a third more than the memory system needs for the frame's
 // bytes (section 4.8 of DESIGN.md).  Split by player like the single-frame pair kernel, each wave carries half of
-// the frame (its player's decision and move, its agent's rows and reward; the cheap shared parts twice), and the
-// launch is left with the write rate as its bound: 3.8 us per frame, what the human-vs-human rollout takes.  One LDS exchange + one workgroup barrier per frame (two with two computer players);
+// the frame (its player's decision and move; the cheap shared parts twice) -- and with ONE computer player the human
+// player's wave, which would otherwise wait for the computer's at every frame's barrier, writes ALL of the frame's
+// outputs, so that the computer's wave has nothing but its decision on the frame's critical path and no store in
+// its in-order vmcnt.  The launch is left with the write rate as its bound: 3.5 us per frame.  One LDS exchange + one workgroup barrier per frame (two with two computer players);
 // the frame in two halves as in the single-wave loop (pair_frame_head / pair_frame_tail), for the gathers' sake.
 template <int ROLE, bool AI1, bool AI2, bool PACKED, bool OBS16>
 __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotArgs hot,
@@ -1332,6 +1334,8 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
 {
     constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
     constexpr bool kKeepsEx = (AI1 || AI2) && (ROLE == 1 ? AI2 : !AI2);
+    constexpr bool kWritesAll = AI1 != AI2 && !kOwnAI;   // one computer player: the human player's wave writes the outputs
+    constexpr bool kWritesNone = AI1 != AI2 && kOwnAI;   // ... and the computer's wave none of them
     constexpr int kOwn = ROLE * PZ_P_WORDS, kOther = (1 - ROLE) * PZ_P_WORDS;
     const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
     const bool live = i < hot.n;
@@ -1407,7 +1411,8 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
     bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
     PairHead head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold);
-    if (kOwnAI) issue_dropped_stores<TrajOut<OBS16>::kStores / 2>();  // (the gathers' wait: see step_kernel's frame loop)
+    // (the gathers' wait, see step_kernel's frame loop -- for a computer's wave that stores rows: with two computer players)
+    if (kOwnAI && !kWritesNone) issue_dropped_stores<TrajOut<OBS16>::kStores / 2>();
     for (int32_t s = 0; s < a.k; ++s) {
         const bool last_frame = s == a.k - 1;
         const bool frozen = head.frozen;
@@ -1416,12 +1421,14 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         finished += (unsigned int)(live && g.e.game_ended && !frozen);
         const Rewards rw = shape_rewards(a.cfg, g, reward, frozen);
         if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
-        // this wave's share of the frame's outputs: its agent's reward and rows; player 1's wave also the flag and the actions
-        {
-            const unsigned int bits = as_float ? __float_as_uint(ROLE == 0 ? rw.f1 : rw.f2)
-                                               : (unsigned int)(ROLE == 0 ? rw.i1 : rw.i2);
-            __builtin_amdgcn_raw_buffer_store_b32(bits, make_rsrc(ROLE == 0 ? out.rew1 : out.rew2, n32 * 4u), out.voff, 0, 0);
-            if (ROLE == 0) {
+        // The frame's outputs.  With ONE computer player its wave is the frame's critical path (its decision on top of
+        // everything the partner does), so the HUMAN player's wave writes everything -- both agents' rewards and rows,
+        // the flag, the actions -- and the computer's wave nothing (kWritesAll / kWritesNone; it then has no store in
+        // its in-order vmcnt either); with two computer players each wave writes its agent's share.
+        if (!kWritesNone) {
+            if (kWritesAll || ROLE == 0) {
+                __builtin_amdgcn_raw_buffer_store_b32(as_float ? __float_as_uint(rw.f1) : (unsigned int)rw.i1,
+                                                      make_rsrc(out.rew1, n32 * 4u), out.voff, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, make_rsrc(out.term, n32), out.ioff, 0, 0);
                 if (a.act_out != nullptr) {
                     const Rsrc ao = make_rsrc(out.act, n32 * 8u);
@@ -1429,11 +1436,17 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
                     __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, out.voff, n32 * 4u, 0);
                 }
             }
+            if (kWritesAll || ROLE == 1)
+                __builtin_amdgcn_raw_buffer_store_b32(as_float ? __float_as_uint(rw.f2) : (unsigned int)rw.i2,
+                                                      make_rsrc(out.rew2, n32 * 4u), out.voff, 0, 0);
             if (live) {
-                if (a.cfg.normalize_obs == 1)
+                if (kWritesAll) {
+                    stage_obs(g, lds_obs[0], lds_obs[1], lane, a.cfg.normalize_obs == 1);
+                } else if (a.cfg.normalize_obs == 1) {
                     stage_one_obs_t<true>(own, other, g.b, lds_obs[ROLE], lane);
-                else
+                } else {
                     stage_one_obs_t<false>(own, other, g.b, lds_obs[ROLE], lane);
+                }
             }
             wave_lds_handover<false>();  // the rows are read back by this wave only
         }
@@ -1442,9 +1455,13 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
             any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
             head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold);
         }
-        out.flush_tensor(reinterpret_cast<const u32x4*>(lds_obs[ROLE]), own_rows, lane, [&]() {
-            policy_actions(id.id_lo, id.id_hi, policy, a.t0 + (uint64_t)s + 1u, n_actions, a1, a2);
-        });
+        auto next_policy = [&]() { policy_actions(id.id_lo, id.id_hi, policy, a.t0 + (uint64_t)s + 1u, n_actions, a1, a2); };
+        if (kWritesNone)
+            next_policy();
+        else if (kWritesAll)
+            out.flush(lds_obs, lane, next_policy);
+        else
+            out.flush_tensor(reinterpret_cast<const u32x4*>(lds_obs[ROLE]), own_rows, lane, next_policy);
         out.advance();
     }
     if (!kOwnAI && bold.pending1) own.bold = rng_integers(id, bold.counter1, 5u);  // the launch's last recorded draw
@@ -2033,8 +2050,9 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
 #endif
 #if !defined(PZ_NO_ROLLOUT_PAIR) && !defined(PZ_ABLATE) && !defined(PZ_STAMPS)
     // pz_rollout_random with a computer player on the flight tables: two waves per 64 games below the size switch
-    // (interleaved A/B, us per frame at k = 32: 3.80 vs 4.34 on one wave; human vs human the single wave is at the
-    // write ceiling already and the split only adds instructions: 3.76 vs 3.67)
+    // (interleaved A/B, us per frame at k = 32: 3.49 vs 4.34 on one wave; human vs human the single wave is at the
+    // write ceiling already: 3.62 on two waves -- player 1's writing all outputs -- vs 3.63 on one, 3.76 with the
+    // outputs split between the waves)
     if (MODE == kRollout && a.n < PZ_TWO_WAVE_MAX_LANES && tables && (ai1 || ai2)) {
         const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
         const bool packed = is_packed(a.cfg), obs16 = a.cfg.normalize_obs == 2;
