@@ -732,8 +732,10 @@ def main():
         traj = {
             "rollout_k32": ("pz_rollout_random, k = 32: 65 536 games, random policy drawn in the kernel", dict()),
             "step_many_k32": ("pz_step_many, k = 32: 65 536 games, actions from a tape in HBM", dict(tape=True)),
-            "rollout_k32_p2_computer": ("pz_rollout_random, k = 32, player 2 = rule-based computer (flight tables)",
-                                        dict(p2_computer=True)),
+            "rollout_k32_p2_computer": ("pz_rollout_random, k = 32, player 2 = rule-based computer (flight tables): two "
+                                        "waves per 64 games", dict(p2_computer=True)),
+            "step_many_k32_p2_computer": ("pz_step_many, k = 32, player 2 = rule-based computer (flight tables)",
+                                          dict(p2_computer=True, tape=True)),
         }
         traj["rollout_k128"] = ("pz_rollout_random, k = 128 (the launch's fixed costs -- state in and out, the first frame's "
                                 "latency before the first store -- over four times as many frames)", dict(k=128))

@@ -1328,10 +1328,14 @@ __global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(PZ_HOT_PARAMS, co
 // outputs, so that the computer's wave has nothing but its decision on the frame's critical path and no store in
 // its in-order vmcnt.  The launch is left with the write rate as its bound: 3.5 us per frame.  One LDS exchange + one workgroup barrier per frame (two with two computer players);
 // the frame in two halves as in the single-wave loop (pair_frame_head / pair_frame_tail), for the gathers' sake.
-template <int ROLE, bool AI1, bool AI2, bool PACKED, bool OBS16>
+// MODE: kRollout (pz_rollout_random: both waves draw the policy's block) or kTape (pz_step_many: the tape is parked in
+// LDS kTapeChunk frames at a time, player 1's wave fetching player 1's row of every frame, player 2's wave the other).
+template <int ROLE, bool AI1, bool AI2, int MODE, bool PACKED, bool OBS16>
 __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotArgs hot,
-                                                  int32_t (*lds_obs)[kLanes * PZ_OBS_DIM], int32_t* __restrict__ xchg, int lane)
+                                                  int32_t (*lds_obs)[kLanes * PZ_OBS_DIM], int32_t* __restrict__ xchg,
+                                                  int32_t* __restrict__ tape_lds, int lane)
 {
+    static_assert(MODE == kRollout || MODE == kTape, "the trajectory launches");
     constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
     constexpr bool kKeepsEx = (AI1 || AI2) && (ROLE == 1 ? AI2 : !AI2);
     constexpr bool kWritesAll = AI1 != AI2 && !kOwnAI;   // one computer player: the human player's wave writes the outputs
@@ -1406,7 +1410,7 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
     int a1 = 0, a2 = 0;
     unsigned int finished = 0;
     bool any_round_started = false;
-    policy_actions(id.id_lo, id.id_hi, policy, a.t0, n_actions, a1, a2);
+    if (MODE == kRollout) policy_actions(id.id_lo, id.id_hi, policy, a.t0, n_actions, a1, a2);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // every state load lands before the frame loop (see step_kernel)
     bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
@@ -1414,6 +1418,22 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
     // (the gathers' wait, see step_kernel's frame loop -- for a computer's wave that stores rows: with two computer players)
     if (kOwnAI && !kWritesNone) issue_dropped_stores<TrajOut<OBS16>::kStores / 2>();
     for (int32_t s = 0; s < a.k; ++s) {
+        if (MODE == kTape) {
+            // (both waves read frame s - 1's actions before that frame's exchange barrier: nobody needs the old chunk here)
+            const int slot = s % kTapeChunk;
+            if (slot == 0) {
+                // (every wave its own player's row; the computer's wave fetching both -- it has no stores the wait would
+                // drain -- was slower: 4.31 vs 4.12 us per frame)
+                const int frames = min(kTapeChunk, a.k - s);
+                for (int f = 0; f < frames; ++f) {  // rows past n read as 0 through the range check
+                    const Rsrc tape = make_rsrc(a.act_p1 + ((int64_t)(s + f) * 2 + ROLE) * a.n, n32 * 4u);
+                    tape_lds[(f * 2 + ROLE) * kLanes + lane] = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, 0, 0);
+                }
+                __syncthreads();
+            }
+            a1 = tape_lds[(slot * 2 + 0) * kLanes + lane];
+            a2 = tape_lds[(slot * 2 + 1) * kLanes + lane];
+        }
         const bool last_frame = s == a.k - 1;
         const bool frozen = head.frozen;
         const int reward = pair_frame_tail<ROLE, AI1, AI2>(g, a.cfg, id, a1, a2, live, head,
@@ -1430,7 +1450,7 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
                 __builtin_amdgcn_raw_buffer_store_b32(as_float ? __float_as_uint(rw.f1) : (unsigned int)rw.i1,
                                                       make_rsrc(out.rew1, n32 * 4u), out.voff, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, make_rsrc(out.term, n32), out.ioff, 0, 0);
-                if (a.act_out != nullptr) {
+                if (MODE == kRollout && a.act_out != nullptr) {
                     const Rsrc ao = make_rsrc(out.act, n32 * 8u);
                     __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a1, ao, out.voff, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, out.voff, n32 * 4u, 0);
@@ -1455,7 +1475,9 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
             any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
             head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold);
         }
-        auto next_policy = [&]() { policy_actions(id.id_lo, id.id_hi, policy, a.t0 + (uint64_t)s + 1u, n_actions, a1, a2); };
+        auto next_policy = [&]() {
+            if (MODE == kRollout) policy_actions(id.id_lo, id.id_hi, policy, a.t0 + (uint64_t)s + 1u, n_actions, a1, a2);
+        };
         if (kWritesNone)
             next_policy();
         else if (kWritesAll)
@@ -1508,19 +1530,20 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
     }
 }
 
-template <bool AI1, bool AI2, bool PACKED = false, bool OBS16 = false>
+template <bool AI1, bool AI2, int MODE, bool PACKED = false, bool OBS16 = false>
 __global__ __launch_bounds__(2 * kLanes) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void rollout_pair_kernel(PZ_HOT_PARAMS, const StepArgs a)
 {
     const HotArgs hot{state, n, stride, act_p1, act_p2};
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     __shared__ int32_t xchg[kLoopXchgWords];  // the players' exchange: LDS of its own, double-buffered by frame parity
+    __shared__ int32_t tape_lds[MODE == kTape ? kTapeChunk * 2 * kLanes : 1];  // parked action tape (kTape only)
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (kLanes - 1);
     if (role == 0)
-        rollout_pair_body<0, AI1, AI2, PACKED, OBS16>(a, hot, lds_obs, xchg, lane);
+        rollout_pair_body<0, AI1, AI2, MODE, PACKED, OBS16>(a, hot, lds_obs, xchg, tape_lds, lane);
     else
-        rollout_pair_body<1, AI1, AI2, PACKED, OBS16>(a, hot, lds_obs, xchg, lane);
+        rollout_pair_body<1, AI1, AI2, MODE, PACKED, OBS16>(a, hot, lds_obs, xchg, tape_lds, lane);
 }
 
 // ---- constructor / reset / observe / policy kernels --------------------------------------------
@@ -2049,23 +2072,23 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
     }
 #endif
 #if !defined(PZ_NO_ROLLOUT_PAIR) && !defined(PZ_ABLATE) && !defined(PZ_STAMPS)
-    // pz_rollout_random with a computer player on the flight tables: two waves per 64 games below the size switch
+    // pz_rollout_random / pz_step_many with a computer player on the flight tables: two waves per 64 games below the size switch
     // (interleaved A/B, us per frame at k = 32: 3.49 vs 4.34 on one wave; human vs human the single wave is at the
     // write ceiling already: 3.62 on two waves -- player 1's writing all outputs -- vs 3.63 on one, 3.76 with the
     // outputs split between the waves)
-    if (MODE == kRollout && a.n < PZ_TWO_WAVE_MAX_LANES && tables && (ai1 || ai2)) {
+    if constexpr (MODE == kRollout || MODE == kTape) if (a.n < PZ_TWO_WAVE_MAX_LANES && tables && (ai1 || ai2)) {
         const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
         const bool packed = is_packed(a.cfg), obs16 = a.cfg.normalize_obs == 2;
 #define PZ_LAUNCH_ROLLOUT_PAIR(A1, A2)                                                                                    \
     do {                                                                                                                  \
         if (packed && obs16)                                                                                              \
-            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, true, true>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);      \
+            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, MODE, true, true>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);      \
         else if (packed)                                                                                                  \
-            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, true, false>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);     \
+            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, MODE, true, false>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);     \
         else if (obs16)                                                                                                   \
-            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, false, true>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);     \
+            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, MODE, false, true>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);     \
         else                                                                                                              \
-            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, false, false>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);    \
+            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, MODE, false, false>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);    \
     } while (0)
         if (ai1 && ai2)
             PZ_LAUNCH_ROLLOUT_PAIR(true, true);
