@@ -373,6 +373,7 @@ def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_t
     n = raw.num_envs
     launches = max(64, 2048 // k)
     out = raw.rollout_random(ACTION_SEED, k, t0=0)  # allocates the trajectory tensors; an untimed launch (frames 0..k-1)
+    placed = dict(raw.trajectory_placement)  # the two observation tensors in different ranks of the HBM?
     tapes = pregenerate_actions(raw, launches * k).view(launches, k, 2, n) if tape else None
     ptrs = (out["_obs"][0].data_ptr(), out["_obs"][1].data_ptr(), out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(),
             out["_term"].data_ptr())
@@ -415,7 +416,8 @@ def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_t
     gbps = bytes_per_step * n / (us_per_frame * 1e-6) / 1e9
     res = {"value": n * frames / wall, "us_per_frame": us_per_frame, "k": k, "launches_per_replay": launches,
            "replays": reps, "timed_frames": frames, "timed_seconds": wall, "bytes_per_game_step": bytes_per_step,
-           "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS, "regime": "hbm-streaming, write-dominated"}
+           "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS, "regime": "hbm-streaming, write-dominated",
+           "placement": placed}
     if check_lanes and not args.no_cpu:
         from oracle import pz_oracle as po
 
@@ -432,6 +434,38 @@ def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_t
         res.update(parity_lanes_checked=lanes, parity_steps_checked=burn + k + (reps + 1) * launches * k,
                    parity_bit_exact=bool((raw.state[:, :lanes].cpu().numpy() == chk.state).all()))
     return res
+
+
+def measure_rollout_api(args, shard, device, k=32, tape=False, p2_computer=False, seconds=0.5):
+    """The same k-frame launches issued eagerly through the env API (`rollout_random(out=...)` / `step_many(out=...)`):
+    what a training loop that calls the Python API gets, host time included (HIP events around the calls)."""
+    env = make_env(shard, device, num_envs=args.num_envs, p1_computer=args.p1_computer, p2_computer=p2_computer)
+    raw = env.unwrapped
+    env.reset()
+    burn_in(raw, min(args.burn_in, 1024))
+    tapes = pregenerate_actions(raw, 16 * k).view(16, k, 2, raw.num_envs) if tape else None
+
+    def call(j, out):
+        return raw.step_many(tapes[j % 16], out=out) if tape else raw.rollout_random(ACTION_SEED, k, t0=j * k, out=out)
+
+    out = call(0, None)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for j in range(8):
+        out = call(j, out)
+    torch.cuda.synchronize(device)
+    calls = max(8, int(seconds / ((time.perf_counter() - t0) / 8)))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    t0 = time.perf_counter()
+    for j in range(calls):
+        out = call(j, out)
+    host = time.perf_counter() - t0
+    ev1.record()
+    torch.cuda.synchronize(device)
+    us = ev0.elapsed_time(ev1) * 1e3 / (calls * k)
+    return {"us_per_frame": us, "value": raw.num_envs / (us * 1e-6), "host_us_per_call": host / calls * 1e6,
+            "calls": calls, "k": k}
 
 
 def write_ceiling(device, mib=1024):
@@ -777,6 +811,10 @@ def main():
                 r.pop("raw")
                 extra[f"launch_{mode}_{fmt}"] = {"value": r["value"], "launch_us": r["launch_us"],
                                                  "wall_us_per_step": r["wall_us_per_step"]}
+        # the k-frame launches through the env API, eagerly (no hipGraph): host time per call stays below the launch
+        extra["rollout_k32_api"] = measure_rollout_api(args, shard, device)
+        extra["step_many_k32_api"] = measure_rollout_api(args, shard, device, tape=True)
+        extra["rollout_k32_p2_computer_api"] = measure_rollout_api(args, shard, device, p2_computer=True)
 
     if rank == 0:
         alg_bytes = main_res["algorithmic_bytes_per_launch"]

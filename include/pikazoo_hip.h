@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PZ_ABI_VERSION 6
+#define PZ_ABI_VERSION 7
 #define PZ_STATE_WORDS 44
 #define PZ_OBS_DIM 35
 
@@ -144,6 +144,19 @@ int pz_count_packed_misfits(const void *packed, int64_t n, int64_t packed_stride
 /* packed -> int32 columns; *flagged (int64, device, may be NULL) += games whose misfit flag is set */
 int pz_unpack_state(const void *packed, int64_t n, int64_t packed_stride, int32_t *state, int64_t stride,
                     int64_t *flagged, void *stream);
+
+/* ---- memory-placement probe ------------------------------------------------------------------
+ * MI355X's HBM3E answers two concurrent write streams a quarter faster when they go to different thirds (ranks) of
+ * the device memory than when both go to the same one: the k-frame launches write two large
+ * observation tensors at once, so where the caller allocated them decides 2.8 vs 3.6 us per frame.  pz_probe_write
+ * issues exactly those stores -- [frames][1024 spans of 8 960 bytes], 16 bytes per lane -- into `a`, into `b`, or
+ * (both non-NULL) into both in turn, with nothing in front of them; a caller that times the three cases learns
+ * whether its two allocations share a rank: t(a, b) ~ t(a) + t(b) when they do, ~ 0.8 of that when they do not.
+ * `bytes` (per buffer; the first floor(bytes / pz_probe_frame_bytes()) frames are written, at least one) are
+ * OVERWRITTEN.  Nothing in the library calls it; pikazoo_amd/placement.py uses it when it allocates trajectory
+ * tensors. */
+int pz_probe_write(void *a, void *b, int64_t bytes, void *stream);
+int64_t pz_probe_frame_bytes(void);   /* = 1024 * 8960 */
 
 /* ---- flight look-up tables of the computer player (optional; caller-owned device memory) -----
  * The two flight predictors of the rule-based computer player are pure functions of a few small

@@ -1644,6 +1644,35 @@ __global__ __launch_bounds__(256) void random_actions_kernel(int32_t* act_p1, in
     act_p2[i] = a2;
 }
 
+// ---- memory-placement probe (pz_probe_write): the trajectory kernels' store pattern into one or two buffers -------
+// Each buffer is taken as [frames][kProbeSpans spans of kProbeSpanBytes]: workgroup w writes span w of every frame,
+// 16 bytes per lane, into both buffers in turn -- two observation tensors of a k-frame launch, nothing in front of
+// the stores.  Timing it on (a), (b) and (a, b) tells whether the two allocations share an HBM rank.
+constexpr uint32_t kProbeSpanBytes = 64u * 35u * 4u;  // one wave's observation rows of a frame
+constexpr uint32_t kProbeSpans = 1024;                // = waves of a 65 536-game launch
+constexpr int64_t kProbeFrameBytes = (int64_t)kProbeSpanBytes * kProbeSpans;
+
+__global__ __launch_bounds__(64) void probe_write_kernel(char* a, char* b, int32_t frames)
+{
+    const int lane = threadIdx.x;
+    const uint32_t span_off = blockIdx.x * kProbeSpanBytes;
+    for (int32_t f = 0; f < frames; ++f) {
+        const int64_t at = (int64_t)f * kProbeFrameBytes + span_off;
+        for (int side = 0; side < 2; ++side) {
+            char* base = side ? b : a;
+            if (base == nullptr) continue;  // (uniform)
+            const Rsrc span = make_rsrc(base + at, kProbeSpanBytes);
+#pragma unroll
+            for (int pass = 0; pass < 9; ++pass) {
+                const uint32_t v = (uint32_t)(pass * 64 + lane);
+                const u32x4 w = {(uint32_t)f, v, (uint32_t)side, 0u};
+                __builtin_amdgcn_raw_buffer_store_b128(w, span, v * 16u, 0, PZ_OBS_AUX);  // beyond the span: dropped
+            }
+        }
+    }
+}
+
+
 // ---- int32 columns <-> packed format (pz_pack_state / pz_unpack_state) ----------------------------------------
 __global__ __launch_bounds__(kLanes) void pack_state_kernel(const int32_t* state, int64_t n, int64_t stride, void* packed,
                                                             int64_t packed_stride, unsigned long long* misfits)
@@ -2231,6 +2260,19 @@ int pz_pack_state(const int32_t* state, int64_t n, int64_t stride, void* packed,
                        stride, packed, packed_stride, reinterpret_cast<unsigned long long*>(misfits));
     return (int)hipGetLastError();
 }
+
+int pz_probe_write(void* a, void* b, int64_t bytes, void* stream)
+{
+    if (a == nullptr && b == nullptr) return PZ_E_NULL;
+    if (misaligned16(a) || misaligned16(b)) return PZ_E_ALIGN;
+    const int64_t frames = bytes / kProbeFrameBytes;
+    if (frames < 1 || frames > 65536) return PZ_E_SIZE;
+    hipLaunchKernelGGL(probe_write_kernel, dim3(kProbeSpans), dim3(64), 0, (hipStream_t)stream, (char*)a, (char*)b,
+                       (int32_t)frames);
+    return (int)hipGetLastError();
+}
+
+int64_t pz_probe_frame_bytes(void) { return kProbeFrameBytes; }
 
 int pz_count_packed_misfits(const void* packed, int64_t n, int64_t packed_stride, int64_t* flagged, void* stream)
 {

@@ -132,6 +132,10 @@ class raw_env:
     the default ring of 1 the next ``step`` overwrites them, with ``output_ring=k`` the results of the last k
     ``step`` / ``reset`` calls stay intact, e.g. 2 for a loop that still reads the previous observation).
 
+    ``place_trajectories`` (default on): the two large observation tensors :meth:`rollout_random` / :meth:`step_many`
+    allocate are placed in different ranks of the device memory when that can be arranged (pikazoo_amd/placement.py:
+    the k-frame launches then run a quarter faster; same results either way).
+
     Returned tensors are views of env-owned buffers that the ``output_ring``-th next ``step`` overwrites;
     ``clone()`` what must outlive that.
     """
@@ -143,7 +147,7 @@ class raw_env:
                  device="cuda", seed: int = 0, env_id_base: int = 0, auto_reset: Optional[bool] = None,
                  validate_actions: bool = True, scalar_api: bool = False, flight_tables: bool = True,
                  sprite_dir=None, sprites=None, state_format: str = "int32", scenery: bool = False,
-                 observation_dtype=torch.int32, output_ring: int = 1):
+                 observation_dtype=torch.int32, output_ring: int = 1, place_trajectories: bool = True):
         assert serve in ("winner", "alternate", "random")  # pikazoo_env.py:104
         if render_mode not in (None, "rgb_array"):
             raise NotImplementedError('render_mode must be None or "rgb_array" (no "human" window on a GPU batch)')
@@ -239,7 +243,10 @@ class raw_env:
             rew = [torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2)]
             term = torch.zeros(n, dtype=torch.uint8, device=dev)
             self._ring.append(_OutputSet(obs, rew, term, self._state_ptr))
+        self._place_trajectories = bool(place_trajectories)
+        self.trajectory_placement = {}  # what placement.alloc_pair did for the latest trajectory tensors (diagnostic)
         self._ring_pos = 0
+        self._last_traj = None  # the latest k-frame result whose last frame the single-frame buffers still owe
         self._use_outputs(self._ring[0])
         self._trunc = torch.zeros(n, dtype=torch.bool, device=dev)  # always False (pikazoo_env.py:234)
         self._episodes = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -497,6 +504,8 @@ class raw_env:
 
     # ---- results packing ----------------------------------------------------------------------------
     def _rewards(self):
+        if self._last_traj is not None:
+            self._settle_last_frame()
         dt = self.reward_dtype
         return [r if dt == torch.int32 else r.view(torch.float32) for r in self._rew_raw]
 
@@ -511,6 +520,8 @@ class raw_env:
         return infos
 
     def _pack_obs(self):
+        if self._last_traj is not None:
+            self._settle_last_frame()
         if self.scalar_api:
             return {a: self._obs_view(i)[0].cpu().numpy() for i, a in enumerate(self.possible_agents)}
         return {a: self._obs_view(i) for i, a in enumerate(self.possible_agents)}
@@ -524,7 +535,7 @@ class raw_env:
         return self._cfg_version
 
     def _pack_step(self):
-        rew = self._rewards()
+        rew = self._rewards()  # (settles the last frame of a k-frame launch first)
         if not self.scalar_api:
             obs = self._pack_obs()
             out = (obs, dict(zip(self.possible_agents, rew)), {a: self._term for a in self.possible_agents},
@@ -553,6 +564,9 @@ class raw_env:
         pikazoo_env.py:149-173); the env stream continues from each lane's draw counter."""
         self.agents = self.possible_agents[:]
         self._next_outputs()
+        if mask is not None and self._last_traj is not None:
+            self._settle_last_frame()  # (a masked reset rewrites only the masked games' rows)
+        self._last_traj = None
         m = None
         if mask is not None:
             m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
@@ -619,6 +633,7 @@ class raw_env:
                 raise IndexError(f"action out of range [0, {n_act})")
         if len(self._ring) > 1:
             self._next_outputs()
+        self._last_traj = None  # (this launch overwrites the single-frame buffers)
         out = self._out
         # pz_step through its prepared-argument form: one FFI call with four scalars (the twelve buffers and the
         # configuration were bound once) -- the host side of a step stays below the duration of the launch it issues
@@ -647,6 +662,7 @@ class raw_env:
         if t0 is None:
             t0 = self.steps_done
         self._next_outputs()
+        self._last_traj = None
         with torch.cuda.device(self.device):
             _native.check(self._lib.pz_step_random(self._state_ptr, self.num_envs, self._stride,
                                                    self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0),
@@ -675,11 +691,8 @@ class raw_env:
         if k > 1 and n % self._traj_multiple() != 0:
             raise ValueError(f"rollout_random needs num_envs to be a multiple of {self._traj_multiple()}")
         if out is None or out["_k"] != k:
-            out = {"_k": k,
-                   "actions": torch.empty((k, 2, n), dtype=torch.int32, device=dev),
-                   "_obs": [torch.empty((k, n, _native.OBS_DIM), dtype=self._traj_obs_dtype(), device=dev) for _ in range(2)],
-                   "_rew": [torch.empty((k, n), dtype=torch.int32, device=dev) for _ in range(2)],
-                   "_term": torch.empty((k, n), dtype=torch.uint8, device=dev)}
+            out = self._alloc_trajectory(k)
+            out["actions"] = torch.empty((k, 2, n), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             _native.check(self._lib.pz_rollout_random(
                 self._state_ptr, n, self._stride, self._cfg_ref, int(action_seed) & 0xFFFFFFFFFFFFFFFF, int(t0), k,
@@ -706,10 +719,7 @@ class raw_env:
         if self.validate_actions and (int(actions.min().item()) < 0 or int(actions.max().item()) >= self.n_actions):
             raise IndexError(f"action out of range [0, {self.n_actions})")
         if out is None or out["_k"] != k:
-            out = {"_k": k,
-                   "_obs": [torch.empty((k, n, _native.OBS_DIM), dtype=self._traj_obs_dtype(), device=dev) for _ in range(2)],
-                   "_rew": [torch.empty((k, n), dtype=torch.int32, device=dev) for _ in range(2)],
-                   "_term": torch.empty((k, n), dtype=torch.uint8, device=dev)}
+            out = self._alloc_trajectory(k)
         out["actions"] = actions
         with torch.cuda.device(dev):
             _native.check(self._lib.pz_step_many(
@@ -722,6 +732,23 @@ class raw_env:
         self.steps_done += k
         return self._finish_trajectory(out)
 
+    def _alloc_trajectory(self, k):
+        """The output tensors of a k-frame launch; the two observation tensors in different ranks of the device
+        memory when they are large enough for that to matter (placement.alloc_pair)."""
+        n, dev = self.num_envs, self.device
+        shape = (k, n, _native.OBS_DIM)
+        if self._place_trajectories:
+            from . import placement
+
+            with torch.cuda.device(dev):
+                obs = list(placement.alloc_pair(shape, self._traj_obs_dtype(), dev))
+            self.trajectory_placement = dict(placement.last_info)
+        else:
+            obs = [torch.empty(shape, dtype=self._traj_obs_dtype(), device=dev) for _ in range(2)]
+        return {"_k": k, "_obs": obs,
+                "_rew": [torch.empty((k, n), dtype=torch.int32, device=dev) for _ in range(2)],
+                "_term": torch.empty((k, n), dtype=torch.uint8, device=dev)}
+
     def _traj_multiple(self):
         """every frame's observation slab of a trajectory launch must stay 16-byte aligned: 140- resp. 70-byte rows"""
         return 8 if self._cfg.normalize_obs == 2 else 4
@@ -732,17 +759,26 @@ class raw_env:
     def _finish_trajectory(self, out):
         self._next_outputs()
         dt, odt = self.reward_dtype, self.obs_dtype
-        rew = [r if dt == torch.int32 else r.view(torch.float32) for r in out["_rew"]]
-        out["obs"] = dict(zip(self.possible_agents, [o if o.dtype == odt else o.view(odt) for o in out["_obs"]]))
-        out["rewards"] = dict(zip(self.possible_agents, rew))
-        out["terminations"] = out["_term"].view(torch.bool)
-        # keep the single-frame views coherent with the last frame
-        self._obs_view(0).copy_(out["obs"][self.possible_agents[0]][-1])
-        self._obs_view(1).copy_(out["obs"][self.possible_agents[1]][-1])
-        self._rew_raw[0].copy_(out["_rew"][0][-1])
-        self._rew_raw[1].copy_(out["_rew"][1][-1])
-        self._term_u8.copy_(out["_term"][-1])
+        if out.get("_views") != (dt, odt):
+            rew = [r if dt == torch.int32 else r.view(torch.float32) for r in out["_rew"]]
+            out["obs"] = dict(zip(self.possible_agents, [o if o.dtype == odt else o.view(odt) for o in out["_obs"]]))
+            out["rewards"] = dict(zip(self.possible_agents, rew))
+            out["terminations"] = out["_term"].view(torch.bool)
+            out["_views"] = (dt, odt)
+        # the single-frame views follow the last frame -- when somebody looks at them (_settle_last_frame): five
+        # small copy launches after every k-frame launch cost the GPU 43 us, half a 32-frame rollout
+        self._last_traj = out
         return out
+
+    def _settle_last_frame(self):
+        """Bring the env-owned single-frame buffers up to the last frame of the latest k-frame launch."""
+        out, self._last_traj = self._last_traj, None
+        if out is not None:
+            self._obs_view(0).copy_(out["obs"][self.possible_agents[0]][-1])
+            self._obs_view(1).copy_(out["obs"][self.possible_agents[1]][-1])
+            self._rew_raw[0].copy_(out["_rew"][0][-1])
+            self._rew_raw[1].copy_(out["_rew"][1][-1])
+            self._term_u8.copy_(out["_term"][-1])
 
     def random_actions(self, action_seed: int, t: Optional[int] = None):
         """The policy stream of :meth:`step_random` as two ``int32[num_envs]`` device tensors."""

@@ -43,7 +43,7 @@ def test_binding_matches_library_layout(built_lib):
     from pikazoo_amd import _native
 
     lib = _native.load()
-    assert lib.pz_abi_version() == 6 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
+    assert lib.pz_abi_version() == 7 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
     assert lib.pz_config_bytes() == C.sizeof(_native.PzConfig) == 104
     assert lib.pz_error_string(0) == b"ok" and b"NULL" in lib.pz_error_string(-1)
     assert C.sizeof(_native.PzFlightTables) == 16
@@ -244,6 +244,10 @@ def test_argument_validation_without_a_gpu(built_lib):
     assert lib.pz_step_bound(block, fake, fake, None) == 0                                         # n == 0: no launch
     assert lib.pz_step_bound(block, None, fake, None) == -1
     assert lib.pz_count_packed_misfits(None, 8, 8, fake, None) == -1 and lib.pz_count_packed_misfits(fake, 8, 4, fake, None) == -2
+    # the placement probe: at least one [1024 x 8960]-byte frame per buffer, 16-byte aligned, one of the two may be NULL
+    assert lib.pz_probe_frame_bytes() == 1024 * 8960
+    assert lib.pz_probe_write(None, None, 1 << 30, None) == -1 and lib.pz_probe_write(fake, None, 1024 * 8960 - 1, None) == -2
+    assert lib.pz_probe_write(C.c_void_p(4100), fake, 1 << 30, None) == -4
     # the landing table: its 2-byte entries (an odd number) + 2 bytes of padding -- the look-up loads whole dwords
     assert lib.pz_flight_table_bytes(0) == 2 * 193 * 23 * 253 * 413 + 2 and lib.pz_flight_table_bytes(1) == 16 * 65 * 192 * 413
 

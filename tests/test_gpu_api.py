@@ -324,6 +324,84 @@ def test_output_ring_keeps_the_previous_results_intact():
     assert torch.equal(first["player_2"], snap)
 
 
+@pytest.mark.parametrize("ring", [1, 2])
+def test_single_frame_views_follow_a_k_frame_launch_lazily(ring):
+    """After rollout_random / step_many the env's own single-frame buffers owe the last frame; they are brought up
+    to date when looked at (no copy launches behind every k-frame launch), and a step in between simply overwrites
+    them: the trajectory and every returned tuple are what k single steps give."""
+    from pikazoo_amd import pikazoo_v0
+
+    kw = dict(num_envs=256, seed=11, validate_actions=False, winning_score=2)
+    a = pikazoo_v0.env(output_ring=ring, **kw)
+    b = pikazoo_v0.env(**kw)
+    a.reset(), b.reset()
+    k = 8
+    traj = a.rollout_random(5, k)
+    for t in range(k):
+        last = b.step(b.random_actions(5, t))
+    assert a._last_traj is traj  # nothing copied yet
+    obs = a._pack_obs()  # looked at: settled
+    assert a._last_traj is None
+    for ag in a.possible_agents:
+        assert torch.equal(obs[ag], last[0][ag]) and torch.equal(obs[ag], traj["obs"][ag][-1])
+    assert torch.equal(a._rewards()[0], last[1]["player_1"]) and torch.equal(a._term, last[2]["player_1"])
+    # a step right behind a k-frame launch: its results are the step's, not the rollout's last frame
+    traj = a.rollout_random(5, k)
+    for t in range(k, 2 * k):
+        b.step(b.random_actions(5, t))
+    ra, rb = a.step(a.random_actions(5, 2 * k)), b.step(b.random_actions(5, 2 * k))
+    assert a._last_traj is None
+    for x, y in zip(ra[:3], rb[:3]):
+        for ag in a.possible_agents:
+            assert torch.equal(x[ag], y[ag])
+    # a masked reset rewrites only the masked games' rows: the others show the k-frame launch's last frame
+    tape = torch.stack([torch.stack(list(b.random_actions(5, 2 * k + 1 + t).values())) for t in range(k)])
+    traj = a.step_many(tape)
+    for t in range(k):
+        last = b.step({"player_1": tape[t, 0], "player_2": tape[t, 1]})
+    mask = torch.zeros(256, dtype=torch.bool, device="cuda")
+    mask[::3] = True
+    oa, _ = a.reset(mask=mask)
+    ob, _ = b.reset(mask=mask)
+    for ag in a.possible_agents:
+        assert torch.equal(oa[ag], ob[ag])
+        assert torch.equal(oa[ag][~mask], traj["obs"][ag][-1][~mask])
+    assert torch.equal(a.state, b.state)
+
+
+def test_trajectory_tensors_are_placed_by_measurement_and_results_do_not_depend_on_it():
+    """rollout_random / step_many allocate their two observation tensors through placement.alloc_pair (the pair is
+    probed with pz_probe_write and, when it shares a rank of the device memory, re-allocated elsewhere); small
+    tensors are left alone; the trajectory is the same with and without."""
+    from pikazoo_amd import pikazoo_v0, placement
+
+    kw = dict(num_envs=65536, seed=3, validate_actions=False)
+    a = pikazoo_v0.env(**kw)
+    b = pikazoo_v0.env(place_trajectories=False, **kw)
+    a.reset(), b.reset()
+    small = a.rollout_random(2, 4)  # 37 MB per tensor: nothing to place
+    assert a.trajectory_placement == {"probed": False, "bytes": 4 * 65536 * 35 * 4}
+    b.rollout_random(2, 4)
+    assert b.trajectory_placement == {}
+    ta, tb = a.rollout_random(2, 32, t0=4), b.rollout_random(2, 32, t0=4)
+    info = a.trajectory_placement
+    assert info["probed"] and info["bytes"] == 32 * 65536 * 35 * 4 and 0.5 < info["ratio"] < 1.3
+    assert info["distinct"] == (info["ratio"] < placement.DISTINCT_BELOW)
+    for ag in a.possible_agents:
+        assert torch.equal(ta["obs"][ag], tb["obs"][ag]) and torch.equal(ta["rewards"][ag], tb["rewards"][ag])
+    assert torch.equal(ta["terminations"], tb["terminations"]) and torch.equal(a.state, b.state)
+    x, y = ta["_obs"]
+    if info["distinct"]:
+        assert placement.pair_ratio(x, y) < placement.DISTINCT_BELOW  # (measured again; overwrites both)
+    del small
+    # the same blocks handed out again are not probed again
+    ptrs = {x.data_ptr(), y.data_ptr()}
+    del ta, x, y
+    again = a.rollout_random(2, 32, t0=36)
+    if {t.data_ptr() for t in again["_obs"]} == ptrs:
+        assert a.trajectory_placement.get("cached") is True
+
+
 def test_step_through_the_bound_entry_point_equals_pz_step():
     """raw_env.step goes through pz_step_bind / pz_step_bound (the arguments prepared once per output set and
     configuration); the trajectory must be the one direct pz_step calls produce, wrappers fused later re-bind."""

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--num-envs", type=int, default=65536)
     ap.add_argument("--p2-computer", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="env.rollout_random() calls instead of C-ABI launches in a hipGraph")
     args = ap.parse_args()
     import torch
     from pikazoo_amd import pikazoo_v0
@@ -46,14 +47,32 @@ def main():
     env = pikazoo_v0.env(num_envs=args.num_envs, device="cuda:0", seed=0, is_player2_computer=args.p2_computer)
     raw = env.unwrapped
     env.reset()
+    from pikazoo_amd import _native
+
+    lib = _native.load()
     k = args.k
-    raw.rollout_random(1, k, t0=0)
+    out = raw.rollout_random(1, k, t0=0)
     torch.cuda.synchronize()
     t_launch = time.perf_counter()
     raw.rollout_random(1, k, t0=0)
     torch.cuda.synchronize()
     per_launch = time.perf_counter() - t_launch
     launches = max(1, int(args.sample / per_launch))
+    print(subprocess.run(["rocm-smi", "--showclkfrq"], capture_output=True, text=True).stdout, flush=True)
+    graph = None
+    if not args.eager:
+        ptrs = (out["_obs"][0].data_ptr(), out["_obs"][1].data_ptr(), out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(),
+                out["_term"].data_ptr())
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                cs = torch.cuda.current_stream().cuda_stream
+                for j in range(launches):
+                    rc = lib.pz_rollout_random(raw._state_ptr, raw.num_envs, raw._stride, raw._cfg_ref, 1, j * k, k,
+                                               out["actions"].data_ptr(), *ptrs, None, raw._episodes.data_ptr(),
+                                               raw._tables_ref, cs)
+                    assert rc == 0, rc
     stop, rows = threading.Event(), []
     th = threading.Thread(target=smi_loop, args=(stop, rows), daemon=True)
     th.start()
@@ -62,8 +81,11 @@ def main():
     def sample(tag, j0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for j in range(launches):
-            raw.rollout_random(1, k, t0=(j0 + j) * k)
+        if graph is not None:
+            graph.replay()
+        else:
+            for j in range(launches):
+                raw.rollout_random(1, k, t0=(j0 + j) * k)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / (launches * k)
