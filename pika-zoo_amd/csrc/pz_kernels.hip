@@ -512,7 +512,13 @@ __device__ unsigned long long g_pz_stamps[8192 * 8];
 //                    (pz_step_many), fetched 16 frames at a time into LDS.
 // SPARSE: changed-only write-back of the rarely changing columns (large batches).
 enum StepMode { kActions = 0, kRandom = 1, kRollout = 2, kTape = 3 };
-constexpr int kTapeChunk = 16;  // frames of the action tape fetched at once by pz_step_many
+#ifndef PZ_TAPE_WAVES
+#define PZ_TAPE_WAVES 8
+#endif
+#ifndef PZ_TAPE_CHUNK
+#define PZ_TAPE_CHUNK 16
+#endif
+constexpr int kTapeChunk = PZ_TAPE_CHUNK;  // frames of the action tape fetched at once by pz_step_many
 
 // The reward pipeline of one frame (see pz_config in the header): the reference's wrapper
 // stack RewardInNormalState / RewardByBallPosition in either order, fused.
@@ -878,7 +884,7 @@ __device__ __forceinline__ void scout_candidates_posted(const int32_t* __restric
 template <bool AI1, bool AI2, int MODE, bool SPARSE, int SCOUT = kNoScout, bool PACKED = false, bool OBS16 = false>
 __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes)
 __attribute__((amdgpu_waves_per_eu((MODE == kRollout || MODE == kTape) && SCOUT != kNoScout ? 2 : 1,
-                                   MODE == kRollout ? (SCOUT != kNoScout ? 2 : PZ_TRAJ_WAVES) : (MODE == kTape && SCOUT != kNoScout ? 2 : 8))))
+                                   MODE == kRollout ? (SCOUT != kNoScout ? 2 : PZ_TRAJ_WAVES) : (MODE == kTape && SCOUT != kNoScout ? 2 : (MODE == kTape ? PZ_TAPE_WAVES : 8)))))
 void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
 {
     const HotArgs hot{state, n, stride, act_p1, act_p2};
@@ -957,6 +963,21 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
             load_game(g, io);
         if (with_stats) sio.load(st);
     }
+    // pz_step_many: the tape is fetched kTapeChunk frames at a time and parked in LDS -- a per-frame global load would
+    // put a full memory latency on every frame of a lone wave, and its wait (vmcnt is in-order) would also drain that
+    // frame's stores; LDS reads only touch lgkmcnt.  The FIRST chunk is requested here, behind the state loads: its
+    // latency is theirs.  (Requesting a chunk half a chunk ahead into registers was tried: the loads pending around the
+    // loop's back edge make the compiler wait at every copy of those registers, every frame.)
+    auto fetch_tape_chunk = [&](int32_t s0) {
+        const int frames = min(kTapeChunk, a.k - s0);
+        for (int f = 0; f < frames; ++f) {  // rows past n read as 0 through the range check
+            const Rsrc tape = make_rsrc(a.act_p1 + (int64_t)(s0 + f) * 2 * a.n, n32 * 8u);
+            tape_lds[(f * 2 + 0) * kLanes + lane] = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, 0, 0);
+            tape_lds[(f * 2 + 1) * kLanes + lane] = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, n32 * 4u, 0);
+        }
+        wave_lds_handover<SCOUT == kNoScout>();  // every lane reads back its own words only
+    };
+    if (MODE == kTape) fetch_tape_chunk(0);
     const Game loaded = g;  // SPARSE: what the columns held before the frame
     PZ_DRAIN_VMEM();
     PZ_STAMP(1);
@@ -991,23 +1012,8 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
         if (kTraj && (AI1 || AI2)) issue_dropped_stores<TrajOut<OBS16>::kStores>();
         for (int32_t s = 0; s < a.k; ++s) {
             if (MODE == kTape) {
-                // The tape is fetched kTapeChunk frames at a time and parked in LDS: a per-frame global load
-                // would put a full memory latency on every frame of a lone wave, and its wait (vmcnt is
-                // in-order) would also drain that frame's stores; LDS reads only touch lgkmcnt.  (Requesting a
-                // chunk half a chunk ahead into registers was tried: the loads pending around the loop's back edge
-                // make the compiler wait at every copy of those registers, every frame.)
                 const int slot = s % kTapeChunk;
-                if (slot == 0) {
-                    const int frames = min(kTapeChunk, a.k - s);
-                    for (int f = 0; f < frames; ++f) {  // rows past n read as 0 through the range check
-                        const Rsrc tape = make_rsrc(a.act_p1 + (int64_t)(s + f) * 2 * a.n, n32 * 8u);
-                        tape_lds[(f * 2 + 0) * kLanes + lane] =
-                            (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, 0, 0);
-                        tape_lds[(f * 2 + 1) * kLanes + lane] =
-                            (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, n32 * 4u, 0);
-                    }
-                    wave_lds_handover<SCOUT == kNoScout>();  // every lane reads back its own words only
-                }
+                if (slot == 0 && s != 0) fetch_tape_chunk(s);
                 a1 = tape_lds[(slot * 2 + 0) * kLanes + lane];
                 a2 = tape_lds[(slot * 2 + 1) * kLanes + lane];
             }
@@ -1411,6 +1417,18 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
     unsigned int finished = 0;
     bool any_round_started = false;
     if (MODE == kRollout) policy_actions(id.id_lo, id.id_hi, policy, a.t0, n_actions, a1, a2);
+    // pz_step_many: every wave parks its own player's row of kTapeChunk frames in LDS (the computer's wave fetching both
+    // -- it has no stores the wait would drain -- was slower: 4.31 vs 4.12 us per frame); the first chunk behind the
+    // state loads, its latency is theirs
+    auto fetch_tape_chunk = [&](int32_t s0) {
+        const int frames = min(kTapeChunk, a.k - s0);
+        for (int f = 0; f < frames; ++f) {  // rows past n read as 0 through the range check
+            const Rsrc tape = make_rsrc(a.act_p1 + ((int64_t)(s0 + f) * 2 + ROLE) * a.n, n32 * 4u);
+            tape_lds[(f * 2 + ROLE) * kLanes + lane] = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, 0, 0);
+        }
+        __syncthreads();
+    };
+    if (MODE == kTape) fetch_tape_chunk(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // every state load lands before the frame loop (see step_kernel)
     bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
@@ -1421,16 +1439,7 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         if (MODE == kTape) {
             // (both waves read frame s - 1's actions before that frame's exchange barrier: nobody needs the old chunk here)
             const int slot = s % kTapeChunk;
-            if (slot == 0) {
-                // (every wave its own player's row; the computer's wave fetching both -- it has no stores the wait would
-                // drain -- was slower: 4.31 vs 4.12 us per frame)
-                const int frames = min(kTapeChunk, a.k - s);
-                for (int f = 0; f < frames; ++f) {  // rows past n read as 0 through the range check
-                    const Rsrc tape = make_rsrc(a.act_p1 + ((int64_t)(s + f) * 2 + ROLE) * a.n, n32 * 4u);
-                    tape_lds[(f * 2 + ROLE) * kLanes + lane] = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, 0, 0);
-                }
-                __syncthreads();
-            }
+            if (slot == 0 && s != 0) fetch_tape_chunk(s);
             a1 = tape_lds[(slot * 2 + 0) * kLanes + lane];
             a2 = tape_lds[(slot * 2 + 1) * kLanes + lane];
         }
@@ -2105,7 +2114,11 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
     // (interleaved A/B, us per frame at k = 32: 3.49 vs 4.34 on one wave; human vs human the single wave is at the
     // write ceiling already: 3.62 on two waves -- player 1's writing all outputs -- vs 3.63 on one, 3.76 with the
     // outputs split between the waves)
-    if constexpr (MODE == kRollout || MODE == kTape) if (a.n < PZ_TWO_WAVE_MAX_LANES && tables && (ai1 || ai2)) {
+#ifndef PZ_HH_PAIR_ROLLOUT
+#define PZ_HH_PAIR_ROLLOUT 1  // 1: human vs human on int16 rows, 2: every human-vs-human k-frame launch
+#endif
+    const bool hh_pair = !(ai1 || ai2) && (PZ_HH_PAIR_ROLLOUT == 2 || (PZ_HH_PAIR_ROLLOUT == 1 && a.cfg.normalize_obs == 2));
+    if constexpr (MODE == kRollout || MODE == kTape) if (a.n < PZ_TWO_WAVE_MAX_LANES && ((tables && (ai1 || ai2)) || hh_pair)) {
         const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
         const bool packed = is_packed(a.cfg), obs16 = a.cfg.normalize_obs == 2;
 #define PZ_LAUNCH_ROLLOUT_PAIR(A1, A2)                                                                                    \
@@ -2123,8 +2136,12 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
             PZ_LAUNCH_ROLLOUT_PAIR(true, true);
         else if (ai1)
             PZ_LAUNCH_ROLLOUT_PAIR(true, false);
-        else
+        else if (ai2)
             PZ_LAUNCH_ROLLOUT_PAIR(false, true);
+#if PZ_HH_PAIR_ROLLOUT
+        else
+            PZ_LAUNCH_ROLLOUT_PAIR(false, false);
+#endif
 #undef PZ_LAUNCH_ROLLOUT_PAIR
         return (int)hipGetLastError();
     }

@@ -18,7 +18,9 @@ import torch
 
 from . import _native
 
-MIN_BYTES = 256 << 20          # smaller tensors: the pair sits in the 256 MiB Infinity Cache for the probe, nothing to learn
+MIN_BYTES = 96 << 20           # smaller tensors: a launch's whole output set sits in the 256 MiB Infinity Cache
+PROBE_BYTES = 512 << 20        # what is probed: a pair smaller than this would sit in that cache for the probe, so smaller
+                               # tensors are carved from blocks of this size and the blocks are probed
 SPACER_BYTES = 4 << 30         # the physical runs of one rank seen on MI355X boxes are 2 .. 63 GiB long
 CANDIDATE_BLOCK = 1 << 30      # candidates are carved from blocks of at least this size: a small allocation is put into
                                # whatever hole fits it (usually next to the first tensor), a large one into fresh memory
@@ -46,11 +48,16 @@ def _time_probe(lib, a_ptr, b_ptr, nbytes, reps=3):
     return best
 
 
+def _span_bytes(t: torch.Tensor) -> int:
+    """Bytes from the tensor's first element to the end of its storage (a view of a larger block: the block's)."""
+    return t.untyped_storage().nbytes() - t.storage_offset() * t.element_size()
+
+
 def pair_ratio(a: torch.Tensor, b: torch.Tensor) -> float:
-    """t(a, b) / (t(a) + t(b)) of the k-frame store pattern (OVERWRITES both tensors): ~1.0 when the two allocations
-    share a rank of the device memory, ~0.8 when they do not."""
+    """t(a, b) / (t(a) + t(b)) of the k-frame store pattern (OVERWRITES both tensors, and what lies behind them in
+    their storage blocks): ~1.0 when the two allocations share a rank of the device memory, ~0.8 when they do not."""
     lib = _native.load()
-    nbytes = min(a.numel() * a.element_size(), b.numel() * b.element_size())
+    nbytes = min(_span_bytes(a), _span_bytes(b))
     with torch.cuda.device(a.device):
         t_a = _time_probe(lib, a.data_ptr(), None, nbytes)
         t_b = _time_probe(lib, None, b.data_ptr(), nbytes)
@@ -70,13 +77,23 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = MAX_SPACER_BYTES
     being captured), ``ratio`` of the pair returned, ``distinct``, ``candidates`` tried, ``spacer_gib`` walked."""
     global last_info
     device = torch.device(device)
-    a = torch.empty(shape, dtype=dtype, device=device)
-    b = torch.empty(shape, dtype=dtype, device=device)
-    nbytes = a.numel() * a.element_size()
+    probe = torch.empty((), dtype=dtype).element_size()
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    nbytes = numel * probe
     info = {"probed": False, "bytes": nbytes}
     last_info = info
-    if nbytes < MIN_BYTES or nbytes < _native.load().pz_probe_frame_bytes() or torch.cuda.is_current_stream_capturing():
-        return a, b
+    if nbytes < MIN_BYTES or torch.cuda.is_current_stream_capturing():
+        return torch.empty(shape, dtype=dtype, device=device), torch.empty(shape, dtype=dtype, device=device)
+    # (tensors below PROBE_BYTES are the front of a block of that size: the block is what the probe writes)
+    block_elems = max(numel, PROBE_BYTES // probe)
+
+    def fresh(elems):
+        block = torch.empty(elems, dtype=dtype, device=device)
+        return block[:numel].view(shape)
+
+    a, b = fresh(block_elems), fresh(block_elems)
     known = _verdicts.get(_key(a, b))
     if known is not None:  # (a pair the allocator hands out again: its blocks came back from torch's cache)
         info.update(probed=True, cached=True, ratio=known, distinct=known < DISTINCT_BELOW, candidates=0, spacer_gib=0.0)
@@ -87,8 +104,7 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = MAX_SPACER_BYTES
     if ratio < DISTINCT_BELOW or (device.index, nbytes) in _gave_up:
         return a, b
     # walk the allocator on: everything tried stays allocated meanwhile, so that the next candidate is other memory
-    numel = a.numel()
-    block_elems = max(numel, CANDIDATE_BLOCK // a.element_size())
+    block_elems = max(numel, CANDIDATE_BLOCK // probe)
     held, walked, tried, found = [], 0, 1, None
     try:
         while walked < max_spacer_bytes:
@@ -97,16 +113,15 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = MAX_SPACER_BYTES
                 break
             held.append(torch.empty(SPACER_BYTES, dtype=torch.uint8, device=device))
             walked += SPACER_BYTES
-            block = torch.empty(block_elems, dtype=dtype, device=device)
-            cand = block[:numel].view(shape)  # (keeps the block alive)
+            cand = fresh(block_elems)  # (a view: keeps its block alive)
             tried += 1
             r = pair_ratio(a, cand)
             _verdicts[_key(a, cand)] = r
             if r < DISTINCT_BELOW:
                 found, ratio = cand, r
                 break
-            held.append(block)
-            del block, cand
+            held.append(cand)
+            del cand
     except torch.cuda.OutOfMemoryError:
         pass
     if found is not None:

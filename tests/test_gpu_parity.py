@@ -774,7 +774,8 @@ def test_two_wave_and_single_wave_kernels_agree_across_the_size_switch(kw, steps
 @pytest.mark.parametrize("fmt,obs_dtype", [("int32", torch.int32), ("packed", torch.int32), ("int32", torch.int16)])
 @pytest.mark.parametrize("kw", [dict(winning_score=1, is_player2_computer=True),
                                 dict(winning_score=1, is_player1_computer=True),
-                                dict(winning_score=2, is_player1_computer=True, is_player2_computer=True, serve="random")])
+                                dict(winning_score=2, is_player1_computer=True, is_player2_computer=True, serve="random"),
+                                dict(winning_score=1)])  # (human vs human: two waves per 64 games on int16 rows only)
 def test_rollout_pair_and_single_wave_kernels_agree_across_the_size_switch(kw, fmt, obs_dtype, oracle):
     """pz_rollout_random with a computer player on the flight tables runs two waves per 64 games below 393 216 games
     (rollout_pair_kernel: the frame split by player, looped) and one from there on: both sides of the switch, every
@@ -803,6 +804,39 @@ def test_rollout_pair_and_single_wave_kernels_agree_across_the_size_switch(kw, f
                     assert np.array_equal(cpu(out["rewards"]["player_2"][f, lo:lo + m]), rrew[1]), ctx
                     assert np.array_equal(cpu(out["terminations"][f, lo:lo + m]).astype(np.uint8), rterm), ctx
                 assert np.array_equal(cpu(raw.state[:, lo:lo + m]), ref.state), (n, lo, launch)
+
+
+@pytest.mark.parametrize("fmt", ["int32", "packed"])
+def test_human_vs_human_k_frame_launches_on_int16_rows_vs_oracle(fmt, oracle):
+    """Human vs human with int16 observation rows, pz_rollout_random and pz_step_many run on two waves per 64 games
+    (each player's wave writes its agent's rows): a rollout, then the same number of frames from a tape, then a
+    rollout again -- every frame's outputs and the state after every launch against the oracle, a ragged batch."""
+    n, k = 64 * 37 + 8, 24
+    env = make_env(num_envs=n, seed=46, env_id_base=3, state_format=fmt, observation_dtype=torch.int16, winning_score=1)
+    raw = env.unwrapped
+    env.reset()
+    ref = oracle.OracleEnv(n, oracle.make_config(seed=46, env_id_base=3, winning_score=1), nthreads=4)
+    ref.reset()
+    t = 0
+    for launch in range(3):
+        acts = [oracle.random_actions(n, 3, 29, t + f) for f in range(k)]
+        if launch == 1:
+            tape = torch.from_numpy(np.stack([np.stack(a) for a in acts]).astype(np.int32)).to(raw.device)
+            out = raw.step_many(tape)
+        else:
+            out = raw.rollout_random(29, k, t0=t)
+        assert out["obs"]["player_1"].dtype == torch.int16
+        for f in range(k):
+            robs, rrew, rterm = ref.step(*acts[f])
+            ctx = (fmt, launch, f)
+            assert np.array_equal(cpu(out["actions"][f, 1]), acts[f][1]), ctx
+            assert np.array_equal(cpu(out["obs"]["player_1"][f]).astype(np.int32), robs[0]), ctx
+            assert np.array_equal(cpu(out["obs"]["player_2"][f]).astype(np.int32), robs[1]), ctx
+            assert np.array_equal(cpu(out["rewards"]["player_1"][f]), rrew[0]), ctx
+            assert np.array_equal(cpu(out["rewards"]["player_2"][f]), rrew[1]), ctx
+            assert np.array_equal(cpu(out["terminations"][f]).astype(np.uint8), rterm), ctx
+        assert np.array_equal(cpu(raw.state), ref.state), (fmt, launch)
+        t += k
 
 
 # ------------------------------------------------------------------------------------------------

@@ -119,7 +119,11 @@ def main():
 
     if rollout:
         k = rollout
-        t_obs = [torch.zeros((k, n, 35), dtype=torch.int32, device=dev) for _ in range(2)]
+        # the two observation tensors in different ranks of the HBM (pikazoo_amd/placement.py), like the env's own:
+        # in one rank the memory system caps every variant at ~3.6 us per frame and hides what the kernels differ in
+        from pikazoo_amd import placement
+        t_obs = list(placement.alloc_pair((k, n, 35), torch.int32, dev))
+        print("  observation tensors:", {x: (round(v, 3) if isinstance(v, float) else v) for x, v in placement.last_info.items()})
         t_rew = [torch.zeros((k, n), dtype=torch.int32, device=dev) for _ in range(2)]
         t_term = torch.zeros((k, n), dtype=torch.uint8, device=dev)
         t_act = torch.zeros((k, 2, n), dtype=torch.int32, device=dev)

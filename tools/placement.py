@@ -22,8 +22,11 @@ def main():
     ap.add_argument("--p2-computer", action="store_true")
     ap.add_argument("--arena-mib", type=int, default=6144)
     ap.add_argument("--bases", type=int, nargs="+", default=None, help="only: the arena set at these byte offsets")
+    ap.add_argument("--tables-rank", action="store_true", help="only (with --p2-computer): the k-frame launch with the flight "
+                    "tables in the rank of obs1, of obs2, and in the third rank")
     ap.add_argument("--step-spread", action="store_true", help="only: pz_step (single frame) with state / obs1 / obs2 in one "
                     "rank of the device memory vs spread over three, at --num-envs")
+    ap.add_argument("--obs16", action="store_true", help="int16 observations (with --product)")
     ap.add_argument("--product", action="store_true", help="only: the env's own allocation, with and without placement")
     ap.add_argument("--many", type=int, default=0, help="only: this many separately allocated sets per k, all kept alive")
     ap.add_argument("--replays", type=int, default=0, help="a fixed number of timed replays per case (under rocprofv3 --pmc: "
@@ -71,7 +74,10 @@ def main():
             off = (off + nbytes + gap + 255) // 256 * 256
         return t
 
-    def time_case(tag, k, t):
+    def time_case(tag, k, t, raw=raw):
+        # (the tensors must be the row format of `raw`'s configuration: int16 rows are half the size of int32 ones)
+        assert t["obs1"].dtype == raw._traj_obs_dtype() and t["obs1"].shape == (k, raw.num_envs, 35)
+        n = raw.num_envs
         launches = max(64, 2048 // k)
         side = torch.cuda.Stream()
         g = torch.cuda.CUDAGraph()
@@ -101,6 +107,61 @@ def main():
         ptrs = " ".join(f"{nm}@{t[nm].data_ptr() & 0xFFFFFFFFFF:010x}" for nm in ("obs1", "obs2", "term"))
         print(f"{tag:34s} k={k:4d}  {us:6.3f} us/frame (best replay {best * 1e3 / (launches * k):6.3f})  {ptrs}", flush=True)
 
+    if args.tables_rank:
+        import ctypes as C
+        from pikazoo_amd import placement
+
+        k = args.k[0]
+        out = raw.rollout_random(1, k, t0=0)
+        print("observation tensors:", raw.trajectory_placement, flush=True)
+        o1, o2 = out["_obs"]
+        land_b, hit_b = int(lib.pz_flight_table_bytes(0)), int(lib.pz_flight_table_bytes(1))
+        blocks, spacers = {}, []
+        while len(blocks) < 3 and len(spacers) < 40:
+            c = torch.empty((land_b + hit_b + 4095) // 4096 * 4096 + (64 << 20), dtype=torch.uint8, device=dev)
+            r1, r2 = placement.pair_ratio(o1, c), placement.pair_ratio(o2, c)
+            kind = "rank of obs1" if r1 >= 0.9 and r2 < 0.9 else "rank of obs2" if r2 >= 0.9 and r1 < 0.9 else "third rank" if r1 < 0.9 and r2 < 0.9 else None
+            if kind and kind not in blocks:
+                blocks[kind] = c
+            else:
+                spacers.append(c)
+            spacers.append(torch.empty(4 << 30, dtype=torch.uint8, device=dev))
+        print("table blocks found:", sorted(blocks), "after", len(spacers), "other allocations", flush=True)
+        tabs = {}
+        cs0 = torch.cuda.current_stream().cuda_stream
+        for kind, c in blocks.items():
+            t_land = c[:land_b]
+            t_hit = c[(land_b + 4095) // 4096 * 4096:][:hit_b]
+            assert lib.pz_build_flight_tables(t_land.data_ptr(), t_hit.data_ptr(), cs0) == 0
+            tabs[kind] = _native.PzFlightTables(t_land.data_ptr(), t_hit.data_ptr())
+        torch.cuda.synchronize()
+        ptrs = (out["_obs"][0].data_ptr(), out["_obs"][1].data_ptr(), out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(),
+                out["_term"].data_ptr())
+        snap = raw.state.clone()
+        for rnd in range(2):
+            for kind in sorted(tabs):
+                raw.set_state(snap)
+                launches = max(64, 2048 // k)
+                side = torch.cuda.Stream()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                        cs = torch.cuda.current_stream().cuda_stream
+                        for j in range(launches):
+                            rc = lib.pz_rollout_random(raw._state_ptr, n, raw._stride, raw._cfg_ref, 1, j * k, k,
+                                                       out["actions"].data_ptr(), *ptrs, None, raw._episodes.data_ptr(),
+                                                       C.byref(tabs[kind]), cs)
+                            assert rc == 0, rc
+                    g.replay()
+                    side.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(side)
+                    for _ in range(30):
+                        g.replay()
+                    e1.record(side)
+                    side.synchronize()
+                print(f"  flight tables in the {kind:13s}: {e0.elapsed_time(e1) * 1e3 / (30 * launches * k):6.3f} us per frame", flush=True)
+        return
     if args.step_spread:
         from pikazoo_amd import placement
 
@@ -167,14 +228,15 @@ def main():
             for rnd in range(3):
                 for place in (False, True):
                     e2 = pikazoo_v0.env(num_envs=args.num_envs, device="cuda:0", seed=0, is_player2_computer=args.p2_computer,
-                                        place_trajectories=place)
+                                        place_trajectories=place, observation_dtype=torch.int16 if args.obs16 else torch.int32)
                     e2.reset()
                     out = e2.unwrapped.rollout_random(1, k, t0=0)
                     keep.append(out)
                     t = {"actions": out["actions"], "obs1": out["_obs"][0], "obs2": out["_obs"][1], "rew1": out["_rew"][0],
                          "rew2": out["_rew"][1], "term": out["_term"]}
                     info = e2.unwrapped.trajectory_placement
-                    time_case(f"env alloc, place={place} {({x: (round(v, 3) if isinstance(v, float) else v) for x, v in info.items() if x != 'bytes'})}"[:110], k, t)
+                    time_case(f"env alloc, place={place} {({x: (round(v, 3) if isinstance(v, float) else v) for x, v in info.items() if x != 'bytes'})}"[:110], k, t,
+                              raw=e2.unwrapped)
         return
     if args.bases is not None:
         for k in args.k:
