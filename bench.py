@@ -42,7 +42,9 @@ The single JSON line also carries
                   5: fused wrappers), the packed / int16 formats and the 524 288-game batch, each timed the
                   same way, oracle-checked, with `regime`, `traffic`, `frac_traffic`; the k-frame
                   launches (pz_rollout_random, pz_step_many, k = 32; on their own 297 + 352 / k bytes,
-                  beside the box's measured write ceiling) and the policy-in-the-step launch.
+                  with where their two observation tensors were placed and what pure stores of the
+                  launch's pattern reach on those tensors, measured in the run) and the
+                  policy-in-the-step launch.
 """
 from __future__ import annotations
 
@@ -357,14 +359,14 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     return res
 
 
-def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_time=0.25, check_lanes=0):
+def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_time=0.25, check_lanes=0, obs16=False):
     """pz_rollout_random (or, tape=True, pz_step_many on a pre-generated action tape): k frames per launch, every
     frame's outputs written to [k][n]... trajectory tensors (state in registers, read / written once per launch).
     Timed like the headline: the launches go through the C ABI into ONE hipGraph (>= 64 launches, each on its own
     step indices t0), one untimed replay, then R replays until the timed region lasts >= min_time; HIP events on the
     launch stream.  Algorithmic bytes per game-step of THESE kernels: 297 (8 of them the action words written resp.
     read) + 352 / k.  `check_lanes`: the first lanes' final state against the CPU oracle replaying the same launches."""
-    env = make_env(shard, device, num_envs=args.num_envs, p1_computer=args.p1_computer, p2_computer=p2_computer)
+    env = make_env(shard, device, num_envs=args.num_envs, p1_computer=args.p1_computer, p2_computer=p2_computer, obs16=obs16)
     raw = env.unwrapped
     lib = _native.load()
     env.reset()
@@ -374,6 +376,11 @@ def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_t
     launches = max(64, 2048 // k)
     out = raw.rollout_random(ACTION_SEED, k, t0=0)  # allocates the trajectory tensors; an untimed launch (frames 0..k-1)
     placed = dict(raw.trajectory_placement)  # the two observation tensors in different ranks of the HBM?
+    # what pure stores of the launch's pattern into THESE two tensors reach (pz_probe_write: nothing in front of the stores)
+    from pikazoo_amd import placement
+
+    with torch.cuda.device(device):
+        pure_store_gbps = placement.pair_write_rate(out["_obs"][0], out["_obs"][1])
     tapes = pregenerate_actions(raw, launches * k).view(launches, k, 2, n) if tape else None
     ptrs = (out["_obs"][0].data_ptr(), out["_obs"][1].data_ptr(), out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(),
             out["_term"].data_ptr())
@@ -412,12 +419,12 @@ def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_t
         wall = time.perf_counter() - t0
     frames = reps * launches * k
     us_per_frame = ev0.elapsed_time(ev1) * 1e3 / frames
-    bytes_per_step = 297 + 352.0 / k
+    bytes_per_step = (157 if obs16 else 297) + 352.0 / k  # (int16 rows: 2 x 70 instead of 2 x 140 bytes)
     gbps = bytes_per_step * n / (us_per_frame * 1e-6) / 1e9
     res = {"value": n * frames / wall, "us_per_frame": us_per_frame, "k": k, "launches_per_replay": launches,
            "replays": reps, "timed_frames": frames, "timed_seconds": wall, "bytes_per_game_step": bytes_per_step,
            "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS, "regime": "hbm-streaming, write-dominated",
-           "placement": placed}
+           "placement": placed, "pure_store_GBps": pure_store_gbps, "frac_of_pure_stores": gbps / pure_store_gbps}
     if check_lanes and not args.no_cpu:
         from oracle import pz_oracle as po
 
@@ -466,24 +473,6 @@ def measure_rollout_api(args, shard, device, k=32, tape=False, p2_computer=False
     us = ev0.elapsed_time(ev1) * 1e3 / (calls * k)
     return {"us_per_frame": us, "value": raw.num_envs / (us * 1e-6), "host_us_per_call": host / calls * 1e6,
             "calls": calls, "k": k}
-
-
-def write_ceiling(device, mib=1024):
-    """What this box takes for plain streaming writes: torch's fill of a 1 GiB tensor, best of 5 (GB/s).  The
-    trajectory kernels are write-dominated; their `frac` is quoted against the 8 TB/s HBM peak, this is the rate
-    a kernel that does nothing but write reaches here (tools/wstream.hip: the rollout's own store pattern reaches
-    the same)."""
-    buf = torch.empty(mib << 20, dtype=torch.uint8, device=device)
-    best = float("inf")
-    for _ in range(6):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for v in range(8):
-            buf.fill_(v)
-        ev1.record()
-        torch.cuda.synchronize(device)
-        best = min(best, ev0.elapsed_time(ev1) / 8)
-    return (mib << 20) / (best * 1e-3) / 1e9
 
 
 def measure_policy_in_the_loop(args, shard, device, launches=2048, fused=False):
@@ -675,7 +664,9 @@ def main():
     if args.rollouts:
         out = {"rollout_k32": measure_rollout(args, shard, device, k=32),
                "step_many_k32": measure_rollout(args, shard, device, k=32, tape=True),
-               "rollout_k32_p2_computer": measure_rollout(args, shard, device, k=32, p2_computer=True)}
+               "rollout_k32_p2_computer": measure_rollout(args, shard, device, k=32, p2_computer=True),
+               "step_many_k32_p2_computer": measure_rollout(args, shard, device, k=32, tape=True, p2_computer=True),
+               "rollout_k32_int16obs": measure_rollout(args, shard, device, k=32, obs16=True)}
         print(json.dumps(out), flush=True)
         return
 
@@ -762,7 +753,6 @@ def main():
         # the k-frame launches (state in registers, every frame's outputs to [k][N]... tensors), on
         # their own 297 + 352 / k algorithmic bytes per game-step; write-dominated, so the rate a pure fill reaches
         # on this box is printed beside them
-        ceiling = write_ceiling(device)
         traj = {
             "rollout_k32": ("pz_rollout_random, k = 32: 65 536 games, random policy drawn in the kernel", dict()),
             "step_many_k32": ("pz_step_many, k = 32: 65 536 games, actions from a tape in HBM", dict(tape=True)),
@@ -771,15 +761,22 @@ def main():
             "step_many_k32_p2_computer": ("pz_step_many, k = 32, player 2 = rule-based computer (flight tables)",
                                           dict(p2_computer=True, tape=True)),
         }
+        traj["rollout_k32_int16obs"] = ("pz_rollout_random, k = 32, int16 observation rows (165 B per game-step): two waves per "
+                                        "64 games, each player's wave writing its agent's rows", dict(obs16=True))
         traj["rollout_k128"] = ("pz_rollout_random, k = 128 (the launch's fixed costs -- state in and out, the first frame's "
                                 "latency before the first store -- over four times as many frames)", dict(k=128))
         for key, (wl, kw) in traj.items():
             r = measure_rollout(args, shard, device, check_lanes=1024, **{"k": 32, **kw})
-            r.update(workload=wl, num_envs=args.num_envs, write_ceiling_GBps=ceiling,
-                     frac_of_write_ceiling=r["achieved_GBps"] / ceiling,
-                     bound_detail="every frame's outputs stream to HBM (623 MB per 32-frame launch): bound by the "
-                                  "memory system's write rate, which a kernel that only writes reaches at "
-                                  "write_ceiling_GBps on this box (tools/wstream.hip: the same for this store pattern)")
+            # counted bytes of one k-frame launch (profiles/traffic.json: FETCH_SIZE x 2 + WRITE_SIZE of the same kernel)
+            tr = load_traffic(key, args.num_envs)
+            r.update(traffic=tr, frac_traffic=None if tr is None else
+                     tr / (r["k"] * r["us_per_frame"] * 1e-6) / 1e9 / HBM_PEAK_GBPS)
+            r.update(workload=wl, num_envs=args.num_envs,
+                     bound_detail="every frame's outputs stream to HBM (623 MB per 32-frame launch of int32 rows): "
+                                  "pure_store_GBps is what the launch's store pattern alone reaches on this entry's own "
+                                  "two observation tensors (pz_probe_write, measured in this run; 7.1 TB/s when "
+                                  "they lie in different ranks of the HBM, 5.6 when they share one: `placement`, "
+                                  "DESIGN 4.9); the int16 rows are not write-bound")
             configs[key] = r
         # the reference's own loop, literally -- sample both agents' actions, then step -- as ONE launch per step
         r = measure_policy_in_the_loop(args, shard, device, fused=True)

@@ -18,18 +18,24 @@ import torch
 
 from . import _native
 
-MIN_BYTES = 96 << 20           # smaller tensors: a launch's whole output set sits in the 256 MiB Infinity Cache
-PROBE_BYTES = 512 << 20        # what is probed: a pair smaller than this would sit in that cache for the probe, so smaller
-                               # tensors are carved from blocks of this size and the blocks are probed
+MIN_BYTES = 256 << 20          # smaller tensors are left alone: the probe of a smaller pair would sit in the 256 MiB
+                               # Infinity Cache, and the launches that write them are not bound by the write rate (int16
+                               # rows at k = 32: 2.88 us per frame in one rank and in two)
 SPACER_BYTES = 4 << 30         # the physical runs of one rank seen on MI355X boxes are 2 .. 63 GiB long
 CANDIDATE_BLOCK = 1 << 30      # candidates are carved from blocks of at least this size: a small allocation is put into
                                # whatever hole fits it (usually next to the first tensor), a large one into fresh memory
 MAX_SPACER_BYTES = 96 << 30    # one rank is 96 GB: further than that the allocator has left the first candidate's rank
-DISTINCT_BELOW = 0.90          # t(a, b) / (t(a) + t(b)): ~1.0 in one rank, ~0.8 in two
+DISTINCT_BELOW = 0.86          # t(a, b) / (t(a) + t(b)): ~1.0 in one rank, 0.77-0.83 in two (in between: a tensor that
+                               # straddles two ranks)
 
 _verdicts: dict = {}           # (device index, low ptr, high ptr, bytes) -> ratio measured for that pair
 _gave_up: set = set()          # (device index, bytes): the budget was spent once, later pairs of that size are not walked again
 last_info: dict = {}           # what the latest alloc_pair did (diagnostic; bench.py prints it)
+
+
+WARM_LAUNCHES = 24             # ~2.5 ms of the probe before anything is timed: after an idle spell (a host-side pause of
+                               # a few seconds is enough) the first launches run at low clocks, and a slow t(a) in front
+                               # of a normal t(a, b) reads as "two ranks"
 
 
 def _time_probe(lib, a_ptr, b_ptr, nbytes, reps=3):
@@ -55,14 +61,33 @@ def _span_bytes(t: torch.Tensor) -> int:
 
 def pair_ratio(a: torch.Tensor, b: torch.Tensor) -> float:
     """t(a, b) / (t(a) + t(b)) of the k-frame store pattern (OVERWRITES both tensors, and what lies behind them in
-    their storage blocks): ~1.0 when the two allocations share a rank of the device memory, ~0.8 when they do not."""
+    their storage blocks): ~1.0 when the two allocations share a rank of the device memory, ~0.8 when they do not.
+    The three cases are timed in turn, twice, behind a warm-up that brings the clocks up; the best of each counts."""
     lib = _native.load()
     nbytes = min(_span_bytes(a), _span_bytes(b))
     with torch.cuda.device(a.device):
-        t_a = _time_probe(lib, a.data_ptr(), None, nbytes)
-        t_b = _time_probe(lib, None, b.data_ptr(), nbytes)
-        t_ab = _time_probe(lib, a.data_ptr(), b.data_ptr(), nbytes)
+        raw = torch.cuda.current_stream().cuda_stream
+        for _ in range(WARM_LAUNCHES):
+            _native.check(lib.pz_probe_write(a.data_ptr(), b.data_ptr(), nbytes, raw), "pz_probe_write")
+        t_a = t_b = t_ab = float("inf")
+        for _ in range(2):
+            t_ab = min(t_ab, _time_probe(lib, a.data_ptr(), b.data_ptr(), nbytes))
+            t_a = min(t_a, _time_probe(lib, a.data_ptr(), None, nbytes))
+            t_b = min(t_b, _time_probe(lib, None, b.data_ptr(), nbytes))
     return t_ab / (t_a + t_b)
+
+
+def pair_write_rate(a: torch.Tensor, b: torch.Tensor) -> float:
+    """GB/s of the k-frame store pattern into both tensors at once (OVERWRITES them): ~7 100 in two ranks, ~5 500 in one."""
+    lib = _native.load()
+    nbytes = min(_span_bytes(a), _span_bytes(b))
+    frame = int(lib.pz_probe_frame_bytes())
+    with torch.cuda.device(a.device):
+        raw = torch.cuda.current_stream().cuda_stream
+        for _ in range(WARM_LAUNCHES):
+            _native.check(lib.pz_probe_write(a.data_ptr(), b.data_ptr(), nbytes, raw), "pz_probe_write")
+        us = _time_probe(lib, a.data_ptr(), b.data_ptr(), nbytes)
+    return 2 * (nbytes // frame) * frame / (us * 1e-6) / 1e9
 
 
 def _key(a, b):
@@ -86,14 +111,12 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = MAX_SPACER_BYTES
     last_info = info
     if nbytes < MIN_BYTES or torch.cuda.is_current_stream_capturing():
         return torch.empty(shape, dtype=dtype, device=device), torch.empty(shape, dtype=dtype, device=device)
-    # (tensors below PROBE_BYTES are the front of a block of that size: the block is what the probe writes)
-    block_elems = max(numel, PROBE_BYTES // probe)
 
-    def fresh(elems):
+    def fresh(elems):  # (the front of a block of `elems` elements; the view keeps the block alive)
         block = torch.empty(elems, dtype=dtype, device=device)
         return block[:numel].view(shape)
 
-    a, b = fresh(block_elems), fresh(block_elems)
+    a, b = fresh(numel), fresh(numel)
     known = _verdicts.get(_key(a, b))
     if known is not None:  # (a pair the allocator hands out again: its blocks came back from torch's cache)
         info.update(probed=True, cached=True, ratio=known, distinct=known < DISTINCT_BELOW, candidates=0, spacer_gib=0.0)

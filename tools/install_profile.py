@@ -31,6 +31,12 @@ TRAFFIC = {
     "packed_random_random_524288": ("pkbig", "pz::step_pair_kernel<false, false, true, false>", 524288),
     "packed_random_random_int16obs": ("ph", "pz::step_pair_kernel<false, false, true, false>", 65536),
     "packed_random_random_524288_int16obs": ("phbig", "pz::step_pair_kernel<false, false, true, false>", 524288),
+    # the k-frame launches (k = 32: bytes per 32-frame launch)
+    "rollout_k32": ("roll", "pz::step_kernel<false, false, 2, false, 0, false, false>", 65536),
+    "step_many_k32": ("roll", "pz::step_kernel<false, false, 3, false, 0, false, false>", 65536),
+    "rollout_k32_p2_computer": ("roll", "pz::rollout_pair_kernel<false, true, 2, false, false>", 65536),
+    "step_many_k32_p2_computer": ("roll", "pz::rollout_pair_kernel<false, true, 3, false, false>", 65536),
+    "rollout_k32_int16obs": ("roll", "pz::rollout_pair_kernel<false, false, 2, false, true>", 65536),
 }
 
 

@@ -22,10 +22,14 @@ def main():
     ap.add_argument("--p2-computer", action="store_true")
     ap.add_argument("--arena-mib", type=int, default=6144)
     ap.add_argument("--bases", type=int, nargs="+", default=None, help="only: the arena set at these byte offsets")
+    ap.add_argument("--tables-align", action="store_true", help="only (with --p2-computer): pz_step with the flight tables in "
+                    "plain allocations vs at a 1 GiB boundary of one large allocation (larger page-table fragments)")
     ap.add_argument("--tables-rank", action="store_true", help="only (with --p2-computer): the k-frame launch with the flight "
                     "tables in the rank of obs1, of obs2, and in the third rank")
     ap.add_argument("--step-spread", action="store_true", help="only: pz_step (single frame) with state / obs1 / obs2 in one "
                     "rank of the device memory vs spread over three, at --num-envs")
+    ap.add_argument("--idle", type=float, default=0.0, help="with --product: seconds of host-side pause in front of every "
+                    "allocation (the probe must not be fooled by the low clocks after an idle spell)")
     ap.add_argument("--obs16", action="store_true", help="int16 observations (with --product)")
     ap.add_argument("--product", action="store_true", help="only: the env's own allocation, with and without placement")
     ap.add_argument("--many", type=int, default=0, help="only: this many separately allocated sets per k, all kept alive")
@@ -107,6 +111,49 @@ def main():
         ptrs = " ".join(f"{nm}@{t[nm].data_ptr() & 0xFFFFFFFFFF:010x}" for nm in ("obs1", "obs2", "term"))
         print(f"{tag:34s} k={k:4d}  {us:6.3f} us/frame (best replay {best * 1e3 / (launches * k):6.3f})  {ptrs}", flush=True)
 
+    if args.tables_align:
+        import ctypes as C
+
+        land_b, hit_b = int(lib.pz_flight_table_bytes(0)), int(lib.pz_flight_table_bytes(1))
+        cs0 = torch.cuda.current_stream().cuda_stream
+        sets = {}
+        t_land, t_hit = torch.empty(land_b, dtype=torch.uint8, device=dev), torch.empty(hit_b, dtype=torch.uint8, device=dev)
+        sets["two plain allocations"] = (t_land, t_hit)
+        big = torch.empty(3 << 30, dtype=torch.uint8, device=dev)
+        off = (-big.data_ptr()) % (1 << 30)
+        sets["1 GiB boundary of a 3 GiB allocation"] = (big[off:off + land_b], big[off + (1 << 30):off + (1 << 30) + hit_b])
+        tabs = {}
+        for kind, (tl, th) in sets.items():
+            assert lib.pz_build_flight_tables(tl.data_ptr(), th.data_ptr(), cs0) == 0
+            tabs[kind] = _native.PzFlightTables(tl.data_ptr(), th.data_ptr())
+        torch.cuda.synchronize()
+        acts = torch.randint(0, 18, (64, 2, n), dtype=torch.int32, device=dev)
+        p_ = raw._ptrs
+        snap = raw.state.clone()
+        for rnd in range(3):
+            for kind in tabs:
+                raw.set_state(snap)
+                side = torch.cuda.Stream()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                        cs = torch.cuda.current_stream().cuda_stream
+                        for t in range(512):
+                            a = acts[t % 64]
+                            rc = lib.pz_step(raw._state_ptr, n, raw._stride, raw._cfg_ref, a[0].data_ptr(), a[1].data_ptr(),
+                                             raw._obs[0].data_ptr(), raw._obs[1].data_ptr(), raw._rew_raw[0].data_ptr(),
+                                             raw._rew_raw[1].data_ptr(), raw._term_u8.data_ptr(), None, C.byref(tabs[kind]), cs)
+                            assert rc == 0, rc
+                    g.replay()
+                    side.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(side)
+                    for _ in range(20):
+                        g.replay()
+                    e1.record(side)
+                    side.synchronize()
+                print(f"  pz_step, player 2 = computer, tables in {kind:40s}: {e0.elapsed_time(e1) * 1e3 / (20 * 512):6.3f} us per launch", flush=True)
+        return
     if args.tables_rank:
         import ctypes as C
         from pikazoo_amd import placement
@@ -230,6 +277,9 @@ def main():
                     e2 = pikazoo_v0.env(num_envs=args.num_envs, device="cuda:0", seed=0, is_player2_computer=args.p2_computer,
                                         place_trajectories=place, observation_dtype=torch.int16 if args.obs16 else torch.int32)
                     e2.reset()
+                    torch.cuda.synchronize()
+                    if args.idle:
+                        __import__("time").sleep(args.idle)
                     out = e2.unwrapped.rollout_random(1, k, t0=0)
                     keep.append(out)
                     t = {"actions": out["actions"], "obs1": out["_obs"][0], "obs2": out["_obs"][1], "rew1": out["_rew"][0],
