@@ -22,6 +22,7 @@
 // column accesses, and rows past the end of the batch are dropped by the hardware range check.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "pikazoo_hip.h"
 #include "pz_physics.hpp"
@@ -41,6 +42,20 @@ constexpr int kWaveObsVecs = (int)(kWaveObsBytes / 16);   // 560 16-byte pieces
 #ifndef PZ_OBS_AUX
 #define PZ_OBS_AUX 2  // observations are written once and not re-read by the step chain: nt, -2.4 % per launch
 #endif
+#ifndef PZ_TRAJ_AUX
+// The k-frame launches' observation rows (623 MB per 32-frame launch): sc0 sc1 nt.  With a computer player, rows written
+// `nt` alone (the single-frame launches' policy) push the flight tables' hot lines out of the caches and the look-ups
+// come from HBM: pz_rollout_random, k = 32, interleaved on one box: nt 3.21-3.25 us per frame, sc1 nt 3.13-3.15,
+// sc0 sc1 nt 3.12-3.14 (plain 4.2, sc1 alone 4.3); human vs human 2.83 / 2.82 / 2.82.  A single-frame launch keeps
+// `nt` (sc1 nt: 6.99 -> 7.08 us; with a computer player 8.87 -> 8.82).
+#define PZ_TRAJ_AUX 19
+#endif
+#ifndef PZ_TRAJ_SMALL_AUX_AI
+#define PZ_TRAJ_SMALL_AUX_AI 18
+#endif
+// the k-frame launches' rewards / flags / actions (17 of a game-step's 297 bytes): sc1 nt where the launch gathers
+// from the flight tables (3.13 -> 3.11 us per frame, k = 128: 2.99 -> 2.94), plain otherwise (nt: 2.81 -> 2.94)
+constexpr int traj_small_aux(bool computer_player) { return computer_player ? PZ_TRAJ_SMALL_AUX_AI : 0; }
 
 using Rsrc = __amdgpu_buffer_rsrc_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -477,10 +492,21 @@ __device__ unsigned long long g_pz_stamps[8192 * 8];
             g_pz_stamps[(blockIdx.x * 2 + (role)) * 8 + (k)] = t_;                          \
         }                                                                                  \
     } while (0)
+// where the wave runs: HW_ID (wave / SIMD / CU / SE) and XCC_ID in slot 7
+#define PZ_PAIR_WHERE(role)                                                                                   \
+    do {                                                                                                      \
+        if (blockIdx.x < 4096 && lane == 0) {                                                                 \
+            unsigned int hw_, xcc_;                                                                           \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)"      \
+                         : "=s"(hw_), "=s"(xcc_));                                                            \
+            g_pz_stamps[(blockIdx.x * 2 + (role)) * 8 + 7] = ((unsigned long long)xcc_ << 32) | hw_;          \
+        }                                                                                                     \
+    } while (0)
 #else
 #define PZ_STAMP(k)
 #define PZ_DRAIN_VMEM()
 #define PZ_PAIR_STAMP(role, k)
+#define PZ_PAIR_WHERE(role)
 #endif
 
 #ifdef PZ_ABLATE
@@ -516,9 +542,54 @@ enum StepMode { kActions = 0, kRandom = 1, kRollout = 2, kTape = 3 };
 #define PZ_TAPE_WAVES 8
 #endif
 #ifndef PZ_TAPE_CHUNK
-#define PZ_TAPE_CHUNK 16
+#define PZ_TAPE_CHUNK 64
 #endif
-constexpr int kTapeChunk = PZ_TAPE_CHUNK;  // frames of the action tape fetched at once by pz_step_many
+// pz_step_many parks its action tape in LDS, ONE BYTE per action (an action is < 18; out-of-range actions are undefined
+// behaviour in the C ABI, include/pikazoo_hip.h): kTapeChunk frames of both players for a wave's 64 games are 8 KB.
+constexpr int kTapeChunk = PZ_TAPE_CHUNK;            // frames of the action tape fetched at once by pz_step_many
+constexpr int kTapeWords = kTapeChunk * 2 * kLanes / 4;  // the parked chunk in int32 words of LDS
+#ifndef PZ_TAPE_AUX
+#define PZ_TAPE_AUX 18  // sc1 nt: a cold tape streamed with the default policy pushes the flight tables' hot lines out of the caches
+#endif
+constexpr int kTapeBatch = 16;                        // tape rows requested together by a refill inside the frame loop
+
+// Rows [s0 + f0, s0 + f0 + B) of the tape (frames past k: an empty descriptor, the range check answers 0 without a
+// memory access) for the players asked for: ALL the loads are in flight before the first one is waited for -- one
+// memory round trip per batch (a refill that waits for each row, or each handful of rows, pays the latency of a cold
+// tape under the launch's write stream several times over: 3.88 vs 3.27 us per frame with a cache-resident tape).
+template <int B, bool P1, bool P2>
+__device__ __forceinline__ void park_tape_rows(const int32_t* tape0, int64_t n, uint32_t n32, int32_t k, int32_t s0, int f0,
+                                               uint32_t voff, unsigned char* __restrict__ parked, int lane)
+{
+    int32_t v1[B], v2[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+        const int32_t s = s0 + f0 + j;
+        const bool ok = s < k;  // wave-uniform
+        const Rsrc row = make_rsrc(tape0 + (int64_t)(ok ? s : 0) * 2 * n, ok ? n32 * 8u : 0u);
+        v1[j] = P1 ? (int32_t)__builtin_amdgcn_raw_buffer_load_b32(row, voff, 0, PZ_TAPE_AUX) : 0;
+        v2[j] = P2 ? (int32_t)__builtin_amdgcn_raw_buffer_load_b32(row, voff + n32 * 4u, 0, PZ_TAPE_AUX) : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+        if (P1) parked[((f0 + j) * 2 + 0) * kLanes + lane] = (unsigned char)v1[j];
+        if (P2) parked[((f0 + j) * 2 + 1) * kLanes + lane] = (unsigned char)v2[j];
+    }
+}
+
+// One chunk (frames s0 .. s0 + kTapeChunk - 1, as far as the launch goes).  FIRST: the launch's first chunk, requested
+// behind the state loads with 32 rows in flight per batch (nothing else is live yet); a refill inside the frame loop
+// keeps to kTapeBatch registers per player.
+template <bool FIRST, bool P1, bool P2>
+__device__ __forceinline__ void park_tape_chunk(const int32_t* tape0, int64_t n, uint32_t n32, int32_t k, int32_t s0,
+                                                uint32_t voff, unsigned char* __restrict__ parked, int lane)
+{
+    constexpr int B = FIRST ? 32 : kTapeBatch;
+    static_assert(kTapeChunk % B == 0, "whole batches");
+#pragma unroll 1
+    for (int f0 = 0; f0 < kTapeChunk && s0 + f0 < k; f0 += B)
+        park_tape_rows<B, P1, P2>(tape0, n, n32, k, s0, f0, voff, parked, lane);
+}
 
 // The reward pipeline of one frame (see pz_config in the header): the reference's wrapper
 // stack RewardInNormalState / RewardByBallPosition in either order, fused.
@@ -705,20 +776,21 @@ struct TrajOut {
         obs2 += obs_frame_bytes;
     }
     // rewards, flag, (rollout) the actions taken; both agents' rows into LDS
+    template <int SMALL_AUX>
     __device__ __forceinline__ void stage(const StepArgs& a, const Game& g, const Rewards& r, bool as_float, bool live,
                                           int a1, int a2, bool with_actions, int lane,
                                           int32_t (*lds_obs)[kLanes * PZ_OBS_DIM])
     {
         if (with_actions) {
             const Rsrc ao = make_rsrc(act, n32 * 8u);
-            __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a1, ao, voff, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, voff, n32 * 4u, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a1, ao, voff, 0, SMALL_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, voff, n32 * 4u, SMALL_AUX);
         }
         __builtin_amdgcn_raw_buffer_store_b32(as_float ? __float_as_uint(r.f1) : (unsigned int)r.i1,
-                                              make_rsrc(rew1, n32 * 4u), voff, 0, 0);
+                                              make_rsrc(rew1, n32 * 4u), voff, 0, SMALL_AUX);
         __builtin_amdgcn_raw_buffer_store_b32(as_float ? __float_as_uint(r.f2) : (unsigned int)r.i2,
-                                              make_rsrc(rew2, n32 * 4u), voff, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, make_rsrc(term, n32), ioff, 0, 0);
+                                              make_rsrc(rew2, n32 * 4u), voff, 0, SMALL_AUX);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, make_rsrc(term, n32), ioff, 0, SMALL_AUX);
         if (live) stage_obs(g, lds_obs[0], lds_obs[1], lane, a.cfg.normalize_obs == 1);
         // the rows are read back by this wave only: its LDS instructions execute in issue order
         wave_lds_handover<false>();
@@ -750,10 +822,10 @@ struct TrajOut {
             const Rsrc s1 = make_rsrc(obs1, obs_span_bytes), s2 = make_rsrc(obs2, obs_span_bytes);
 #pragma unroll
             for (int pass = 0; pass < 9; ++pass)
-                __builtin_amdgcn_raw_buffer_store_b128(p1[pass], s1, piece_off[pass], 0, PZ_OBS_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(p1[pass], s1, piece_off[pass], 0, PZ_TRAJ_AUX);
 #pragma unroll
             for (int pass = 0; pass < 9; ++pass)
-                __builtin_amdgcn_raw_buffer_store_b128(p2[pass], s2, piece_off[pass], 0, PZ_OBS_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(p2[pass], s2, piece_off[pass], 0, PZ_TRAJ_AUX);
         }
     }
     // one tensor's pieces requested from LDS at once (36 VGPRs), `between()`, their stores back to back
@@ -774,7 +846,7 @@ struct TrajOut {
             for (int pass = 0; pass < 5; ++pass) {
                 const u32x4 w = {(lo[pass].x & 0xFFFFu) | (lo[pass].y << 16), (lo[pass].z & 0xFFFFu) | (lo[pass].w << 16),
                                  (hi[pass].x & 0xFFFFu) | (hi[pass].y << 16), (hi[pass].z & 0xFFFFu) | (hi[pass].w << 16)};
-                __builtin_amdgcn_raw_buffer_store_b128(w, span, piece_off[pass], 0, PZ_OBS_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(w, span, piece_off[pass], 0, PZ_TRAJ_AUX);
             }
         } else {
             u32x4 piece[9];
@@ -784,7 +856,7 @@ struct TrajOut {
             const Rsrc span = make_rsrc(slab, obs_span_bytes);
 #pragma unroll
             for (int pass = 0; pass < 9; ++pass)
-                __builtin_amdgcn_raw_buffer_store_b128(piece[pass], span, piece_off[pass], 0, PZ_OBS_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(piece[pass], span, piece_off[pass], 0, PZ_TRAJ_AUX);
         }
     }
     static constexpr int kStores = OBS16 ? 10 : 18;  // row stores per frame
@@ -893,7 +965,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
     static_assert(SCOUT == kNoScout || ((AI1 || AI2) && (MODE == kActions) == (SCOUT == kScoutLoads)),
                   "kScoutLoads serves the single-frame AI launch, kScoutPosted the k-frame ones");
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
-    __shared__ int32_t tape_lds[MODE == kTape ? kTapeChunk * 2 * kLanes : 1];  // parked action tape (kTape only)
+    __shared__ int32_t tape_lds[MODE == kTape ? kTapeWords : 1];  // parked action tape (kTape only)
     __shared__ int32_t cand[SCOUT != kNoScout ? kLanes * kCandPitch : 1];
     __shared__ int32_t hits[SCOUT == kScoutLoads ? kLanes * kHitPitch : 1];
     __shared__ int32_t posts[SCOUT == kScoutPosted ? kLanes * kPostPitch : 1];
@@ -968,16 +1040,12 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
     // frame's stores; LDS reads only touch lgkmcnt.  The FIRST chunk is requested here, behind the state loads: its
     // latency is theirs.  (Requesting a chunk half a chunk ahead into registers was tried: the loads pending around the
     // loop's back edge make the compiler wait at every copy of those registers, every frame.)
-    auto fetch_tape_chunk = [&](int32_t s0) {
-        const int frames = min(kTapeChunk, a.k - s0);
-        for (int f = 0; f < frames; ++f) {  // rows past n read as 0 through the range check
-            const Rsrc tape = make_rsrc(a.act_p1 + (int64_t)(s0 + f) * 2 * a.n, n32 * 8u);
-            tape_lds[(f * 2 + 0) * kLanes + lane] = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, 0, 0);
-            tape_lds[(f * 2 + 1) * kLanes + lane] = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, n32 * 4u, 0);
-        }
-        wave_lds_handover<SCOUT == kNoScout>();  // every lane reads back its own words only
+    unsigned char* const parked = reinterpret_cast<unsigned char*>(tape_lds);
+    auto fetch_tape_chunk = [&](int32_t s0, auto first) {  // (games past n read as 0 through the range check)
+        park_tape_chunk<decltype(first)::value, true, true>(a.act_p1, a.n, n32, a.k, s0, io.voff, parked, lane);
+        wave_lds_handover<SCOUT == kNoScout>();  // every lane reads back its own bytes only
     };
-    if (MODE == kTape) fetch_tape_chunk(0);
+    if (MODE == kTape) fetch_tape_chunk(0, std::true_type{});
     const Game loaded = g;  // SPARSE: what the columns held before the frame
     PZ_DRAIN_VMEM();
     PZ_STAMP(1);
@@ -1013,9 +1081,9 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
         for (int32_t s = 0; s < a.k; ++s) {
             if (MODE == kTape) {
                 const int slot = s % kTapeChunk;
-                if (slot == 0 && s != 0) fetch_tape_chunk(s);
-                a1 = tape_lds[(slot * 2 + 0) * kLanes + lane];
-                a2 = tape_lds[(slot * 2 + 1) * kLanes + lane];
+                if (slot == 0 && s != 0) fetch_tape_chunk(s, std::false_type{});
+                a1 = parked[(slot * 2 + 0) * kLanes + lane];
+                a2 = parked[(slot * 2 + 1) * kLanes + lane];
             }
 #ifdef PZ_PREDICT_EVERY_HIT
             const bool last_frame = true;
@@ -1041,7 +1109,8 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
                 }
             };
             if (kTraj) {
-                out.stage(a, g, rw, as_float, live, a1, a2, MODE == kRollout && a.act_out != nullptr, lane, lds_obs);
+                out.template stage<traj_small_aux(AI1 || AI2)>(a, g, rw, as_float, live, a1, a2, MODE == kRollout && a.act_out != nullptr, lane,
+                                                               lds_obs);
                 next_head();
                 out.flush(lds_obs, lane, next_policy);
                 out.advance();
@@ -1116,6 +1185,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     const RngId id = make_rng_id(a.cfg, live ? i : 0);
     const FlightLut lut = make_lut(a.tables);
     PZ_PAIR_STAMP(ROLE, 0);
+    PZ_PAIR_WHERE(ROLE);
     int a1 = 0, a2 = 0;
     if (!RANDOM) {
         a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.voff, 0, 0);
@@ -1421,15 +1491,12 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
     // pz_step_many: every wave parks its own player's row of kTapeChunk frames in LDS (the computer's wave fetching both
     // -- it has no stores the wait would drain -- was slower: 4.31 vs 4.12 us per frame); the first chunk behind the
     // state loads, its latency is theirs
-    auto fetch_tape_chunk = [&](int32_t s0) {
-        const int frames = min(kTapeChunk, a.k - s0);
-        for (int f = 0; f < frames; ++f) {  // rows past n read as 0 through the range check
-            const Rsrc tape = make_rsrc(a.act_p1 + ((int64_t)(s0 + f) * 2 + ROLE) * a.n, n32 * 4u);
-            tape_lds[(f * 2 + ROLE) * kLanes + lane] = (int)__builtin_amdgcn_raw_buffer_load_b32(tape, io.voff, 0, 0);
-        }
+    unsigned char* const parked = reinterpret_cast<unsigned char*>(tape_lds);
+    auto fetch_tape_chunk = [&](int32_t s0, auto first) {  // (games past n read as 0 through the range check)
+        park_tape_chunk<decltype(first)::value, ROLE == 0, ROLE == 1>(a.act_p1, a.n, n32, a.k, s0, io.voff, parked, lane);
         __syncthreads();
     };
-    if (MODE == kTape) fetch_tape_chunk(0);
+    if (MODE == kTape) fetch_tape_chunk(0, std::true_type{});
     __builtin_amdgcn_s_waitcnt(0x0F70);  // every state load lands before the frame loop (see step_kernel)
     bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
@@ -1440,9 +1507,9 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         if (MODE == kTape) {
             // (both waves read frame s - 1's actions before that frame's exchange barrier: nobody needs the old chunk here)
             const int slot = s % kTapeChunk;
-            if (slot == 0 && s != 0) fetch_tape_chunk(s);
-            a1 = tape_lds[(slot * 2 + 0) * kLanes + lane];
-            a2 = tape_lds[(slot * 2 + 1) * kLanes + lane];
+            if (slot == 0 && s != 0) fetch_tape_chunk(s, std::false_type{});
+            a1 = parked[(slot * 2 + 0) * kLanes + lane];
+            a2 = parked[(slot * 2 + 1) * kLanes + lane];
         }
         const bool last_frame = s == a.k - 1;
         const bool frozen = head.frozen;
@@ -1458,17 +1525,17 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         if (!kWritesNone) {
             if (kWritesAll || ROLE == 0) {
                 __builtin_amdgcn_raw_buffer_store_b32(as_float ? __float_as_uint(rw.f1) : (unsigned int)rw.i1,
-                                                      make_rsrc(out.rew1, n32 * 4u), out.voff, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, make_rsrc(out.term, n32), out.ioff, 0, 0);
+                                                      make_rsrc(out.rew1, n32 * 4u), out.voff, 0, traj_small_aux(AI1 || AI2));
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, make_rsrc(out.term, n32), out.ioff, 0, traj_small_aux(AI1 || AI2));
                 if (MODE == kRollout && a.act_out != nullptr) {
                     const Rsrc ao = make_rsrc(out.act, n32 * 8u);
-                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a1, ao, out.voff, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, out.voff, n32 * 4u, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a1, ao, out.voff, 0, traj_small_aux(AI1 || AI2));
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)a2, ao, out.voff, n32 * 4u, traj_small_aux(AI1 || AI2));
                 }
             }
             if (kWritesAll || ROLE == 1)
                 __builtin_amdgcn_raw_buffer_store_b32(as_float ? __float_as_uint(rw.f2) : (unsigned int)rw.i2,
-                                                      make_rsrc(out.rew2, n32 * 4u), out.voff, 0, 0);
+                                                      make_rsrc(out.rew2, n32 * 4u), out.voff, 0, traj_small_aux(AI1 || AI2));
             if (live) {
                 if (kWritesAll) {
                     stage_obs(g, lds_obs[0], lds_obs[1], lane, a.cfg.normalize_obs == 1);
@@ -1547,7 +1614,7 @@ void rollout_pair_kernel(PZ_HOT_PARAMS, const StepArgs a)
     const HotArgs hot{state, n, stride, act_p1, act_p2};
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     __shared__ int32_t xchg[kLoopXchgWords];  // the players' exchange: LDS of its own, double-buffered by frame parity
-    __shared__ int32_t tape_lds[MODE == kTape ? kTapeChunk * 2 * kLanes : 1];  // parked action tape (kTape only)
+    __shared__ int32_t tape_lds[MODE == kTape ? kTapeWords : 1];  // parked action tape (kTape only)
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & (kLanes - 1);
     if (role == 0)
@@ -1676,7 +1743,7 @@ __global__ __launch_bounds__(64) void probe_write_kernel(char* a, char* b, int32
             for (int pass = 0; pass < 9; ++pass) {
                 const uint32_t v = (uint32_t)(pass * 64 + lane);
                 const u32x4 w = {(uint32_t)f, v, (uint32_t)side, 0u};
-                __builtin_amdgcn_raw_buffer_store_b128(w, span, v * 16u, 0, PZ_OBS_AUX);  // beyond the span: dropped
+                __builtin_amdgcn_raw_buffer_store_b128(w, span, v * 16u, 0, PZ_TRAJ_AUX);  // beyond the span: dropped
             }
         }
     }

@@ -127,7 +127,9 @@ def main():
         t_rew = [torch.zeros((k, n), dtype=torch.int32, device=dev) for _ in range(2)]
         t_term = torch.zeros((k, n), dtype=torch.uint8, device=dev)
         t_act = torch.zeros((k, 2, n), dtype=torch.int32, device=dev)
-        tapes = torch.randint(0, 13 if wrappers else 18, (16, k, 2, n), dtype=torch.int32, device=dev) if tape else None
+        # --tapes N: distinct tapes cycled through (default 16 = 268 MB at k = 32: streamed from HBM; 1 = cache-resident)
+        n_tapes = int(args[args.index("--tapes") + 1]) if "--tapes" in args else 16
+        tapes = torch.randint(0, 13 if wrappers else 18, (n_tapes, k, 2, n), dtype=torch.int32, device=dev) if tape else None
 
     def run(nm, steps):
         lib = libs[nm]
@@ -138,7 +140,7 @@ def main():
         if rollout:
             for j in range(max(1, steps // rollout)):
                 if tape:
-                    rc = lib.pz_step_many(state.data_ptr(), n, n, C.byref(cfg), tapes[j % 16].data_ptr(), rollout,
+                    rc = lib.pz_step_many(state.data_ptr(), n, n, C.byref(cfg), tapes[j % n_tapes].data_ptr(), rollout,
                                           t_obs[0].data_ptr(), t_obs[1].data_ptr(), t_rew[0].data_ptr(), t_rew[1].data_ptr(),
                                           t_term.data_ptr(), None, None, tb, stream)
                     assert rc == 0, rc

@@ -93,6 +93,37 @@ def main():
             for role in (0, 1):
                 dr = d[role::2]
                 print(f"    wave of player {role + 1} (median): " + ", ".join(f"{names[k + 1]} {np.median(dr[:, k]):.2f}" for k in range(6)))
+        if pair and "--where" in args:
+            # which waves share a SIMD (HW_ID / XCC_ID of every wave, slot 7), and what that does to the frame
+            where = buf.reshape(8192, 8)[:waves, 7].astype(np.uint64)
+            hw, xcc = (where & np.uint64(0xFFFFFFFF)).astype(np.int64), (where >> np.uint64(32)).astype(np.int64) & 0xF
+            simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
+            home = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+            cuid = home // 4
+            roles = np.arange(waves) % 2
+            frame = rel[:, 2] - rel[:, 1]  # loaded -> computed
+            import collections
+            by_home = collections.defaultdict(list)
+            for w in range(waves):
+                by_home[int(home[w])].append(w)
+            comp = collections.Counter(tuple(sorted(int(roles[w]) for w in ws)) for ws in by_home.values())
+            print(f"    SIMDs in use {len(by_home)}, CUs {len(set(cuid.tolist()))}, XCCs {len(set(xcc.tolist()))}; "
+                  f"roles sharing a SIMD: {dict(comp)}")
+            same_wg = sum(1 for ws in by_home.values() for a in ws for b in ws if a < b and a // 2 == b // 2)
+            print(f"    pairs of one workgroup on one SIMD: {same_wg}")
+            stats = collections.defaultdict(list)
+            for ws in by_home.values():
+                for w in ws:
+                    mates = tuple(sorted(int(roles[v]) for v in ws if v != w))
+                    stats[(int(roles[w]), mates)].append(frame[w])
+            for key in sorted(stats):
+                v = np.array(stats[key])
+                print(f"    role {key[0]} with SIMD mates {key[1]}: {len(v):5d} waves, loaded->computed median {np.median(v):5.2f} "
+                      f"p95 {np.percentile(v, 95):5.2f} max {v.max():5.2f} us")
+            wg_cu = collections.Counter(int(cuid[2 * g]) for g in range(waves // 2))
+            print(f"    workgroups per CU: {dict(collections.Counter(wg_cu.values()))}")
+            sample = [(g, int(xcc[2 * g]), int(se[2 * g]), int(cu[2 * g]), int(simd[2 * g]), int(simd[2 * g + 1])) for g in range(24)]
+            print("    first workgroups (wg, xcc, se, cu, simd of wave 0, simd of wave 1): " + " ".join(map(str, sample)))
         fb = np.zeros(8192 * 8, np.uint64)
         lib.pz_debug_read_frame_stamps.argtypes = [P, C.c_int64]
         assert lib.pz_debug_read_frame_stamps(fb.ctypes.data, 8192 * 8) == 0
