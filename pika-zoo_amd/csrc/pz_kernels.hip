@@ -1181,6 +1181,10 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     const StatsIO sio = make_stats_io(a.episode_stats, with_stats, a.stride, i);
     constexpr int kOwn = ROLE * PZ_P_WORDS, kOther = (1 - ROLE) * PZ_P_WORDS;
 
+    // One computer player: its wave is the one the launch waits for, and it shares its SIMD with the human player's
+    // wave of another workgroup, which has time to spare at its exchange barrier -- let the computer's wave issue first
+    // (interleaved A/B: config 3 8.87 -> 8.67 us per launch, packed 7.63 -> 7.39; priority 3 the same)
+    if (kOwnAI && (AI1 != AI2)) __builtin_amdgcn_s_setprio(1);
     Game g{};
     const RngId id = make_rng_id(a.cfg, live ? i : 0);
     const FlightLut lut = make_lut(a.tables);
@@ -1428,6 +1432,9 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
     const bool with_stats = ROLE == 0 && a.episode_stats != nullptr && a.cfg.episode_stats_mode != 0;
     const StatsIO sio = make_stats_io(a.episode_stats, with_stats, a.stride, i);
 
+    // (as in the single-frame pair kernel: the computer's wave is every frame's critical path; pz_rollout_random at
+    // k = 32 3.12-3.25 -> 2.99-3.01 us per frame in the same position of the interleaved rounds, k = 128 3.09 -> 2.79)
+    if (kOwnAI && (AI1 != AI2)) __builtin_amdgcn_s_setprio(1);
     Game g{};
     RngId id = make_rng_id(a.cfg, live ? i : 0);
     id.ks = make_parked_schedule(a.cfg.seed);  // the frame loop's key schedules live in VGPRs (KeySchedule)
@@ -1743,7 +1750,8 @@ __global__ __launch_bounds__(64) void probe_write_kernel(char* a, char* b, int32
             for (int pass = 0; pass < 9; ++pass) {
                 const uint32_t v = (uint32_t)(pass * 64 + lane);
                 const u32x4 w = {(uint32_t)f, v, (uint32_t)side, 0u};
-                __builtin_amdgcn_raw_buffer_store_b128(w, span, v * 16u, 0, PZ_TRAJ_AUX);  // beyond the span: dropped
+                // (nt, the policy placement.py's thresholds were measured with -- not the k-frame launches' PZ_TRAJ_AUX)
+                __builtin_amdgcn_raw_buffer_store_b128(w, span, v * 16u, 0, PZ_OBS_AUX);  // beyond the span: dropped
             }
         }
     }
