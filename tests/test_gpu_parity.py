@@ -613,6 +613,47 @@ def test_step_many_equals_single_steps(oracle):
 
 
 @pytest.mark.parametrize("fmt", ["int32", "packed"])
+@pytest.mark.parametrize("variant", ["human", "p2_computer", "both_computer", "int16_rows", "p2_computer_computed"])
+def test_step_many_refills_its_parked_tape(variant, fmt, oracle):
+    """pz_step_many parks its tape in LDS 64 frames at a time, one byte per action: launches of k = 150 (two refills, the
+    last chunk 22 frames = one whole batch of rows and a partial one), k = 64 (exactly one chunk) and k = 65 (a one-frame
+    refill), every action 0..17 on the tape, a ragged batch -- every frame's outputs and the state after every launch
+    against the oracle; in each of the kernels that fetch a tape (one wave per 64 games; two waves with a computer
+    player, with two, and with int16 rows; the scout-wave launch without flight tables)."""
+    n = 64 * 5 + 24  # (int16 rows want a multiple of eight games)
+    kw = dict(num_envs=n, seed=77, env_id_base=5, state_format=fmt, winning_score=2)
+    okw = dict(seed=77, env_id_base=5, winning_score=2)
+    if variant in ("p2_computer", "p2_computer_computed", "both_computer"):
+        kw.update(is_player2_computer=True), okw.update(is_player2_computer=True)
+    if variant == "both_computer":
+        kw.update(is_player1_computer=True), okw.update(is_player1_computer=True)
+    if variant == "p2_computer_computed":
+        kw.update(flight_tables=False)
+    if variant == "int16_rows":
+        kw.update(observation_dtype=torch.int16)
+    env = make_env(**kw)
+    raw = env.unwrapped
+    env.reset()
+    ref = oracle.OracleEnv(n, oracle.make_config(**okw), nthreads=4)
+    ref.reset()
+    rng = np.random.default_rng(12)
+    for launch, k in enumerate((150, 64, 65)):
+        tape = rng.integers(0, 18, size=(k, 2, n), dtype=np.int32)
+        tape[:18, 0, 0] = np.arange(18)  # every action value on the tape for sure
+        tape[:18, 1, 1] = np.arange(18)[::-1]
+        out = raw.step_many(torch.from_numpy(tape).to(raw.device))
+        for f in range(k):
+            robs, rrew, rterm = ref.step(tape[f, 0], tape[f, 1])
+            ctx = (variant, fmt, launch, f)
+            assert np.array_equal(cpu(out["obs"]["player_1"][f]).astype(np.int32), robs[0]), ctx
+            assert np.array_equal(cpu(out["obs"]["player_2"][f]).astype(np.int32), robs[1]), ctx
+            assert np.array_equal(cpu(out["rewards"]["player_1"][f]), rrew[0]), ctx
+            assert np.array_equal(cpu(out["rewards"]["player_2"][f]), rrew[1]), ctx
+            assert np.array_equal(cpu(out["terminations"][f]).astype(np.uint8), rterm), ctx
+        assert np.array_equal(cpu(raw.state), ref.state), (variant, fmt, launch)
+
+
+@pytest.mark.parametrize("fmt", ["int32", "packed"])
 def test_large_batch_offsets(fmt, oracle):
     """2^24 games in one launch (3 GB of state -- 0.6 GB packed --, 2 x 2.3 GB of observations): the 32-bit buffer
     offsets near their upper range, through pz_step_random and pz_step (single-wave kernel / packed pair kernel),
