@@ -1181,6 +1181,12 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     const StatsIO sio = make_stats_io(a.episode_stats, with_stats, a.stride, i);
     constexpr int kOwn = ROLE * PZ_P_WORDS, kOther = (1 - ROLE) * PZ_P_WORDS;
 
+    // Packed state, human vs human: every other workgroup issues at priority 1.  The two waves of a SIMD belong to two
+    // workgroups and compete for its VALU through the whole frame (packing and unpacking make this the format with the
+    // most VALU work per byte moved); with one of them preferred, half of the launch's workgroups reach their stores
+    // earlier and the write drain starts earlier: 6.36 -> 6.11 us per launch, 524 288 games 31.7 -> 31.2, with int16
+    // rows 5.61 -> 5.46 / 23.7 -> 22.8.  The int32 columns do not care (6.996 vs 7.010; by role: 7.25-7.52).
+    if (PACKED && !AI1 && !AI2 && (blockIdx.x & 1u) != 0) __builtin_amdgcn_s_setprio(1);
     // One computer player: its wave is the one the launch waits for, and it shares its SIMD with the human player's
     // wave of another workgroup, which has time to spare at its exchange barrier -- let the computer's wave issue first
     // (interleaved A/B: config 3 8.87 -> 8.67 us per launch, packed 7.63 -> 7.39; priority 3 the same)
