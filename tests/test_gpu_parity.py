@@ -747,8 +747,40 @@ def test_randomized_config_sweep_vs_oracle(oracle):
         aseed = rnd.getrandbits(64)
         t = 0
         for phase in range(4):
-            mode = rnd.choice(["step", "random", "random_k"])
-            if mode == "step":
+            # (the trajectory launches want a multiple of four games)
+            mode = rnd.choice(["step", "random", "random_k"] + (["tape", "rollout"] if n % 4 == 0 else []))
+            if mode in ("tape", "rollout"):
+                # pz_step_many / pz_rollout_random: every frame's outputs against the oracle's frame; k on both sides of
+                # the tape's 64-frame chunk
+                kk = rnd.choice([2, 7, 33, 64, 65, 130])
+                t_obs = [torch.full((kk, n, 35), -7, dtype=torch.int32, device=dev) for _ in range(2)]
+                t_rew = [torch.full((kk, n), -7, dtype=torch.int32, device=dev) for _ in range(2)]
+                t_term = torch.full((kk, n), 9, dtype=torch.uint8, device=dev)
+                acts = [oracle.random_actions(n, k["env_id_base"], aseed, t + f, n_act) for f in range(kk)]
+                tape = torch.from_numpy(np.stack([np.stack(a) for a in acts]).astype(np.int32)).to(dev)
+                if mode == "tape":
+                    assert lib.pz_step_many(state.data_ptr(), n, stride, C.byref(cfg), tape.data_ptr(), kk,
+                                            t_obs[0].data_ptr(), t_obs[1].data_ptr(), t_rew[0].data_ptr(),
+                                            t_rew[1].data_ptr(), t_term.data_ptr(), sp, None, tb, stream) == 0
+                else:
+                    t_act = torch.full((kk, 2, n), -7, dtype=torch.int32, device=dev)
+                    assert lib.pz_rollout_random(state.data_ptr(), n, stride, C.byref(cfg), aseed, t, kk, t_act.data_ptr(),
+                                                 t_obs[0].data_ptr(), t_obs[1].data_ptr(), t_rew[0].data_ptr(),
+                                                 t_rew[1].data_ptr(), t_term.data_ptr(), sp, None, tb, stream) == 0
+                    assert torch.equal(t_act, tape), (trial, phase, mode)
+                h_obs, h_rew, h_term = [cpu(x) for x in t_obs], [cpu(x) for x in t_rew], cpu(t_term)
+                for f in range(kk):
+                    robs, rrew, rterm = ref.step(*acts[f])
+                    ctx = (trial, phase, mode, kk, f, n, stride, tb is not None, packed, k)
+                    assert np.array_equal(h_obs[0][f], robs[0].view(np.int32)), ctx
+                    assert np.array_equal(h_obs[1][f], robs[1].view(np.int32)), ctx
+                    assert np.array_equal(h_rew[0][f], rrew[0].view(np.int32)), ctx
+                    assert np.array_equal(h_rew[1][f], rrew[1].view(np.int32)), ctx
+                    assert np.array_equal(h_term[f], rterm), ctx
+                for dst, src in ((obs[0], t_obs[0]), (obs[1], t_obs[1]), (rew[0], t_rew[0]), (rew[1], t_rew[1]), (term, t_term)):
+                    dst.copy_(src[-1])  # the single-frame buffers of this test follow the last frame
+                t += kk
+            elif mode == "step":
                 for _ in range(15):
                     a1, a2 = oracle.random_actions(n, k["env_id_base"], aseed, t, n_act)
                     d1, d2 = torch.as_tensor(a1, device=dev), torch.as_tensor(a2, device=dev)
