@@ -1337,8 +1337,17 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
                 own.bold = keep;
                 bold_pending = true;
             } else {
-                uint32_t own_draw = g.e.rng + (uint32_t)ROLE;
-                player_new_round(own, ROLE == 0 ? 36 : kGroundWidth - 36, id, own_draw);
+#ifdef PZ_CT_ABLATE
+                if (PZ_CT_ABLATE & 16) {
+                    const int keep = own.bold;
+                    player_new_round_undrawn(own, ROLE == 0 ? 36 : kGroundWidth - 36);
+                    own.bold = keep;
+                } else
+#endif
+                {
+                    uint32_t own_draw = g.e.rng + (uint32_t)ROLE;
+                    player_new_round(own, ROLE == 0 ? 36 : kGroundWidth - 36, id, own_draw);
+                }
             }
             other.x = ROLE == 0 ? kGroundWidth - 36 : 36;
             other.y = kPlayerGroundY;
@@ -1384,9 +1393,22 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             const bool scan = power_hit_scan_needed(own, g.b);
             const int ayv = abs(g.b.yv);
             int ex[6] = {0, 0, 0, 0, 0, 0};
+#ifdef PZ_CT_ABLATE
+            // Timing-only variants decided at COMPILE time (tools/ab.py with -DPZ_CT_ABLATE=bits; results are wrong by
+            // construction): 1 no pre-drawn Philox words, 2 no landing look-up, 4 no candidate look-up, 8 no decision,
+            // 16 no boldness draw at a round start, 32 no look-up after a collision.  (The run-time hooks of PZ_ABLATE read
+            // their bits from memory in front of every part they guard, which costs more than most of the parts.)
+            LandingProbe lp = (PZ_CT_ABLATE & 2) ? LandingProbe{false, false, 0u, (uint32_t)g.b.x}
+                                                 : lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv);
+            CandidateProbe cp = (PZ_CT_ABLATE & 4) ? CandidateProbe{false, false, lut_u32x4{(uint32_t)g.b.x, (uint32_t)g.b.y, 7u, 0u}}
+                                                   : lut.candidates_issue(scan, g.b.x, g.b.y, ayv);
+            PreDrawn pre = (PZ_CT_ABLATE & 1) ? PreDrawn{(uint32_t)g.b.x * 2654435761u, (uint32_t)g.b.y * 2654435761u, 1u}
+                                              : predraw3(id, rng_base + draws_other);
+#else
             LandingProbe lp = lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv);
             CandidateProbe cp = lut.candidates_issue(scan && !PZ_ABLATE_SKIP(64), g.b.x, g.b.y, ayv);
             PreDrawn pre = PZ_ABLATE_SKIP(256) ? PreDrawn{1u, 1u, 1u} : predraw3(id, rng_base + draws_other);
+#endif
             // Keep the Philox blocks where they are written -- under the two gathers.  Left alone the compiler sinks
             // them below the (rare) out-of-domain branches of the look-ups and waits for the gathers first.  The empty
             // statement reads the draws together with the gathered registers: the draws must be complete before it,
@@ -1401,6 +1423,11 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             }
             g.b.ex = PZ_ABLATE_SKIP(32) ? g.b.x : lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, 0);
             lut.candidates_finish(cp, g.b.x, g.b.y, ayv, ex);
+#ifdef PZ_CT_ABLATE
+            if (PZ_CT_ABLATE & 8) {  // no decision: the decoded action stands, the inputs are kept alive
+                in_own.xd = (int)((pre.w0 ^ pre.w1 ^ pre.w2 ^ (uint32_t)(ex[0] + ex[5] + g.b.ex)) & 1u);
+            } else
+#endif
             if (!PZ_ABLATE_SKIP(512))
                 draws_own = computer_decide_predrawn<ROLE == 1>(own, g.b, other.x, pre, scan, ex, in_own);
         }
@@ -1481,7 +1508,11 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     // :331-332 -- predicted again after a processed collision (one evaluation after both collisions leaves what
     // the second of two would).  Nothing in the frame reads it any more: the gather is issued here and taken
     // by the caller behind its other stores (`after_hit`).
+#ifdef PZ_CT_ABLATE
+    if (kKeepsEx && !(PZ_CT_ABLATE & 32)) after_hit = lut.landing_issue(hit_processed, g.b.x, g.b.y, g.b.xv, g.b.yv);
+#else
     if (kKeepsEx) after_hit = lut.landing_issue(hit_processed, g.b.x, g.b.y, g.b.xv, g.b.yv);
+#endif
     PZ_FRAME_STAMP(7);
     return reward;
 }
