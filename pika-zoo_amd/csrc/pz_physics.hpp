@@ -1308,6 +1308,8 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     const bool active = live && !frozen;
     Input in1{0, 0, 0}, in2{0, 0, 0};
     bool ground = false;
+    bool bold_late = false;       // the computer's round-start boldness, drawn behind the gathers' issue
+    uint32_t bold_counter = 0u;
     PZ_FRAME_STAMP(0);
     if (active) {
         if (g.e.round_ended) {  // reset (:149-164) or new round (:176-180); game_ended implies round_ended
@@ -1345,8 +1347,19 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
                 } else
 #endif
                 {
-                    uint32_t own_draw = g.e.rng + (uint32_t)ROLE;
-                    player_new_round(own, ROLE == 0 ? 36 : kGroundWidth - 36, id, own_draw);
+                    if (kOwnAI) {
+                        // the computer's own boldness is read by its decision only: drawn behind the issue of the frame's
+                        // two gathers, whose latency has room for a fourth Philox block (8.62 -> 8.53 us per launch, packed
+                        // 7.46 -> 7.32, with the computer's wave at priority 1; without it, round 2: 8.39 -> 8.48)
+                        const int keep = own.bold;
+                        player_new_round_undrawn(own, ROLE == 0 ? 36 : kGroundWidth - 36);
+                        own.bold = keep;
+                        bold_late = true;
+                        bold_counter = g.e.rng + (uint32_t)ROLE;
+                    } else {
+                        uint32_t own_draw = g.e.rng + (uint32_t)ROLE;
+                        player_new_round(own, ROLE == 0 ? 36 : kGroundWidth - 36, id, own_draw);
+                    }
                 }
             }
             other.x = ROLE == 0 ? kGroundWidth - 36 : 36;
@@ -1409,6 +1422,10 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             CandidateProbe cp = lut.candidates_issue(scan && !PZ_ABLATE_SKIP(64), g.b.x, g.b.y, ayv);
             PreDrawn pre = PZ_ABLATE_SKIP(256) ? PreDrawn{1u, 1u, 1u} : predraw3(id, rng_base + draws_other);
 #endif
+            if (__builtin_amdgcn_ballot_w64(bold_late) != 0ull) {  // (wave-uniform: a lane of the wave starts a round)
+                const int drawn = rng_integers(id, bold_counter, 5u);
+                own.bold = bold_late ? drawn : own.bold;
+            }
             // Keep the Philox blocks where they are written -- under the two gathers.  Left alone the compiler sinks
             // them below the (rare) out-of-domain branches of the look-ups and waits for the gathers first.  The empty
             // statement reads the draws together with the gathered registers: the draws must be complete before it,
