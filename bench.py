@@ -409,10 +409,12 @@ def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_t
         stream.synchronize()
         est = time.perf_counter() - t0
         reps = max(1, math.ceil(min_time / max(est, 1e-6)))
+        lead_in = 0
         if p2_computer or args.p1_computer:
             # a launch that gathers from the flight tables settles over its first ~100 ms of back-to-back launches (the
             # tables' hot lines find their way into the caches: tools/eager_vs_graph.py, 3.8 -> 3.2 us per frame): untimed
-            for _ in range(max(1, math.ceil(0.15 / max(est, 1e-6)))):
+            lead_in = max(1, math.ceil(0.15 / max(est, 1e-6)))
+            for _ in range(lead_in):
                 graph.replay()
             stream.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -441,10 +443,10 @@ def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_t
         chk.reset()
         chk.rollout_random(BURN_SEED, 0, burn)
         chk.rollout_random(ACTION_SEED, 0, k)  # the allocating launch
-        for _ in range(reps + 1):
+        for _ in range(reps + 1 + lead_in):
             for j in range(launches):  # (the tape holds the policy stream's slices j * k ..: the same actions)
                 chk.rollout_random(ACTION_SEED, j * k, k)
-        res.update(parity_lanes_checked=lanes, parity_steps_checked=burn + k + (reps + 1) * launches * k,
+        res.update(parity_lanes_checked=lanes, parity_steps_checked=burn + k + (reps + 1 + lead_in) * launches * k,
                    parity_bit_exact=bool((raw.state[:, :lanes].cpu().numpy() == chk.state).all()))
     return res
 
