@@ -1513,7 +1513,8 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
     __builtin_amdgcn_s_waitcnt(0x0F70);  // every state load lands before the frame loop (see step_kernel)
     bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
-    PairHead head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold);
+    bool ex_fresh = false;  // a computer's wave: g.b.ex is the landing point of the ball as it stands (pz_physics.hpp)
+    PairHead head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold, ex_fresh);
     // (the gathers' wait, see step_kernel's frame loop -- for a computer's wave that stores rows: with two computer players)
     if (kOwnAI && !kWritesNone) issue_dropped_stores<TrajOut<OBS16>::kStores / 2>();
     for (int32_t s = 0; s < a.k; ++s) {
@@ -1527,7 +1528,8 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         const bool last_frame = s == a.k - 1;
         const bool frozen = head.frozen;
         const int reward = pair_frame_tail<ROLE, AI1, AI2>(g, a.cfg, id, a1, a2, live, head,
-                                                           xchg + (s & 1) * (2 * kLoopXchgRegion), lane, lut, last_frame);
+                                                           xchg + (s & 1) * (2 * kLoopXchgRegion), lane, lut, last_frame,
+                                                           &ex_fresh);
         finished += (unsigned int)(live && g.e.game_ended && !frozen);
         const Rewards rw = shape_rewards(a.cfg, g, reward, frozen);
         if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
@@ -1563,7 +1565,7 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         if (s + 1 < a.k) {  // this frame's outputs are staged: the game may move on
             resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
             any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
-            head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold);
+            head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold, ex_fresh);
         }
         auto next_policy = [&]() {
             if (MODE == kRollout) policy_actions(id.id_lo, id.id_hi, policy, a.t0 + (uint64_t)s + 1u, n_actions, a1, a2);

@@ -1550,8 +1550,33 @@ constexpr int kLoopXchgEarlyAt = 10 * kXchgPitch;            // the early post {
 constexpr int kLoopXchgRegion = kLoopXchgEarlyAt + 2 * 64;   // words per region (one per wave)
 constexpr int kLoopXchgWords = 2 * 2 * kLoopXchgRegion;      // two regions, two frame parities
 
+// ---- a ball keeps its landing point along a free flight --------------------------------------------------------------
+// calculate_expected_landing_point_x_for (physics.py:643-686) iterates a copy of the ball with the statements of
+// process_collision_between_ball_and_world_and_set_ball_position (:359-431) until it would touch the ground.  So for a
+// ball B that the world step moves to W(B) without touching the ground, P(W(B)) = P(B) -- the predictor's first iteration
+// on B IS that world step -- with two exceptions: (1) over the net at y == 192 exactly the world step bounces the ball off
+// the net's top (`y <= NET_PILLAR_TOP_BOTTOM_Y_COORD`, :408) where the predictor pushes it sideways (`<`, :667); (2) P(B)
+// counts its iterations against INFINITE_LOOP_LIMIT (:33), which only a ball without x velocity bouncing on the net top
+// for ever reaches.  tools/flight_rule.c checks the statement on every one of the landing table's 4.6e8 balls against the
+// oracle's predictor (416 234 714 balls covered, no violation; 2 387 182 excluded, 155 343 of them rightly).
+// The k-frame pair kernel, which holds the ball and its last prediction in registers, looks a landing point up only for
+// the games whose flight was interrupted: a collision, a ball outside the table's domain, the launch's first frame --
+// a round that starts serves a ball without x velocity at x = 56 / 376, which comes down where it is.
+__device__ __forceinline__ bool ball_in_landing_domain(int x, int y, int xv, int yv)
+{
+    return (ft_xv_index(xv) >= 0) & ((unsigned)(x - kBallRadius) < (unsigned)kFtXCount) & ((unsigned)y < (unsigned)kFtYCount) &
+           (abs(yv) <= PZ_FT_YV_MAX);
+}
+// B = (x, y, xv) BEFORE the world step
+__device__ __forceinline__ bool flight_keeps_landing_point(int x, int y, int xv)
+{
+    const bool over_net = abs(x - kGroundHalfWidth) < kNetPillarHalfWidth;
+    return !(over_net & ((y == kNetTopBottomY) | (xv == 0)));
+}
+
 struct PairHead {
     bool frozen, ground;
+    bool known;               // own computer player: g.b.ex already is this frame's landing point (no look-up)
     uint32_t rng_base;        // the env stream's counter before this frame's decisions
     uint32_t landing_word;    // own computer player: LandingProbe::value
     lut_u32x4 candidate_row;  //                      CandidateProbe::value
@@ -1561,7 +1586,7 @@ struct PairHead {
 // DEFER_OWN: the own (human) player's boldness draw is recorded in *bold (counter1 / pending1) instead of made
 template <int ROLE, bool AI1, bool AI2, bool DEFER_OWN>
 __device__ __forceinline__ PairHead pair_frame_head(Game& g, const pz_config& cfg, const RngId& id, bool live,
-                                                    const FlightLut& lut, BoldDefer* bold)
+                                                    const FlightLut& lut, BoldDefer* bold, const bool ex_fresh = false)
 {
     constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
     static_assert(!(DEFER_OWN && kOwnAI), "a computer player reads its boldness");
@@ -1570,8 +1595,10 @@ __device__ __forceinline__ PairHead pair_frame_head(Game& g, const pz_config& cf
     PairHead h{};
     h.frozen = live && g.e.game_ended && !cfg.auto_reset;
     const bool active = live && !h.frozen;
+    bool round_began = false;
     if (active) {
         if (g.e.round_ended) {  // reset (:149-164) or new round (:176-180); game_ended implies round_ended
+            round_began = true;
             if (g.e.game_ended) {
                 g.e.game_ended = 0;
                 g.e.p2serve = 0;
@@ -1599,13 +1626,28 @@ __device__ __forceinline__ PairHead pair_frame_head(Game& g, const pz_config& cf
             g.e.rng += 2u;
             ball_new_round(g.b, get_server(cfg, g.e, id));  // a random serve is drawn by both waves
         }
+        if (kOwnAI) {
+            // ex_fresh: g.b.ex is the landing point of the ball as it stands (the last frame predicted it for its moved
+            // ball and no collision has changed the flight since)
+            h.known = round_began | (ex_fresh & ball_in_landing_domain(g.b.x, g.b.y, g.b.xv, g.b.yv) &
+                                     flight_keeps_landing_point(g.b.x, g.b.y, g.b.xv));
+            g.b.ex = round_began ? g.b.x : g.b.ex;  // (a serve has no x velocity and is not over the net)
+        }
         h.ground = ball_world_step(g.b);
+        if (kOwnAI) h.known &= !h.ground & (round_began | ball_in_landing_domain(g.b.x, g.b.y, g.b.xv, g.b.yv));
     }
     h.rng_base = g.e.rng;
     if (kOwnAI && active) {
         const bool scan = power_hit_scan_needed(own, g.b);
-        h.landing_word = lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv).value;
+#ifdef PZ_CT_ABLATE  // (timing only, see step_games_pair: 64 no landing look-up, 128 no candidate look-up in the k-frame pair kernel)
+        h.landing_word = (PZ_CT_ABLATE & 64) ? (uint32_t)g.b.x : lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv).value;
+        h.candidate_row = (PZ_CT_ABLATE & 128) ? lut_u32x4{(uint32_t)g.b.x, (uint32_t)g.b.y, 7u, 0u}
+                                               : lut.candidates_issue(scan, g.b.x, g.b.y, abs(g.b.yv)).value;
+#else
+        // (a lane that knows its landing point reads entry 0 like a lane outside the domain: a line the whole wave shares)
+        h.landing_word = lut.landing_issue(!h.known, g.b.x, g.b.y, g.b.xv, g.b.yv).value;
         h.candidate_row = lut.candidates_issue(scan, g.b.x, g.b.y, abs(g.b.yv)).value;
+#endif
         // (player 2 behind a computer player 1 learns the counter of its first draw from player 1's early post: tail)
         if (!(ROLE == 1 && AI1)) h.pre = predraw3(id, h.rng_base);
     }
@@ -1616,7 +1658,7 @@ __device__ __forceinline__ PairHead pair_frame_head(Game& g, const pz_config& cf
 template <int ROLE, bool AI1, bool AI2>
 __device__ __forceinline__ int pair_frame_tail(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
                                                PairHead& h, int32_t* __restrict__ xchg, int lane, const FlightLut& lut,
-                                               const bool last_frame)
+                                               const bool last_frame, bool* ex_fresh = nullptr)
 {
     constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
     constexpr bool kOtherAI = ROLE == 0 ? AI2 : AI1;
@@ -1661,11 +1703,11 @@ __device__ __forceinline__ int pair_frame_tail(Game& g, const pz_config& cfg, co
             other.x = (other.state == 4) ? other.x : nx;
         }
         uint32_t unused;
-        LandingProbe lp = lut.landing_locate(true, g.b.x, g.b.y, g.b.xv, g.b.yv, unused);
+        LandingProbe lp = lut.landing_locate(!h.known, g.b.x, g.b.y, g.b.xv, g.b.yv, unused);
         lp.value = h.landing_word;
         CandidateProbe cp = lut.candidates_locate(scan, g.b.x, g.b.y, ayv, unused);
         cp.value = h.candidate_row;
-        g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, 0);  // :314-315
+        g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, g.b.ex);  // :314-315 (known: it stands, see the head)
         lut.candidates_finish(cp, g.b.x, g.b.y, ayv, ex);
         draws_own = computer_decide_predrawn<ROLE == 1>(own, g.b, other.x, pre, scan, ex, in_own);
     }
@@ -1735,6 +1777,10 @@ __device__ __forceinline__ int pair_frame_tail(Game& g, const pz_config& cfg, co
         // next frame's prediction before anything reads it: evaluated on the last frame and for a game that freezes
         const bool ex_observable = last_frame | (g.e.game_ended != 0 && cfg.auto_reset == 0);
         if (kKeepsEx && (hit1 | hit2) && ex_observable) g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
+        // a processed collision has changed the flight: g.b.ex no longer belongs to the ball (pair_frame_head)
+        if (kOwnAI && ex_fresh != nullptr) *ex_fresh = !(hit1 | hit2);
+    } else if (kOwnAI && ex_fresh != nullptr) {
+        *ex_fresh = false;
     }
     return reward;
 }
