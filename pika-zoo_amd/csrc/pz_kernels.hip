@@ -535,7 +535,7 @@ __device__ unsigned long long g_pz_stamps[8192 * 8];
 //                    trajectory tensors (pz_rollout_random); the state stays in registers for
 //                    the whole launch, so per frame only the outputs move;
 //       kTape     -- the same with the actions of every frame read from an int32[k][2][n] tape
-//                    (pz_step_many), fetched 16 frames at a time into LDS.
+//                    (pz_step_many), parked in LDS one byte per action, 64 frames per fetch.
 // SPARSE: changed-only write-back of the rarely changing columns (large batches).
 enum StepMode { kActions = 0, kRandom = 1, kRollout = 2, kTape = 3 };
 #ifndef PZ_TAPE_WAVES
