@@ -1,4 +1,8 @@
-// exhaustive check of the flight-invariance rule: P(W(B)) == P(B) for every ball B of the landing table's domain
+// Test infrastructure (built and run by tests/test_oracle_golden.py::test_a_ball_keeps_its_landing_point_along_a_free_flight):
+// the statement the k-frame pair kernel's `known` landing points rest on (pz_physics.hpp, pair_frame_head), checked on EVERY
+// ball B of the landing table's domain against the oracle's predictor: if the world step (physics.py:359-431) moves B to
+// W(B) without touching the ground, then P(W(B)) == P(B) -- unless B is over the net at y == 192 or has no x velocity
+// there (flight_keeps_landing_point).   gcc -O2 -fopenmp tests/flight_rule.c oracle/pz_oracle.c -lm
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>

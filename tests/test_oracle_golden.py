@@ -343,3 +343,21 @@ def test_normalized_observation_equals_the_float64_quotient_over_extended_ranges
         o1, _ = env.observe()
         want = ((values.astype(np.int64) - int(OBS_LOW[col])) / (np.int64(OBS_HIGH[col]) - np.int64(OBS_LOW[col]))).astype(np.float32)
         assert o1.dtype == np.float32 and np.array_equal(o1[:, col], want), (col, row)
+
+
+def test_a_ball_keeps_its_landing_point_along_a_free_flight(tmp_path):
+    """The statement behind the k-frame pair kernel's `known` landing points (pz_physics.hpp: pair_frame_head,
+    flight_keeps_landing_point): for every ball B of the landing table's domain that the world step
+    (physics.py:359-431) moves to W(B) without touching the ground, the predictor (:643-686) gives P(W(B)) == P(B) --
+    unless B is over the net at y == 192 or without x velocity.  tests/flight_rule.c walks all 4.6e8 balls against the
+    oracle's predictor (a few seconds on eight threads)."""
+    import subprocess
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "flight_rule"
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-o", str(exe), str(repo / "tests" / "flight_rule.c"),
+                           str(repo / "oracle" / "pz_oracle.c"), "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "violations 0;" in out.stdout and "states 463826671" in out.stdout, out.stdout
