@@ -1558,7 +1558,7 @@ constexpr int kLoopXchgWords = 2 * 2 * kLoopXchgRegion;      // two regions, two
 // the net's top (`y <= NET_PILLAR_TOP_BOTTOM_Y_COORD`, :408) where the predictor pushes it sideways (`<`, :667); (2) P(B)
 // counts its iterations against INFINITE_LOOP_LIMIT (:33), which only a ball without x velocity bouncing on the net top
 // for ever reaches.  tests/flight_rule.c checks the statement on every one of the landing table's 4.6e8 balls against the
-// oracle's predictor (416 234 714 balls covered, no violation; 2 387 182 excluded, 155 343 of them rightly).
+// predictor's CPU restatement (416 234 714 balls covered, no violation; 2 387 182 excluded, 155 343 of them rightly).
 // The k-frame pair kernel, which holds the ball and its last prediction in registers, looks a landing point up only for
 // the games whose flight was interrupted: a collision, a ball outside the table's domain, the launch's first frame --
 // a round that starts serves a ball without x velocity at x = 56 / 376, which comes down where it is.
