@@ -112,13 +112,13 @@ def parse_args():
 
 
 def make_env(shard, device, *, num_envs, p1_computer=False, p2_computer=False, wrappers=False, flight_tables=True,
-             state_format="int32", obs16=False):
+             state_format="int32", obs16=False, validate_actions=False):
     from pikazoo_amd.wrappers import RewardByBallPosition, SimplifyAction
 
     env = pikazoo_v0.env(winning_score=15, serve="winner", is_player2_computer=p2_computer,
                          is_player1_computer=p1_computer,
                          num_envs=num_envs, device=device, seed=0, env_id_base=shard.env_id_base,
-                         auto_reset=True, validate_actions=False, flight_tables=flight_tables,
+                         auto_reset=True, validate_actions=validate_actions, flight_tables=flight_tables,
                          state_format=state_format, observation_dtype=torch.int16 if obs16 else torch.int32)
     if wrappers:
         env = SimplifyAction(env)
@@ -316,7 +316,8 @@ def cpu_baseline(args, raw_gpu, p2_computer, wrappers):
 
 
 def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=False, launch=None, steps=None,
-            warmup=None, burn=None, min_time=None, check_lanes=0, flight_tables=True, state_format="int32", obs16=False):
+            warmup=None, burn=None, min_time=None, check_lanes=0, flight_tables=True, state_format="int32", obs16=False,
+            validate_actions=False):
     num_envs = args.num_envs if num_envs is None else num_envs
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
@@ -324,7 +325,8 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     min_time = args.min_time if min_time is None else min_time
     launch = args.launch if launch is None else launch
     env = make_env(shard, device, num_envs=num_envs, p1_computer=args.p1_computer, p2_computer=p2_computer,
-                   wrappers=wrappers, flight_tables=flight_tables, state_format=state_format, obs16=obs16)
+                   wrappers=wrappers, flight_tables=flight_tables, state_format=state_format, obs16=obs16,
+                   validate_actions=validate_actions)
     raw = env.unwrapped
     env.reset()
     burn_in(raw, burn)
@@ -359,14 +361,16 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     return res
 
 
-def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_time=0.25, check_lanes=0, obs16=False):
+def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_time=0.25, check_lanes=0, obs16=False,
+                    num_envs=None):
     """pz_rollout_random (or, tape=True, pz_step_many on a pre-generated action tape): k frames per launch, every
     frame's outputs written to [k][n]... trajectory tensors (state in registers, read / written once per launch).
     Timed like the headline: the launches go through the C ABI into ONE hipGraph (>= 64 launches, each on its own
     step indices t0), one untimed replay, then R replays until the timed region lasts >= min_time; HIP events on the
     launch stream.  Algorithmic bytes per game-step of THESE kernels: 297 (8 of them the action words written resp.
     read) + 352 / k.  `check_lanes`: the first lanes' final state against the CPU oracle replaying the same launches."""
-    env = make_env(shard, device, num_envs=args.num_envs, p1_computer=args.p1_computer, p2_computer=p2_computer, obs16=obs16)
+    env = make_env(shard, device, num_envs=args.num_envs if num_envs is None else num_envs, p1_computer=args.p1_computer,
+                   p2_computer=p2_computer, obs16=obs16)
     raw = env.unwrapped
     lib = _native.load()
     env.reset()
@@ -379,8 +383,10 @@ def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_t
     # what pure stores of the launch's pattern into THESE two tensors reach (pz_probe_write: nothing in front of the stores)
     from pikazoo_amd import placement
 
-    with torch.cuda.device(device):
-        pure_store_gbps = placement.pair_write_rate(out["_obs"][0], out["_obs"][1])
+    pure_store_gbps = None  # (a tensor below one probe frame -- a small batch -- has no such figure)
+    if min(t.numel() * t.element_size() for t in out["_obs"]) >= int(lib.pz_probe_frame_bytes()):
+        with torch.cuda.device(device):
+            pure_store_gbps = placement.pair_write_rate(out["_obs"][0], out["_obs"][1])
     tapes = pregenerate_actions(raw, launches * k).view(launches, k, 2, n) if tape else None
     ptrs = (out["_obs"][0].data_ptr(), out["_obs"][1].data_ptr(), out["_rew"][0].data_ptr(), out["_rew"][1].data_ptr(),
             out["_term"].data_ptr())
@@ -431,8 +437,11 @@ def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_t
     gbps = bytes_per_step * n / (us_per_frame * 1e-6) / 1e9
     res = {"value": n * frames / wall, "us_per_frame": us_per_frame, "k": k, "launches_per_replay": launches,
            "replays": reps, "timed_frames": frames, "timed_seconds": wall, "bytes_per_game_step": bytes_per_step,
-           "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS, "regime": "hbm-streaming, write-dominated",
-           "placement": placed, "pure_store_GBps": pure_store_gbps, "frac_of_pure_stores": gbps / pure_store_gbps}
+           "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS, "regime": TRAJ_REGIME,
+           "placement": placed, "pure_store_GBps": pure_store_gbps,
+           "frac_of_pure_stores": None if pure_store_gbps is None else gbps / pure_store_gbps}
+    if n < 16384:
+        res["regime"] = "launch-latency"
     if check_lanes and not args.no_cpu:
         from oracle import pz_oracle as po
 
@@ -605,7 +614,12 @@ def regime(num_envs):
     return "infinity-cache-resident" if ws < INFINITY_CACHE_BYTES // 2 else "hbm-streaming"
 
 
+TRAJ_REGIME = "hbm-streaming, write-dominated"
 BOUND_DETAIL = {
+    TRAJ_REGIME: "k-frame launches: every frame's outputs stream to HBM (623 MB per 32-frame launch of int32 rows); "
+                 "pure_store_GBps is what the launch's store pattern alone sustains on the entry's own two observation "
+                 "tensors (pz_probe_write, >= 20 ms in this run; ~7 TB/s when they lie in different ranks of the HBM, "
+                 "5.6 when they share one: `placement`, DESIGN 4.9); int16 rows are not write-bound",
     "launch-latency": "fewer workgroups than CUs: the launch lasts as long as the dependent-launch chain "
                       "(dispatch + load latency + frame + store acknowledge), not as long as its bytes",
     "infinity-cache-resident": "working set re-touched every launch out of the 256 MiB Infinity Cache: bound by the "
@@ -623,7 +637,7 @@ def fractions(r, num_envs, key):
     reg = regime(num_envs)
     return {"frac": r["frac"], "frac_wall": r["frac_wall"], "traffic": traffic,
             "frac_traffic": (traffic / launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-            "traffic_key": key, "regime": reg, "bound_detail": BOUND_DETAIL[reg]}
+            "traffic_key": key, "regime": reg}  # (what a regime means: `roofline.regimes`, once per line)
 
 
 def config_entry(r, workload, num_envs, key):
@@ -691,8 +705,9 @@ def main():
     # every rank's own figures (a straggler GPU is invisible in the MAX-over-ranks wall clock alone)
     parity = main_res.get("parity_bit_exact")
     rows = dist.all_gather_rows([rank, main_res["launch_us"], raw_main.num_envs * main_res["timed_steps"] /
-                                 (main_res["event_ms"] * 1e-3), -1.0 if parity is None else float(parity)], device=cdev)
-    per_rank = [{"rank": int(r[0]), "launch_us": r[1], "value": r[2],
+                                 (main_res["event_ms"] * 1e-3), -1.0 if parity is None else float(parity),
+                                 raw_main.env_id_base], device=cdev)
+    per_rank = [{"rank": int(r[0]), "env_id_base": int(r[4]), "launch_us": r[1], "value": r[2],
                  "parity_bit_exact": None if r[3] < 0 else bool(r[3])} for r in rows]
     cpu = None
     if single and not args.no_cpu:
@@ -776,20 +791,17 @@ def main():
         }
         traj["rollout_k32_int16obs"] = ("pz_rollout_random, k = 32, int16 observation rows (165 B per game-step): two waves per "
                                         "64 games, each player's wave writing its agent's rows", dict(obs16=True))
+        traj["rollout_k32_4096"] = ("pz_rollout_random, k = 32 at config 2's batch size (4 096 games = 64 workgroups: what one "
+                                    "launch per frame leaves on the table there)", dict(num_envs=4096))
         traj["rollout_k128"] = ("pz_rollout_random, k = 128 (the launch's fixed costs -- state in and out, the first frame's "
                                 "latency before the first store -- over four times as many frames)", dict(k=128))
         for key, (wl, kw) in traj.items():
             r = measure_rollout(args, shard, device, check_lanes=1024, **{"k": 32, **kw})
             # counted bytes of one k-frame launch (profiles/traffic.json: FETCH_SIZE x 2 + WRITE_SIZE of the same kernel)
-            tr = load_traffic(key, args.num_envs)
+            tr = load_traffic(key, kw.get("num_envs", args.num_envs))
             r.update(traffic=tr, frac_traffic=None if tr is None else
                      tr / (r["k"] * r["us_per_frame"] * 1e-6) / 1e9 / HBM_PEAK_GBPS)
-            r.update(workload=wl, num_envs=args.num_envs,
-                     bound_detail="every frame's outputs stream to HBM (623 MB per 32-frame launch of int32 rows): "
-                                  "pure_store_GBps is what the launch's store pattern alone reaches on this entry's own "
-                                  "two observation tensors (pz_probe_write, measured in this run; 7.1 TB/s when "
-                                  "they lie in different ranks of the HBM, 5.6 when they share one: `placement`, "
-                                  "DESIGN 4.9); the int16 rows are not write-bound")
+            r.update(workload=wl, num_envs=kw.get("num_envs", args.num_envs))
             configs[key] = r
         # the reference's own loop, literally -- sample both agents' actions, then step -- as ONE launch per step
         r = measure_policy_in_the_loop(args, shard, device, fused=True)
@@ -821,6 +833,13 @@ def main():
                 r.pop("raw")
                 extra[f"launch_{mode}_{fmt}"] = {"value": r["value"], "launch_us": r["launch_us"],
                                                  "wall_us_per_step": r["wall_us_per_step"]}
+        # env.step() of an env built with the constructor's defaults (validate_actions=True: the range check runs inside
+        # the launch and is polled without a sync) beside the validate_actions=False figure above
+        r = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers, launch="api", burn=512,
+                    min_time=0.1, validate_actions=True)
+        r.pop("raw")
+        extra["launch_api_int32_default_constructor"] = {"value": r["value"], "launch_us": r["launch_us"],
+                                                         "wall_us_per_step": r["wall_us_per_step"]}
         # the k-frame launches through the env API, eagerly (no hipGraph): host time per call stays below the launch
         extra["rollout_k32_api"] = measure_rollout_api(args, shard, device)
         extra["step_many_k32_api"] = measure_rollout_api(args, shard, device, tape=True)
@@ -859,7 +878,9 @@ def main():
                                       args.state_format == "packed"),
             },
             "roofline": {
-                "bound": "hbm", "achieved": main_res["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                # the bound is HBM-side in every regime; which part of the memory system a launch of this batch size
+                # actually runs against is the regime (`regimes` below says what each name means)
+                "bound": f"hbm ({fr['regime']})", "achieved": main_res["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 # `frac` is a CONTRACT-bytes figure: the algorithmic 649 B/game-step over the HIP-event
                 # launch duration over 8 TB/s -- not achieved HBM bandwidth: the changed-only write-back moves fewer
                 # bytes (`traffic`, `frac_traffic`: PMC counters), and at this batch size they move through the
@@ -871,9 +892,20 @@ def main():
                 "frac_wall": fr["frac_wall"],
                 # ... and with the PMC-measured bytes instead of the 649 B/game-step contract figure
                 "frac_traffic": fr["frac_traffic"],
-                "regime": fr["regime"], "bound_detail": fr["bound_detail"],
+                "regime": fr["regime"], "regimes": BOUND_DETAIL,
             },
         }
+        if configs:
+            # the other BASELINE configs and the k-frame launches, condensed (the full entries are in `configs`): every
+            # figure the documents quote for them, inside the object the driver's record keeps whole
+            keep = ("launch_us", "us_per_frame", "value", "frac", "frac_traffic", "frac_of_pure_stores", "regime",
+                    "parity_bit_exact")
+            names = ("cfg2", "cfg3", "cfg3_compute", "cfg5", "int32_524288", "packed_headline", "packed_cfg3", "packed_524288",
+                     "rollout_k32", "step_many_k32", "rollout_k32_p2_computer", "step_many_k32_p2_computer", "rollout_k128",
+                     "rollout_k32_4096", "policy_fused_into_the_step")
+            out["roofline"]["by_config"] = {
+                name: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in configs[name].items() if k in keep}
+                for name in names if name in configs}
         if other_tape is not None:
             out["other_action_tape"] = other_tape
         if cpu is not None:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PZ_ABI_VERSION 7
+#define PZ_ABI_VERSION 8
 #define PZ_STATE_WORDS 44
 #define PZ_OBS_DIM 35
 
@@ -70,7 +70,7 @@ enum pz_error {
 /* Constructor kwargs of pikazoo_v0.env (pikazoo_env.py:79-86) + the fused wrappers
  * (wrappers/simplify_action.py, reward_by_ball_position.py, reward_in_normal_state.py,
  * normalize_observation.py, record_episode_statistics.py) + the batched-env additions
- * (auto_reset, seed, env_id_base). POD, 104 bytes, passed by pointer from the host and by
+ * (auto_reset, seed, env_id_base, action_faults). POD, 112 bytes, passed by pointer from the host and by
  * value to the kernels.
  *
  * Reward pipeline of one frame, in the order the reference's wrapper stack would apply it:
@@ -105,6 +105,15 @@ typedef struct pz_config {
                                      1 sums the env's own reward, 2 the fully wrapped reward */
     uint64_t seed;                /* Philox4x32-10 key of the env RNG stream */
     int64_t env_id_base;          /* global id of lane 0 (shards of one job use disjoint ranges) */
+    uint64_t *action_faults;      /* NULL, or a device counter (caller-owned, 8-byte aligned, zeroed by the caller): the
+                                     launches that READ actions (pz_step, pz_step_bound, pz_step_many) add to it when an
+                                     action lies outside [0, 18) -- [0, 13) with simplify_action.  The reference's table
+                                     lookup raises IndexError there (pikazoo_env.py:182); a launch cannot raise, so it
+                                     counts: non-zero afterwards = some action was out of range (at least one count per
+                                     offending game and launch).  Such an action is never used as an index (the decode
+                                     shifts bit tables): that game's input for the frame is undefined, no memory is
+                                     touched out of bounds, every other game is unaffected.  With NULL nothing is
+                                     checked (the range is then the caller's contract, as in ABI 7). */
 } pz_config;
 
 /* ---- the packed state format (cfg->packed_state = 1) -----------------------------------------------

@@ -68,6 +68,9 @@ typedef struct pzo_config {
                                     the env's own reward, 2 sums the fully wrapped reward */
     uint64_t seed;               /* Philox key of the env RNG stream */
     int64_t env_id_base;         /* global id of lane 0 (multi-GPU sharding) */
+    uint64_t *action_faults;     /* product-side diagnostic pointer (pz_config, ABI 8): kept for the identical byte
+                                    layout, never read here -- the reference raises IndexError on such an action
+                                    (pikazoo_env.py:182), the oracle's behaviour for one is undefined */
 } pzo_config;
 
 /* Philox4x32-10 block (Salmon et al., SC'11); out[4] */

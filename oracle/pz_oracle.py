@@ -69,6 +69,7 @@ class Config(C.Structure):
         ("episode_stats_mode", C.c_int32),
         ("seed", C.c_uint64),
         ("env_id_base", C.c_int64),
+        ("action_faults", C.c_void_p),  # product-side diagnostic pointer (layout only; never read by the oracle)
     ]
 
 

@@ -245,14 +245,19 @@ def fused_options(wrappers) -> dict:
             opt["simplify_action"] = True
         elif name == "RewardByBallPosition":
             assert not opt["normalize_obs"], "RewardByBallPosition must sit below NormalizeObservation"
+            assert opt["additional_reward"] is None, "one RewardByBallPosition"
+            assert opt["episode_stats"] != 2, "statistics between two reward wrappers"
             opt.update(additional_reward=list(kw["additional_reward"]), x_line=kw.get("x_line", 216),
                        y_line=kw.get("y_line", 176))
             seen_reward_wrapper = True
         elif name == "RewardInNormalState":
+            assert opt["normal_state_reward"] is None, "one RewardInNormalState"
+            assert opt["episode_stats"] != 2, "statistics between two reward wrappers"
             opt["normal_state_reward"] = kw["reward"]
             opt["normal_state_outside"] = opt["additional_reward"] is not None
             seen_reward_wrapper = True
         elif name == "NormalizeObservation":
+            assert not opt["normalize_obs"], "one NormalizeObservation"
             opt["normalize_obs"] = True
         elif name == "RecordEpisodeStatistics":
             later_reward = any(n in ("RewardByBallPosition", "RewardInNormalState") for n, _ in stack[idx + 1:])
@@ -261,6 +266,31 @@ def fused_options(wrappers) -> dict:
         else:
             raise ValueError(name)
     return opt
+
+
+def fusable(wrappers) -> bool:
+    """Can the step kernel express this stack as its fused branches (fused_options), or do some of its wrappers have to
+    run on the step's outputs (the product's wrapper classes then do that themselves; oracle/wrappers_oracle.py is the
+    CPU restatement the tests check them and these fixtures with)?"""
+    try:
+        fused_options(wrappers)
+        return True
+    except AssertionError:
+        return False
+    except ValueError:
+        raise
+
+
+def stack_traits(wrappers) -> dict:
+    """What a capture has to know about a stack, fusable or not: the size of the action space, whether observations /
+    rewards come out as floats, whether infos carry episode statistics."""
+    names = [n for n, _ in wrapper_stack(wrappers)]
+    if names.count("SimplifyAction") > 1 or names.count("RecordEpisodeStatistics") > 1:
+        raise ValueError("captures take at most one SimplifyAction / RecordEpisodeStatistics")
+    return dict(n_actions=13 if "SimplifyAction" in names else 18,
+                float_obs="NormalizeObservation" in names,
+                float_reward=any(n in ("RewardByBallPosition", "RewardInNormalState") for n in names),
+                has_stats="RecordEpisodeStatistics" in names)
 
 
 def reference_available() -> bool:
@@ -335,11 +365,11 @@ def capture(name: str, lanes: int, steps: int, seed: int, action_seed: int, env_
     full=True stores every state/obs/reward; digest_every>0 stores one 64-bit digest of the
     [W, lanes] state matrix every that many steps instead (long runs for rare branches)."""
     wrappers = wrappers or {}
-    opt = fused_options(wrappers)
-    n_actions = 13 if opt["simplify_action"] else 18
-    fused_reward = opt["additional_reward"] is not None or opt["normal_state_reward"] is not None
-    float_obs = opt["normalize_obs"]
-    has_stats = opt["episode_stats"] != 0
+    traits = stack_traits(wrappers)
+    n_actions = traits["n_actions"]
+    fused_reward = traits["float_reward"]
+    float_obs = traits["float_obs"]
+    has_stats = traits["has_stats"]
     envs = [make_reference_env(seed, env_id_base + i, wrappers, **env_kwargs) for i in range(lanes)]
     state_ctor = np.stack([extract_state(raw, shim) for _, raw, shim in envs], axis=1)
     obs_reset = np.zeros((lanes, 2, po.OBS), np.float64 if float_obs else np.int64)
@@ -702,6 +732,32 @@ FIXTURES += [
                  ["RecordEpisodeStatistics", {}]])),
 ]
 
+# stacks the step kernel cannot fuse (the reference composes its wrappers in any order): the product's wrapper classes
+# apply what cannot be a kernel branch on the step's outputs; the CPU side is oracle/wrappers_oracle.py
+UNFUSED_FIXTURES = [
+    # RewardByBallPosition ABOVE NormalizeObservation: it compares the normalized obs[26], obs[27] with the lines
+    # (reward_by_ball_position.py:22-24), i.e. every step lands in zone 0
+    ("unfused_ballpos_above_normalize", 4, 1200, dict(winning_score=2, serve="winner"),
+     dict(stack=[["NormalizeObservation", {}],
+                 ["RewardByBallPosition", dict(additional_reward=list(TEST_TABLE), x_line=216, y_line=176)]])),
+    # RecordEpisodeStatistics BETWEEN two reward wrappers: its sums see the first one only
+    ("unfused_stats_between_reward_wrappers", 4, 1500, dict(winning_score=2, is_player2_computer=True),
+     dict(stack=[["RewardByBallPosition", dict(additional_reward=list(TEST_TABLE), x_line=216, y_line=176)],
+                 ["RecordEpisodeStatistics", {}],
+                 ["RewardInNormalState", dict(reward=0.5)]])),
+    # two RewardByBallPosition, two RewardInNormalState, NormalizeObservation twice (the second one's bounds are the
+    # first one's Box(0, 1): the identity), SimplifyAction below it all
+    ("unfused_doubled_wrappers", 4, 1200, dict(winning_score=2, serve="alternate"),
+     dict(stack=[["SimplifyAction", {}],
+                 ["RewardByBallPosition", dict(additional_reward=list(TEST_TABLE), x_line=216, y_line=176)],
+                 ["RewardByBallPosition", dict(additional_reward=list(INT_TABLE), x_line=200, y_line=150)],
+                 ["RewardInNormalState", dict(reward=-0.002)],
+                 ["NormalizeObservation", {}],
+                 ["NormalizeObservation", {}],
+                 ["RewardInNormalState", dict(reward=0.25)],
+                 ["RecordEpisodeStatistics", {}]])),
+]
+
 FIXTURES += [
     # BASELINE.json configs[0]: one env, pikazoo_v0.env() defaults, random actions, 10 000 steps
     ("cfg1_one_env_10k", 1, 10000, dict(), None),
@@ -741,6 +797,16 @@ def main(argv=None):
         meta = json.loads(bytes(data["meta"]).decode())
         print(f"{name}: {lanes}x{steps} episodes={meta['episodes']} "
               f"{(GOLDEN / (name + '.npz')).stat().st_size / 1e3:.0f} kB {time.time() - t0:.1f}s")
+    for k, (name, lanes, steps, kw, wr) in enumerate(UNFUSED_FIXTURES):
+        if args.only and args.only != name:
+            continue
+        assert not fusable(wr), name
+        data = capture(name, lanes, steps, seed=31337 + k, action_seed=140 + k, env_id_base=30000 + 1000 * k, env_kwargs=kw,
+                       wrappers=wr, full=True)
+        np.savez_compressed(GOLDEN / f"{name}.npz", **data)
+        meta = json.loads(bytes(data["meta"]).decode())
+        print(f"{name}: {lanes}x{steps} episodes={meta['episodes']} "
+              f"{(GOLDEN / (name + '.npz')).stat().st_size / 1e3:.0f} kB")
     for k, (name, lanes, steps, side, kw) in enumerate(SINGLE_AGENT_RUNS):
         if args.only and args.only != name:
             continue

@@ -42,6 +42,21 @@ constexpr int kWaveObsVecs = (int)(kWaveObsBytes / 16);   // 560 16-byte pieces
 #ifndef PZ_OBS_AUX
 #define PZ_OBS_AUX 2  // observations are written once and not re-read by the step chain: nt, -2.4 % per launch
 #endif
+#ifndef PZ_HH_ROLLOUT_GENERIC
+#define PZ_HH_ROLLOUT_GENERIC 1  // launch_step_players: the human-vs-human rollout keeps its generic kernel (measured)
+#endif
+#ifndef PZ_TRAJ_STORE_ORDER
+#define PZ_TRAJ_STORE_ORDER 0
+#endif
+#ifndef PZ_DEV_FORCE_PLAIN
+#define PZ_DEV_FORCE_PLAIN false  // (diagnostic: every k-frame kernel compiled as its PLAIN form)
+#endif
+#ifndef PZ_AI_STATE_FIRST
+#define PZ_AI_STATE_FIRST 0  // (A/B switch: a computer-player launch writes its state in front of its observation rows)
+#endif
+#ifndef PZ_EARLY_OWN_STORES
+#define PZ_EARLY_OWN_STORES 2  // pair_body: what the human player's wave stores in front of the exchange barrier (0: nothing)
+#endif
 #ifndef PZ_TRAJ_AUX
 // The k-frame launches' observation rows (623 MB per 32-frame launch): sc0 sc1 nt.  With a computer player, rows written
 // `nt` alone (the single-frame launches' policy) push the flight tables' hot lines out of the caches and the look-ups
@@ -308,6 +323,20 @@ __device__ __forceinline__ void store_game_packed(const Game& g, const PackedIO&
     if (with_tail && tail != was.tail) pio.st_tail(tail);
 }
 
+// Out-of-range actions.  The reference's table lookup raises IndexError on one (pikazoo_env.py:182); a launch cannot
+// raise, so it counts into cfg.action_faults (NULL: unchecked, the range is the caller's contract).  `bad`: this lane
+// read an action outside [0, n_actions).  One scalar test and, when some lane of the wave has one, a ballot per launch;
+// the atomics only ever run on a caller's bug.  Nothing indexes memory with an action (the decode shifts bit tables, the
+// tape is parked as bytes), so the damage is that game's input for the frame.
+__device__ __forceinline__ uint32_t action_count(const pz_config& cfg) { return cfg.simplify_action ? 13u : 18u; }
+
+__device__ __forceinline__ void count_action_faults(const pz_config& cfg, bool bad)
+{
+    if (cfg.action_faults == nullptr) return;                  // wave-uniform (a kernel argument)
+    if (__builtin_amdgcn_ballot_w64(bad) == 0ull) return;      // wave-uniform
+    if (bad) atomicAdd(reinterpret_cast<unsigned long long*>(cfg.action_faults), 1ull);
+}
+
 __device__ __forceinline__ RngId make_rng_id(const pz_config& cfg, int64_t lane_index)
 {
     const uint64_t gid = (uint64_t)(cfg.env_id_base + lane_index);
@@ -519,12 +548,45 @@ __device__ unsigned long long g_pz_stamps[8192 * 8];
 #define PZ_SKIP_OBS ((a.cfg.packed_state & 16) != 0)
 #define PZ_SKIP_STATE_STORES ((a.cfg.packed_state & 1024) != 0)  // pair kernel: no state / reward / flag stores
 #define PZ_SKIP_OBS_STORES ((a.cfg.packed_state & 2048) != 0)    // pair kernel: observations staged but not stored
+#elif defined(PZ_CT_ABLATE)
+// compile-time ablations (tools/ab.py -DPZ_CT_ABLATE=bits, see step_games_pair): 256 no state / reward / flag stores,
+// 512 observations staged but not stored -- behind a condition the compiler cannot fold, so that nothing in front of the
+// stores is removed as dead code
+__device__ __forceinline__ bool ct_never()
+{
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return z != 0;
+}
+#define PZ_SKIP_FRAME false
+#define PZ_SKIP_OBS false
+#define PZ_SKIP_STATE_STORES ((((PZ_CT_ABLATE) & 256) != 0) && !pz::ct_never())
+#define PZ_SKIP_OBS_STORES ((((PZ_CT_ABLATE) & 512) != 0) && !pz::ct_never())
 #else
 #define PZ_SKIP_FRAME false
 #define PZ_SKIP_OBS false
 #define PZ_SKIP_STATE_STORES false
 #define PZ_SKIP_OBS_STORES false
 #endif
+
+// PLAIN launches (k-frame kernels): no fused wrapper, no episode statistics, raw integer rows.  The configuration words
+// of those features then read as compile-time constants, and their branches -- with the scalars and lane masks the
+// compiler would otherwise carry around the frame loop for them (the reward table alone is eight SGPRs of a budget of
+// ~100) -- leave the kernel.  The host picks the PLAIN instantiation when the configuration allows (launch_step).
+template <bool PLAIN, bool OBS16>
+__device__ __forceinline__ StepArgs effective_args(const StepArgs& in)
+{
+    StepArgs a = in;
+    if (PLAIN) {
+        a.cfg.simplify_action = 0;
+        a.cfg.ballpos_reward = 0;
+        a.cfg.normal_state_mode = 0;
+        a.cfg.episode_stats_mode = 0;
+        a.cfg.normalize_obs = OBS16 ? 2 : 0;
+        a.episode_stats = nullptr;
+    }
+    return a;
+}
 
 // ---- the fused step kernel -------------------------------------------------------------------
 // AI1/AI2: player 1 / 2 is the rule-based computer (compile-time so the human-vs-human build
@@ -551,44 +613,61 @@ constexpr int kTapeWords = kTapeChunk * 2 * kLanes / 4;  // the parked chunk in 
 #ifndef PZ_TAPE_AUX
 #define PZ_TAPE_AUX 18  // sc1 nt: a cold tape streamed with the default policy pushes the flight tables' hot lines out of the caches
 #endif
-constexpr int kTapeBatch = 16;                        // tape rows requested together by a refill inside the frame loop
+constexpr int kTapeBatch = 16;                        // tape rows requested together by a refill inside the frame loop (= kTapeGroup)
 
-// Rows [s0 + f0, s0 + f0 + B) of the tape (frames past k: an empty descriptor, the range check answers 0 without a
-// memory access) for the players asked for: ALL the loads are in flight before the first one is waited for -- one
-// memory round trip per batch (a refill that waits for each row, or each handful of rows, pays the latency of a cold
-// tape under the launch's write stream several times over: 3.88 vs 3.27 us per frame with a cache-resident tape).
+// Rows [s0 + f0, s0 + f0 + B) of the tape for the players asked for: ALL the loads are in flight before the first one is
+// waited for -- one memory round trip per batch (a refill that waits for each row, or each handful of rows, pays the
+// latency of a cold tape under the launch's write stream several times over: 3.88 vs 3.27 us per frame with a
+// cache-resident tape).  kTapeGroup rows share one descriptor, which ends with the launch's last frame: a row is
+// addressed through the per-lane offset (the part of a buffer address the range check covers), so rows past k read as 0
+// without a memory access -- and a batch needs two descriptors instead of one per row (32 of them, 128 scalars, were
+// most of what the tape kernels spilled).  A lane past the end of the batch reads some other game's action: it is never
+// used.  Returns whether this lane read an action >= n_actions (count_action_faults).
+constexpr int kTapeGroup = 16;  // kTapeGroup rows of 8 n bytes stay below 2^32 for every batch one launch can take
 template <int B, bool P1, bool P2>
-__device__ __forceinline__ void park_tape_rows(const int32_t* tape0, int64_t n, uint32_t n32, int32_t k, int32_t s0, int f0,
-                                               uint32_t voff, unsigned char* __restrict__ parked, int lane)
+__device__ __forceinline__ bool park_tape_rows(const int32_t* tape0, int64_t n, uint32_t n32, int32_t k, int32_t s0, int f0,
+                                               uint32_t voff, unsigned char* __restrict__ parked, int lane, uint32_t n_actions)
 {
+    static_assert(B % kTapeGroup == 0, "whole groups");
     int32_t v1[B], v2[B];
 #pragma unroll
-    for (int j = 0; j < B; ++j) {
-        const int32_t s = s0 + f0 + j;
-        const bool ok = s < k;  // wave-uniform
-        const Rsrc row = make_rsrc(tape0 + (int64_t)(ok ? s : 0) * 2 * n, ok ? n32 * 8u : 0u);
-        v1[j] = P1 ? (int32_t)__builtin_amdgcn_raw_buffer_load_b32(row, voff, 0, PZ_TAPE_AUX) : 0;
-        v2[j] = P2 ? (int32_t)__builtin_amdgcn_raw_buffer_load_b32(row, voff + n32 * 4u, 0, PZ_TAPE_AUX) : 0;
+    for (int h = 0; h < B; h += kTapeGroup) {
+        const int32_t first = s0 + f0 + h;
+        const int32_t left = min(max(k - first, 0), kTapeGroup);  // wave-uniform
+        const Rsrc rows = make_rsrc(tape0 + (int64_t)(left > 0 ? first : 0) * 2 * n, (uint32_t)left * n32 * 8u);
+        uint32_t o1 = voff, o2 = voff + n32 * 4u;
+#pragma unroll
+        for (int j = 0; j < kTapeGroup; ++j) {
+            v1[h + j] = P1 ? (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rows, o1, 0, PZ_TAPE_AUX) : 0;
+            v2[h + j] = P2 ? (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rows, o2, 0, PZ_TAPE_AUX) : 0;
+            o1 += n32 * 8u;
+            o2 += n32 * 8u;
+        }
     }
+    uint32_t worst = 0u;
 #pragma unroll
     for (int j = 0; j < B; ++j) {
         if (P1) parked[((f0 + j) * 2 + 0) * kLanes + lane] = (unsigned char)v1[j];
         if (P2) parked[((f0 + j) * 2 + 1) * kLanes + lane] = (unsigned char)v2[j];
+        worst = max(worst, max((uint32_t)v1[j], (uint32_t)v2[j]));
     }
+    return worst >= n_actions;
 }
 
 // One chunk (frames s0 .. s0 + kTapeChunk - 1, as far as the launch goes).  FIRST: the launch's first chunk, requested
 // behind the state loads with 32 rows in flight per batch (nothing else is live yet); a refill inside the frame loop
 // keeps to kTapeBatch registers per player.
 template <bool FIRST, bool P1, bool P2>
-__device__ __forceinline__ void park_tape_chunk(const int32_t* tape0, int64_t n, uint32_t n32, int32_t k, int32_t s0,
-                                                uint32_t voff, unsigned char* __restrict__ parked, int lane)
+__device__ __forceinline__ bool park_tape_chunk(const int32_t* tape0, int64_t n, uint32_t n32, int32_t k, int32_t s0,
+                                                uint32_t voff, unsigned char* __restrict__ parked, int lane, uint32_t n_actions)
 {
     constexpr int B = FIRST ? 32 : kTapeBatch;
     static_assert(kTapeChunk % B == 0, "whole batches");
+    bool bad = false;
 #pragma unroll 1
     for (int f0 = 0; f0 < kTapeChunk && s0 + f0 < k; f0 += B)
-        park_tape_rows<B, P1, P2>(tape0, n, n32, k, s0, f0, voff, parked, lane);
+        bad |= park_tape_rows<B, P1, P2>(tape0, n, n32, k, s0, f0, voff, parked, lane, n_actions);
+    return bad;
 }
 
 // The reward pipeline of one frame (see pz_config in the header): the reference's wrapper
@@ -609,7 +688,22 @@ __device__ __forceinline__ float zone_reward(const pz_config& cfg, int k)
     return v;
 }
 
-__device__ __forceinline__ Rewards shape_rewards(const pz_config& cfg, const Game& g, int reward, bool frozen)
+// The k-frame kernels hold the table in eight per-lane registers for the whole launch (`parked`): as scalars the
+// compiler carries it around the frame loop in eight SGPRs of a budget of ~100, spills it and brings all eight back
+// through v_readlane in front of every use (a lone wave per SIMD has hundreds of VGPRs to spare).
+struct ZoneTable {
+    float z[8];
+};
+__device__ __forceinline__ ZoneTable park_zone_table(const pz_config& cfg)
+{
+    ZoneTable t;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t.z[k] = zone_reward(cfg, k);
+    return t;
+}
+
+__device__ __forceinline__ Rewards shape_rewards(const pz_config& cfg, const Game& g, int reward, bool frozen,
+                                                 const ZoneTable* parked = nullptr)
 {
     Rewards r{reward, -reward, (float)reward, (float)(-reward)};
     if (frozen) return r;
@@ -620,8 +714,9 @@ __device__ __forceinline__ Rewards shape_rewards(const pz_config& cfg, const Gam
     if (cfg.ballpos_reward) {  // reward_by_ball_position.py:22-29: zone from the post-step ball position
         // additional_reward[i * 4 + zone], zone = (y > y_line) + 2 * (x >= x_line)
         const bool low = g.b.y > cfg.y_line, right = g.b.x >= cfg.x_line;
-        r.f1 += right ? (low ? zone_reward(cfg, 3) : zone_reward(cfg, 2)) : (low ? zone_reward(cfg, 1) : zone_reward(cfg, 0));
-        r.f2 += right ? (low ? zone_reward(cfg, 7) : zone_reward(cfg, 6)) : (low ? zone_reward(cfg, 5) : zone_reward(cfg, 4));
+        auto z = [&](int k) { return parked != nullptr ? parked->z[k] : zone_reward(cfg, k); };
+        r.f1 += right ? (low ? z(3) : z(2)) : (low ? z(1) : z(0));
+        r.f2 += right ? (low ? z(7) : z(6)) : (low ? z(5) : z(4));
     }
     if (cfg.normal_state_mode == 2) {  // the wrapper outside RewardByBallPosition
         r.f1 = (r.f1 == 0.0f) ? cfg.normal_state_reward : r.f1;
@@ -820,12 +915,29 @@ struct TrajOut {
             for (int pass = 0; pass < 9; ++pass) p2[pass] = src2[min(pass * kLanes + lane, kWaveObsVecs - 1)];
             between();
             const Rsrc s1 = make_rsrc(obs1, obs_span_bytes), s2 = make_rsrc(obs2, obs_span_bytes);
+#if PZ_TRAJ_STORE_ORDER == 1  // (A/B: the two tensors' pieces alternate)
+#pragma unroll
+            for (int pass = 0; pass < 9; ++pass) {
+                __builtin_amdgcn_raw_buffer_store_b128(p1[pass], s1, piece_off[pass], 0, PZ_TRAJ_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(p2[pass], s2, piece_off[pass], 0, PZ_TRAJ_AUX);
+            }
+#elif PZ_TRAJ_STORE_ORDER == 2  // (A/B: every other workgroup writes player 2's tensor first)
+            const bool swap = (blockIdx.x & 1u) != 0;
+            const Rsrc sa = swap ? s2 : s1, sb = swap ? s1 : s2;
+#pragma unroll
+            for (int pass = 0; pass < 9; ++pass)
+                __builtin_amdgcn_raw_buffer_store_b128(swap ? p2[pass] : p1[pass], sa, piece_off[pass], 0, PZ_TRAJ_AUX);
+#pragma unroll
+            for (int pass = 0; pass < 9; ++pass)
+                __builtin_amdgcn_raw_buffer_store_b128(swap ? p1[pass] : p2[pass], sb, piece_off[pass], 0, PZ_TRAJ_AUX);
+#else
 #pragma unroll
             for (int pass = 0; pass < 9; ++pass)
                 __builtin_amdgcn_raw_buffer_store_b128(p1[pass], s1, piece_off[pass], 0, PZ_TRAJ_AUX);
 #pragma unroll
             for (int pass = 0; pass < 9; ++pass)
                 __builtin_amdgcn_raw_buffer_store_b128(p2[pass], s2, piece_off[pass], 0, PZ_TRAJ_AUX);
+#endif
         }
     }
     // one tensor's pieces requested from LDS at once (36 VGPRs), `between()`, their stores back to back
@@ -953,12 +1065,14 @@ __device__ __forceinline__ void scout_candidates_posted(const int32_t* __restric
 #ifndef PZ_TRAJ_WAVES
 #define PZ_TRAJ_WAVES 1
 #endif
-template <bool AI1, bool AI2, int MODE, bool SPARSE, int SCOUT = kNoScout, bool PACKED = false, bool OBS16 = false>
+template <bool AI1, bool AI2, int MODE, bool SPARSE, int SCOUT = kNoScout, bool PACKED = false, bool OBS16 = false,
+          bool PLAIN = false>
 __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes)
 __attribute__((amdgpu_waves_per_eu((MODE == kRollout || MODE == kTape) && SCOUT != kNoScout ? 2 : 1,
                                    MODE == kRollout ? (SCOUT != kNoScout ? 2 : PZ_TRAJ_WAVES) : (MODE == kTape && SCOUT != kNoScout ? 2 : (MODE == kTape ? PZ_TAPE_WAVES : 8)))))
-void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
+void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
 {
+    const StepArgs a = effective_args<PLAIN || PZ_DEV_FORCE_PLAIN, OBS16>(args);
     const HotArgs hot{state, n, stride, act_p1, act_p2};
     static_assert(!PACKED || (SCOUT == kNoScout && !SPARSE), "the packed format has no scout and no changed-only variant");
     static_assert(!OBS16 || MODE == kRollout || MODE == kTape, "the single-frame launches take the row format at run time");
@@ -1041,8 +1155,10 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
     // latency is theirs.  (Requesting a chunk half a chunk ahead into registers was tried: the loads pending around the
     // loop's back edge make the compiler wait at every copy of those registers, every frame.)
     unsigned char* const parked = reinterpret_cast<unsigned char*>(tape_lds);
-    auto fetch_tape_chunk = [&](int32_t s0, auto first) {  // (games past n read as 0 through the range check)
-        park_tape_chunk<decltype(first)::value, true, true>(a.act_p1, a.n, n32, a.k, s0, io.voff, parked, lane);
+    bool bad_action = false;
+    auto fetch_tape_chunk = [&](int32_t s0, auto first) {
+        bad_action |= park_tape_chunk<decltype(first)::value, true, true>(a.act_p1, a.n, n32, a.k, s0, io.voff, parked, lane,
+                                                                          action_count(a.cfg));
         wave_lds_handover<SCOUT == kNoScout>();  // every lane reads back its own bytes only
     };
     if (MODE == kTape) fetch_tape_chunk(0, std::true_type{});
@@ -1061,6 +1177,9 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
         // counter and the Philox block runs once, behind the loop, instead of on three frames out of four.
         constexpr bool kDefer1 = !AI1, kDefer2 = !AI2;
         BoldDefer bold{false, false, 0u, 0u};
+        // (not beside a scout wave: two waves per SIMD leave 256 registers each, which that kernel already fills)
+        const ZoneTable zones = SCOUT == kNoScout ? park_zone_table(a.cfg) : ZoneTable{};
+        const ZoneTable* const parked_zones = SCOUT == kNoScout ? &zones : nullptr;
         TrajOut<OBS16> out;
         if (kTraj) out.init(a, i, lane, live);
         if (MODE != kTape) policy_actions(id.id_lo, id.id_hi, policy, a.t0, n_actions, a1, a2);
@@ -1094,7 +1213,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
             reward = frame_tail<AI1, AI2, SCOUT, false>(g, a.cfg, id, a1, a2, live, head, lds_obs[0], lane, lut, link,
                                                         nullptr, last_frame);
             finished += (unsigned int)(live && g.e.game_ended && !frozen);
-            rw = shape_rewards(a.cfg, g, reward, frozen);
+            rw = shape_rewards(a.cfg, g, reward, frozen, parked_zones);
             if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
             // the next frame's policy draw (one block too many per launch): in a trajectory launch it is the independent
             // VALU work that runs under the LDS reads of this frame's rows
@@ -1132,12 +1251,18 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
     }
     PZ_STAMP(2);
     if (live) {
-        if constexpr (PACKED)
+        if constexpr (PACKED) {
             store_game_packed(g, pio, was, true);
-        else if (SPARSE)
+        } else if (SPARSE) {
             store_game_changed(g, loaded, io, ex_pending);
-        else
-            store_game(g, io, ex_pending);
+        } else {
+            // behind a frame loop the column offsets are computed afresh: the compiler otherwise keeps the 44 products
+            // column x pitch of the loads alive across the loop for these stores -- 44 scalars of a budget of ~100,
+            // spilled and brought back through v_readlane (the opaque copy of the pitch is a new value to it)
+            StateIO back = io;
+            if (MODE != kActions) asm volatile("" : "+s"(back.pitch));
+            store_game(g, back, ex_pending);
+        }
         if (with_stats) sio.store(st);
     }
     if (MODE != kRollout && MODE != kTape) emit_outputs(a, g, rw, as_float, live, i, lane, 0, lds_obs, PZ_SKIP_OBS);
@@ -1145,6 +1270,9 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs a)
     PZ_DRAIN_VMEM();
     PZ_STAMP(6);
 
+    // the launches that read actions: pz_step (a1 / a2 as loaded) and pz_step_many (noted while the tape was parked)
+    if (MODE == kActions) bad_action = (uint32_t)a1 >= action_count(a.cfg) || (uint32_t)a2 >= action_count(a.cfg);
+    if (MODE == kActions || MODE == kTape) count_action_faults(a.cfg, live && bad_action);
     if (a.episodes_done != nullptr) {
         // one atomic per wave: reduce the per-lane counts across the wavefront first
         unsigned int total = finished;
@@ -1256,8 +1384,41 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
 #endif
     LandingProbe after_hit{false, false, 0u, 0u};
     bool bold_pending = false;  // a human player's new-round boldness draw, made behind the stores
+    // In a launch with ONE computer player the human player's wave reaches the exchange barrier ~1 000 cycles before its
+    // partner (tools/stamps.py): while it waits it puts on their way (1) its own player's columns -- final once it has
+    // moved; the collision flag follows behind the barrier -- (interleaved A/B, config 3, cold tape: 8.58 -> 8.44 us per
+    // launch; human vs human, where nobody waits, the same stores gained nothing in round 2)
+    // (3, A/B only: the computer's wave stores its player in front of the barrier too)
+    constexpr bool kEarlyOwn = PZ_EARLY_OWN_STORES != 0 && !PACKED && (AI1 != AI2) && (!kOwnAI || PZ_EARLY_OWN_STORES >= 3);
+    // ... and (2) the ball's position, trail and rotation: final once the world step has run (a ball-player collision
+    // changes velocities, power-hit flag and punch_effect_x only) -- the human player's wave stores all seven, the
+    // computer's wave none of them (8.44 -> 8.40; hot tape 8.30 -> 8.17 -> 8.15: profiles/r04_experiments/)
+    constexpr bool kEarlyBall = kEarlyOwn && !kOwnAI && PZ_EARLY_OWN_STORES >= 2;
+    constexpr bool kPartnerStoresBall = PZ_EARLY_OWN_STORES >= 2 && !PACKED && (AI1 != AI2) && kOwnAI;
+    int coll_before = 0;
+    auto before_barrier = [&]() {
+        if constexpr (kEarlyOwn) {
+            if (live && !PZ_SKIP_STATE_STORES) {
+                Player& mine = ROLE == 0 ? g.p1 : g.p2;
+                const Player& was = ROLE == 0 ? loaded.p1 : loaded.p2;
+                coll_before = mine.coll;
+                mine.coll = was.coll;  // (not final yet: stored behind the barrier when it changed)
+                store_player_changed(mine, was, io, kOwn);
+                mine.coll = coll_before;
+                if constexpr (kEarlyBall) {
+                    io.st(PZ_B_X, g.b.x);
+                    io.st(PZ_B_Y, g.b.y);
+                    io.st(PZ_B_PREVIOUS_X, g.b.px);
+                    io.st(PZ_B_PREVIOUS_Y, g.b.py);
+                    io.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
+                    io.st(PZ_B_PREVIOUS_PREVIOUS_Y, g.b.ppy);
+                    io.st(PZ_B_FINE_ROTATION, g.b.rot);
+                }
+            }
+        }
+    };
     const int reward = step_games_pair<ROLE, AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, xchg, kLanes * PZ_OBS_DIM,
-                                                        lane, lut, after_hit, bold_pending);
+                                                        lane, lut, after_hit, bold_pending, before_barrier);
     const Rewards rw = shape_rewards(a.cfg, g, reward, frozen);
     if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
     PZ_PAIR_STAMP(ROLE, 2);
@@ -1298,10 +1459,17 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
             return;
         }
         // changed-only write-back of the rarely changing columns, as in store_game_changed
-        store_player_changed(ROLE == 0 ? g.p1 : g.p2, ROLE == 0 ? loaded.p1 : loaded.p2, io, kOwn);
+        if constexpr (kEarlyOwn) {
+            const Player& mine = ROLE == 0 ? g.p1 : g.p2;
+            if (mine.coll != (ROLE == 0 ? loaded.p1 : loaded.p2).coll) io.st(kOwn + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED, mine.coll);
+        } else {
+            store_player_changed(ROLE == 0 ? g.p1 : g.p2, ROLE == 0 ? loaded.p1 : loaded.p2, io, kOwn);
+        }
         if (ROLE == 0) {
-            io.st(PZ_B_X, g.b.x);
-            io.st(PZ_B_Y, g.b.y);
+            if (!kEarlyBall && !kPartnerStoresBall) {
+                io.st(PZ_B_X, g.b.x);
+                io.st(PZ_B_Y, g.b.y);
+            }
             io.st(PZ_B_Y_VELOCITY, g.b.yv);
             if (g.b.xv != loaded.b.xv) io.st(PZ_B_X_VELOCITY, g.b.xv);
             if (g.b.power != loaded.b.power) io.st(PZ_B_IS_POWER_HIT, g.b.power);
@@ -1315,7 +1483,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
             if (with_stats) sio.store(st);
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, make_rsrc(a.terminated, n32),
                                                  (uint32_t)i, 0, 0);
-        } else {
+        } else if (!kEarlyBall && !kPartnerStoresBall) {
             io.st(PZ_B_PREVIOUS_X, g.b.px);
             io.st(PZ_B_PREVIOUS_Y, g.b.py);
             io.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
@@ -1349,7 +1517,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     // Interleaved A/B (tools/ab.py, us per launch, state first | observations first): human vs human 7.14 | 7.27,
     // player 2 = computer 8.58 | 8.41 -- the observation tensors are three quarters of the written bytes, and in the
     // computer-player launch the waves reach their stores less evenly.
-    if (AI1 || AI2) {
+    if ((AI1 || AI2) && !PZ_AI_STATE_FIRST) {
         store_observations();
         store_state();
     } else {
@@ -1372,6 +1540,8 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         if (started) pio.st_bold(ROLE, (ROLE == 0 ? g.p1 : g.p2).bold);
     }
     // last: after a ball-player collision the value comes from a table gather issued at the end of the frame
+    // (taken over by the human player's wave -- disjoint lanes, the same store -- it costs: 8.58 -> 8.65 us per launch
+    // alone, nothing on top of the early stores, packed 7.22 -> 7.60: profiles/r04_experiments/)
     if (kKeepsEx) {
         const int ex = lut.landing_finish(after_hit, g.b.x, g.b.y, g.b.xv, g.b.yv, g.b.ex);
         if (live && ex != loaded.b.ex) {
@@ -1381,6 +1551,9 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
                 io.st(PZ_B_EXPECTED_LANDING_POINT_X, ex);
         }
     }
+    // (player 1's wave checks both action words: both waves load both)
+    if (!RANDOM && ROLE == 0)
+        count_action_faults(a.cfg, live && ((uint32_t)a1 >= action_count(a.cfg) || (uint32_t)a2 >= action_count(a.cfg)));
     if (RANDOM && ROLE == 0 && a.episodes_done != nullptr) {  // pz_step_random's counter: one atomic per workgroup
         unsigned int total = (unsigned int)(live && g.e.game_ended && !frozen);
         for (int off = kLanes / 2; off > 0; off >>= 1) total += __shfl_down(total, off, kLanes);
@@ -1388,6 +1561,9 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     }
 }
 
+// (32 games per workgroup -- half-filled waves, four per SIMD at 65 536 games instead of two, more of them to hide each
+// other's memory latency -- was built for this kernel in round 4 and lost: human vs human 6.97 -> 7.49 us per launch,
+// player 2 = computer 8.57 -> 9.35, profiles/r04_experiments/ab_g32_and_early_stores.log)
 template <bool AI1, bool AI2, bool PACKED = false, bool RANDOM = false>
 __global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(PZ_HOT_PARAMS, const StepArgs a)
 {
@@ -1494,6 +1670,7 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
 
     const uint32_t n_actions = a.cfg.simplify_action ? 13u : 18u;
     BoldDefer bold{false, false, 0u, 0u};
+    const ZoneTable zones = park_zone_table(a.cfg);
     TrajOut<OBS16> out;
     out.init(a, i, lane, live);
     char*& own_rows = ROLE == 0 ? out.obs1 : out.obs2;
@@ -1505,8 +1682,10 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
     // -- it has no stores the wait would drain -- was slower: 4.31 vs 4.12 us per frame); the first chunk behind the
     // state loads, its latency is theirs
     unsigned char* const parked = reinterpret_cast<unsigned char*>(tape_lds);
-    auto fetch_tape_chunk = [&](int32_t s0, auto first) {  // (games past n read as 0 through the range check)
-        park_tape_chunk<decltype(first)::value, ROLE == 0, ROLE == 1>(a.act_p1, a.n, n32, a.k, s0, io.voff, parked, lane);
+    bool bad_action = false;  // (every wave checks the row it parks: its own player's)
+    auto fetch_tape_chunk = [&](int32_t s0, auto first) {
+        bad_action |= park_tape_chunk<decltype(first)::value, ROLE == 0, ROLE == 1>(a.act_p1, a.n, n32, a.k, s0, io.voff, parked,
+                                                                                     lane, action_count(a.cfg));
         __syncthreads();
     };
     if (MODE == kTape) fetch_tape_chunk(0, std::true_type{});
@@ -1531,7 +1710,7 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
                                                            xchg + (s & 1) * (2 * kLoopXchgRegion), lane, lut, last_frame,
                                                            &ex_fresh);
         finished += (unsigned int)(live && g.e.game_ended && !frozen);
-        const Rewards rw = shape_rewards(a.cfg, g, reward, frozen);
+        const Rewards rw = shape_rewards(a.cfg, g, reward, frozen, &zones);
         if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
         // The frame's outputs.  With ONE computer player its wave is the frame's critical path (its decision on top of
         // everything the partner does), so the HUMAN player's wave writes everything -- both agents' rewards and rows,
@@ -1590,31 +1769,35 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
             if (kOwnAI ? any_round_started : bold.pending1) pio.st_bold(ROLE, own.bold);
             if (kKeepsEx) pio.st_ex(g.b.ex);
         } else {
-            store_player(own, io, kOwn);
+            // (column offsets computed afresh behind the frame loop: see step_kernel)
+            StateIO back = io;
+            asm volatile("" : "+s"(back.pitch));
+            store_player(own, back, kOwn);
             if (ROLE == 0) {
-                io.st(PZ_B_X, g.b.x);
-                io.st(PZ_B_Y, g.b.y);
-                io.st(PZ_B_X_VELOCITY, g.b.xv);
-                io.st(PZ_B_Y_VELOCITY, g.b.yv);
-                io.st(PZ_B_IS_POWER_HIT, g.b.power);
-                io.st(PZ_B_PUNCH_EFFECT_X, g.b.punch);
-                io.st(PZ_E_SCORE_P1, g.e.s1);
-                io.st(PZ_E_SCORE_P2, g.e.s2);
-                io.st(PZ_E_IS_PLAYER2_SERVE, g.e.p2serve);
-                io.st(PZ_E_ROUND_ENDED, g.e.round_ended);
-                io.st(PZ_E_GAME_ENDED, g.e.game_ended);
-                io.st(PZ_E_RNG_DRAW_COUNTER, (int32_t)g.e.rng);
+                back.st(PZ_B_X, g.b.x);
+                back.st(PZ_B_Y, g.b.y);
+                back.st(PZ_B_X_VELOCITY, g.b.xv);
+                back.st(PZ_B_Y_VELOCITY, g.b.yv);
+                back.st(PZ_B_IS_POWER_HIT, g.b.power);
+                back.st(PZ_B_PUNCH_EFFECT_X, g.b.punch);
+                back.st(PZ_E_SCORE_P1, g.e.s1);
+                back.st(PZ_E_SCORE_P2, g.e.s2);
+                back.st(PZ_E_IS_PLAYER2_SERVE, g.e.p2serve);
+                back.st(PZ_E_ROUND_ENDED, g.e.round_ended);
+                back.st(PZ_E_GAME_ENDED, g.e.game_ended);
+                back.st(PZ_E_RNG_DRAW_COUNTER, (int32_t)g.e.rng);
             } else {
-                io.st(PZ_B_PREVIOUS_X, g.b.px);
-                io.st(PZ_B_PREVIOUS_Y, g.b.py);
-                io.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
-                io.st(PZ_B_PREVIOUS_PREVIOUS_Y, g.b.ppy);
-                io.st(PZ_B_FINE_ROTATION, g.b.rot);
+                back.st(PZ_B_PREVIOUS_X, g.b.px);
+                back.st(PZ_B_PREVIOUS_Y, g.b.py);
+                back.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
+                back.st(PZ_B_PREVIOUS_PREVIOUS_Y, g.b.ppy);
+                back.st(PZ_B_FINE_ROTATION, g.b.rot);
             }
-            if (kKeepsEx) io.st(PZ_B_EXPECTED_LANDING_POINT_X, g.b.ex);
+            if (kKeepsEx) back.st(PZ_B_EXPECTED_LANDING_POINT_X, g.b.ex);
         }
         if (with_stats) sio.store(st);
     }
+    if (MODE == kTape) count_action_faults(a.cfg, live && bad_action);
     if (ROLE == 0 && a.episodes_done != nullptr) {
         unsigned int total = finished;
         for (int off = kLanes / 2; off > 0; off >>= 1) total += __shfl_down(total, off, kLanes);
@@ -1622,10 +1805,11 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
     }
 }
 
-template <bool AI1, bool AI2, int MODE, bool PACKED = false, bool OBS16 = false>
+template <bool AI1, bool AI2, int MODE, bool PACKED = false, bool OBS16 = false, bool PLAIN = false>
 __global__ __launch_bounds__(2 * kLanes) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void rollout_pair_kernel(PZ_HOT_PARAMS, const StepArgs a)
+void rollout_pair_kernel(PZ_HOT_PARAMS, const StepArgs args)
 {
+    const StepArgs a = effective_args<PLAIN || PZ_DEV_FORCE_PLAIN, OBS16>(args);
     const HotArgs hot{state, n, stride, act_p1, act_p2};
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     __shared__ int32_t xchg[kLoopXchgWords];  // the players' exchange: LDS of its own, double-buffered by frame parity
@@ -2109,6 +2293,15 @@ constexpr int64_t kMaxLanesPerLaunch = (int64_t)0xFFFFFFFFu / (PZ_STATE_WORDS * 
 //   per k frames, where the plain write-back is always right.
 
 static inline bool is_packed(const pz_config& cfg) { return (cfg.packed_state & 1) != 0; }
+// no fused wrapper, no episode statistics, raw integer rows: what the PLAIN k-frame kernels are compiled for
+static inline bool is_plain(const StepArgs& a)
+{
+#ifdef PZ_DEV_NO_PLAIN  // (tools/ab.py: the generic k-frame kernels on a plain configuration)
+    return false;
+#endif
+    return a.cfg.simplify_action == 0 && a.cfg.ballpos_reward == 0 && a.cfg.normal_state_mode == 0 &&
+           a.cfg.normalize_obs != 1 && (a.cfg.episode_stats_mode == 0 || a.episode_stats == nullptr);
+}
 static inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
 
 static int check_common(const void* state, int64_t n, int64_t stride, const pz_config* cfg)
@@ -2131,6 +2324,27 @@ static int check_common(const void* state, int64_t n, int64_t stride, const pz_c
 
 static inline unsigned int blocks_for(int64_t n, int per) { return (unsigned int)((n + per - 1) / per); }
 
+// Diagnostic builds only (tools/ab.py, tools/kernel_notes.py; the product never defines it): -DPZ_DEV_SUBSET=bits keeps
+// a subset of the step kernels' instantiations -- a variant that is only ever timed on one configuration builds in a
+// fraction of the 100 s the full library takes.  bits 0-3: launch modes kActions / kRandom / kRollout / kTape; 4: the packed
+// state format; 5: int16 rows; 6: human vs human; 7: player 2 = computer; 8: the other computer-player combinations;
+// 9: step_pair_kernel; 10: rollout_pair_kernel; 11: step_kernel; 12: the PLAIN forms of the k-frame kernels; 13: their
+// generic forms.  A launch that was left out returns PZ_E_CONFIG.
+enum DevFamily { kDevPair = 9, kDevRolloutPair = 10, kDevSingle = 11 };
+#ifdef PZ_DEV_SUBSET
+constexpr bool dev_keep(int family, int mode, bool ai1, bool ai2, bool packed, bool obs16, bool plain = false)
+{
+    constexpr unsigned m = PZ_DEV_SUBSET;
+    const bool players = (!ai1 && !ai2) ? (m >> 6) & 1u : ((!ai1 && ai2) ? (m >> 7) & 1u : (m >> 8) & 1u);
+    const bool form = (mode != kRollout && mode != kTape) || ((m >> (plain ? 12 : 13)) & 1u);
+    return ((m >> family) & 1u) && ((m >> mode) & 1u) && players && (!packed || ((m >> 4) & 1u)) &&
+           (!obs16 || ((m >> 5) & 1u)) && form;
+}
+#define PZ_KEEP(...) pz::dev_keep(__VA_ARGS__)
+#else
+#define PZ_KEEP(...) true
+#endif
+
 // one step_kernel instantiation per player configuration; the trajectory modes also per observation row format
 // (OBS16, compile-time there: see TrajOut::flush)
 template <int MODE, bool SPARSE, int SCOUT, bool PACKED, bool OBS16>
@@ -2138,14 +2352,44 @@ static int launch_step_players(const StepArgs& a, hipStream_t stream)
 {
     const dim3 grid(blocks_for(a.n, kLanes)), block(SCOUT != kNoScout ? 2 * kLanes : kLanes);
     const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
+    // the k-frame launches of a configuration without fused wrappers / statistics: the PLAIN instantiation (effective_args)
+    // -- but for the human-vs-human rollout on one wave: that launch runs at the write ceiling of the two observation
+    // tensors either way, and its leaner PLAIN form (6 SGPR spills instead of 53) measured 0.6 - 3.4 % SLOWER there,
+    // on every box and in every position of the interleaved rounds (us per frame, k = 32: 2.91 vs 2.81-2.84; k = 128:
+    // 2.73 vs 2.65; store order within the frame: no effect; profiles/r04_experiments/ab_rollout_hh_*), while the tape
+    // kernel and every computer-player launch gain 1-2 % from theirs
+    constexpr bool kHasPlain = (MODE == kRollout || MODE == kTape) && SCOUT == kNoScout && !PACKED;
+    const bool plain = kHasPlain && is_plain(a);
+#define PZ_PLAIN_HERE(A1, A2) (kHasPlain && !(PZ_HH_ROLLOUT_GENERIC && MODE == kRollout && !(A1) && !(A2)))
+#define PZ_LAUNCH_SINGLE_AS(A1, A2, PLAIN)                                                                                \
+    do {                                                                                                                  \
+        if constexpr (PZ_KEEP(kDevSingle, MODE, A1, A2, PACKED, OBS16, PLAIN))                                             \
+            hipLaunchKernelGGL((step_kernel<A1, A2, MODE, SPARSE, SCOUT, PACKED, OBS16, PLAIN>), grid, block, 0, stream,   \
+                               PZ_HOT_ARGS(a), a);                                                                        \
+        else                                                                                                              \
+            return PZ_E_CONFIG;                                                                                           \
+    } while (0)
+#define PZ_LAUNCH_SINGLE(A1, A2)                                                                                          \
+    do {                                                                                                                  \
+        if constexpr (PZ_PLAIN_HERE(A1, A2)) {                                                                            \
+            if (plain) {                                                                                                  \
+                PZ_LAUNCH_SINGLE_AS(A1, A2, true);                                                                        \
+                break;                                                                                                    \
+            }                                                                                                             \
+        }                                                                                                                 \
+        PZ_LAUNCH_SINGLE_AS(A1, A2, false);                                                                               \
+    } while (0)
     if (ai1 && ai2)
-        hipLaunchKernelGGL((step_kernel<true, true, MODE, SPARSE, SCOUT, PACKED, OBS16>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+        PZ_LAUNCH_SINGLE(true, true);
     else if (ai1)
-        hipLaunchKernelGGL((step_kernel<true, false, MODE, SPARSE, SCOUT, PACKED, OBS16>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+        PZ_LAUNCH_SINGLE(true, false);
     else if (ai2)
-        hipLaunchKernelGGL((step_kernel<false, true, MODE, SPARSE, SCOUT, PACKED, OBS16>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+        PZ_LAUNCH_SINGLE(false, true);
     else if constexpr (SCOUT == kNoScout)  // (a scout wave only ever serves a computer player)
-        hipLaunchKernelGGL((step_kernel<false, false, MODE, SPARSE, SCOUT, PACKED, OBS16>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+        PZ_LAUNCH_SINGLE(false, false);
+#undef PZ_LAUNCH_SINGLE
+#undef PZ_LAUNCH_SINGLE_AS
+#undef PZ_PLAIN_HERE
     return (int)hipGetLastError();
 }
 
@@ -2162,10 +2406,18 @@ template <bool AI1, bool AI2, bool RANDOM = false>
 static int launch_pair(const StepArgs& a, hipStream_t stream)
 {
     const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
-    if (is_packed(a.cfg))
-        hipLaunchKernelGGL((step_pair_kernel<AI1, AI2, true, RANDOM>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
-    else
-        hipLaunchKernelGGL((step_pair_kernel<AI1, AI2, false, RANDOM>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+    constexpr int kMode = RANDOM ? kRandom : kActions;
+    if (is_packed(a.cfg)) {
+        if constexpr (PZ_KEEP(kDevPair, kMode, AI1, AI2, true, false))
+            hipLaunchKernelGGL((step_pair_kernel<AI1, AI2, true, RANDOM>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+        else
+            return PZ_E_CONFIG;
+    } else {
+        if constexpr (PZ_KEEP(kDevPair, kMode, AI1, AI2, false, false))
+            hipLaunchKernelGGL((step_pair_kernel<AI1, AI2, false, RANDOM>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);
+        else
+            return PZ_E_CONFIG;
+    }
     return (int)hipGetLastError();
 }
 
@@ -2204,17 +2456,29 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
     const bool hh_pair = !(ai1 || ai2) && (PZ_HH_PAIR_ROLLOUT == 2 || (PZ_HH_PAIR_ROLLOUT == 1 && a.cfg.normalize_obs == 2));
     if constexpr (MODE == kRollout || MODE == kTape) if (a.n < PZ_TWO_WAVE_MAX_LANES && ((tables && (ai1 || ai2)) || hh_pair)) {
         const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
-        const bool packed = is_packed(a.cfg), obs16 = a.cfg.normalize_obs == 2;
+        const bool packed = is_packed(a.cfg), obs16 = a.cfg.normalize_obs == 2, plain = is_plain(a);
+#define PZ_LAUNCH_ROLLOUT_PAIR_AS(A1, A2, PK, O16, PLAIN)                                                                 \
+    do {                                                                                                                  \
+        if constexpr (PZ_KEEP(kDevRolloutPair, MODE, A1, A2, PK, O16, PLAIN))                                              \
+            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, MODE, PK, O16, PLAIN>), grid, block, 0, stream,                \
+                               PZ_HOT_ARGS(a), a);                                                                        \
+        else                                                                                                              \
+            return PZ_E_CONFIG;                                                                                           \
+    } while (0)
 #define PZ_LAUNCH_ROLLOUT_PAIR(A1, A2)                                                                                    \
     do {                                                                                                                  \
         if (packed && obs16)                                                                                              \
-            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, MODE, true, true>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);      \
+            PZ_LAUNCH_ROLLOUT_PAIR_AS(A1, A2, true, true, false);                                                         \
         else if (packed)                                                                                                  \
-            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, MODE, true, false>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);     \
+            PZ_LAUNCH_ROLLOUT_PAIR_AS(A1, A2, true, false, false);                                                        \
+        else if (obs16 && plain)                                                                                          \
+            PZ_LAUNCH_ROLLOUT_PAIR_AS(A1, A2, false, true, true);                                                         \
         else if (obs16)                                                                                                   \
-            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, MODE, false, true>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);     \
+            PZ_LAUNCH_ROLLOUT_PAIR_AS(A1, A2, false, true, false);                                                        \
+        else if (plain)                                                                                                   \
+            PZ_LAUNCH_ROLLOUT_PAIR_AS(A1, A2, false, false, true);                                                        \
         else                                                                                                              \
-            hipLaunchKernelGGL((rollout_pair_kernel<A1, A2, MODE, false, false>), grid, block, 0, stream, PZ_HOT_ARGS(a), a);    \
+            PZ_LAUNCH_ROLLOUT_PAIR_AS(A1, A2, false, false, false);                                                       \
     } while (0)
         if (ai1 && ai2)
             PZ_LAUNCH_ROLLOUT_PAIR(true, true);
@@ -2227,6 +2491,7 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
             PZ_LAUNCH_ROLLOUT_PAIR(false, false);
 #endif
 #undef PZ_LAUNCH_ROLLOUT_PAIR
+#undef PZ_LAUNCH_ROLLOUT_PAIR_AS
         return (int)hipGetLastError();
     }
 #endif

@@ -1294,10 +1294,13 @@ __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const R
 constexpr int kXchgPitch = 64;      // exchange word k of lane l lives at [k * 64 + l] (10 words: 9 player + decision)
 constexpr int kEarlyPostAt = 1024;  // word offset of the early post {x, draws} inside a region (2 x 64 words)
 
-template <int ROLE, bool AI1, bool AI2>
+// before_barrier(): called once the own player has moved and been posted, in front of the exchange barrier -- what the
+// caller can do with its finished player while the partner wave is still deciding
+template <int ROLE, bool AI1, bool AI2, class BeforeBarrier>
 __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2,
                                                bool live, bool& frozen, int32_t* __restrict__ xchg, int xchg_region,
-                                               int lane, const FlightLut& lut, LandingProbe& after_hit, bool& bold_pending)
+                                               int lane, const FlightLut& lut, LandingProbe& after_hit, bool& bold_pending,
+                                               BeforeBarrier&& before_barrier)
 {
     constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
     constexpr bool kOtherAI = ROLE == 0 ? AI2 : AI1;
@@ -1475,6 +1478,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
         mine[8 * kXchgPitch] = own.hitprev;
         if (kOwnAI) mine[9 * kXchgPitch] = (in_own.xd + 1) | ((in_own.yd + 1) << 2) | (int32_t)(draws_own << 4);
     }
+    before_barrier();
     __syncthreads();
     if (live) {
         const int32_t* theirs = xchg + ROLE * xchg_region + lane;

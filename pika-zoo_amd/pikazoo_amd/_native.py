@@ -11,7 +11,7 @@ from pathlib import Path
 PKG_ROOT = Path(__file__).resolve().parent.parent  # .../pika-zoo_amd
 LIB_PATH = PKG_ROOT / "lib" / "libpikazoo_hip.so"
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PACKED_BYTES_PER_GAME = 36
 SCENERY_WORDS = 75
 STATE_WORDS = 44
@@ -41,6 +41,7 @@ class PzConfig(C.Structure):
         ("episode_stats_mode", C.c_int32),
         ("seed", C.c_uint64),
         ("env_id_base", C.c_int64),
+        ("action_faults", C.c_void_p),  # NULL or a device uint64 counter of out-of-range actions (pikazoo_env.py:182)
     ]
 
 

@@ -10,9 +10,14 @@ of one rank take as long together as one after the other, two of different ranks
 
 :func:`alloc_pair` allocates the pair, probes it, and when the two share a rank walks the allocator on -- spacer
 blocks, a new candidate, probe again -- until a candidate in another rank turns up (or a budget is spent; then the
-last pair is used as it is).  Everything it held on the way is given back.  No result depends on any of this.
+last pair is used as it is).  Everything it held on the way sits in a private memory pool and goes back to the driver
+with it; the process's own cached memory is never touched.  The walk is bounded (32 GiB by default, a quarter of the
+free memory at most), skipped when the device is shared, and ``PIKAZOO_PLACE_TRAJECTORIES=0`` switches the whole
+thing off.  No result depends on any of this.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 
@@ -25,6 +30,9 @@ SPACER_BYTES = 4 << 30         # the physical runs of one rank seen on MI355X bo
 CANDIDATE_BLOCK = 1 << 30      # candidates are carved from blocks of at least this size: a small allocation is put into
                                # whatever hole fits it (usually next to the first tensor), a large one into fresh memory
 MAX_SPACER_BYTES = 96 << 30    # one rank is 96 GB: further than that the allocator has left the first candidate's rank
+                               # (what a caller may ask for with max_spacer_bytes=)
+DEFAULT_SPACER_BUDGET = 32 << 30   # what alloc_pair walks by itself (the driver's bench run needed 8 GiB / 3 candidates)
+OTHER_TENANT_BYTES = 4 << 30   # device memory held by somebody else (another process / rank): above this, no walk
 DISTINCT_BELOW = 0.86          # t(a, b) / (t(a) + t(b)): ~1.0 in one rank, 0.77-0.83 in two (in between: a tensor that
                                # straddles two ranks)
 
@@ -77,16 +85,30 @@ def pair_ratio(a: torch.Tensor, b: torch.Tensor) -> float:
     return t_ab / (t_a + t_b)
 
 
-def pair_write_rate(a: torch.Tensor, b: torch.Tensor) -> float:
-    """GB/s of the k-frame store pattern into both tensors at once (OVERWRITES them): ~7 100 in two ranks, ~5 500 in one."""
+def pair_write_rate(a: torch.Tensor, b: torch.Tensor, seconds: float = 0.02) -> float:
+    """GB/s the k-frame store pattern SUSTAINS into both tensors at once (OVERWRITES them): back-to-back probe launches
+    for at least `seconds`, timed as one region with events on the launch stream -- ~7 000 in two ranks, ~5 500 in one.
+    (A single best-of-3 launch of ~80 us, as in round 3, reads a few per cent low: a kernel measured against it over
+    0.25 s then seems to beat its own ceiling.)"""
     lib = _native.load()
     nbytes = min(_span_bytes(a), _span_bytes(b))
     frame = int(lib.pz_probe_frame_bytes())
+    if nbytes < frame:
+        raise ValueError(f"pair_write_rate needs tensors of at least one probe frame ({frame} bytes)")
     with torch.cuda.device(a.device):
-        raw = torch.cuda.current_stream().cuda_stream
+        stream = torch.cuda.current_stream()
+        raw = stream.cuda_stream
         for _ in range(WARM_LAUNCHES):
             _native.check(lib.pz_probe_write(a.data_ptr(), b.data_ptr(), nbytes, raw), "pz_probe_write")
-        us = _time_probe(lib, a.data_ptr(), b.data_ptr(), nbytes)
+        one = _time_probe(lib, a.data_ptr(), b.data_ptr(), nbytes, reps=1)
+        launches = max(8, int(seconds * 1e6 / max(one, 1.0)) + 1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(launches):
+            _native.check(lib.pz_probe_write(a.data_ptr(), b.data_ptr(), nbytes, raw), "pz_probe_write")
+        e1.record(stream)
+        e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / launches
     return 2 * (nbytes // frame) * frame / (us * 1e-6) / 1e9
 
 
@@ -95,11 +117,45 @@ def _key(a, b):
     return (a.device.index, lo, hi, a.numel() * a.element_size())
 
 
-def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = MAX_SPACER_BYTES):
+def enabled() -> bool:
+    """``PIKAZOO_PLACE_TRAJECTORIES=0`` in the environment switches the placement off for the whole process."""
+    return os.environ.get("PIKAZOO_PLACE_TRAJECTORIES", "1").strip().lower() not in ("0", "false", "off", "no")
+
+
+def reset():
+    """Forget every cached verdict (e.g. after the process has returned memory to the driver)."""
+    _verdicts.clear()
+    _gave_up.clear()
+
+
+def _why_not_walk(device, budget: int):
+    """A reason not to walk the allocator (the pair is then used as allocated), or None.  The walk holds gigabytes for
+    a few milliseconds: it is only done where this process has the device to itself and the memory is plainly there."""
+    if budget < SPACER_BYTES:
+        return "no budget (max_spacer_bytes)"
+    world = os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE")
+    if world and world.isdigit() and int(world) > max(1, torch.cuda.device_count()):
+        return f"{world} ranks on {torch.cuda.device_count()} visible GPU(s): the device is shared"
+    free, total = torch.cuda.mem_get_info(device)
+    others = (total - free) - torch.cuda.memory_reserved(device)
+    if others > OTHER_TENANT_BYTES:
+        return f"{others / (1 << 30):.1f} GiB of the device are held by somebody else"
+    if not hasattr(torch.cuda, "MemPool") or not hasattr(torch.cuda, "use_mem_pool"):
+        return "this torch has no private memory pools (torch.cuda.MemPool)"
+    return None
+
+
+def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = None):
     """Two uninitialised tensors of `shape` that do not share a rank of the device memory, when that can be arranged.
 
-    Returns (a, b).  `last_info` says what happened: ``probed`` (False for small tensors, or while a hipGraph is
-    being captured), ``ratio`` of the pair returned, ``distinct``, ``candidates`` tried, ``spacer_gib`` walked."""
+    Returns (a, b).  `last_info` says what happened: ``probed`` (False for small tensors, while a hipGraph is being
+    captured, or with ``PIKAZOO_PLACE_TRAJECTORIES=0``), ``ratio`` of the pair returned, ``distinct``, ``candidates``
+    tried, ``spacer_gib`` walked, ``walk`` (why the allocator was not walked, if it was not).
+
+    What the walk may hold, for the few milliseconds it lasts: at most `max_spacer_bytes` (default
+    ``DEFAULT_SPACER_BUDGET`` = 32 GiB, and never more than a quarter of the free memory) -- in a PRIVATE memory pool
+    that is released to the driver afterwards, so nothing of the process's own cached memory is touched.  It is not
+    walked at all when somebody else holds memory on the device or ranks share it (``_why_not_walk``)."""
     global last_info
     device = torch.device(device)
     probe = torch.empty((), dtype=dtype).element_size()
@@ -109,7 +165,7 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = MAX_SPACER_BYTES
     nbytes = numel * probe
     info = {"probed": False, "bytes": nbytes}
     last_info = info
-    if nbytes < MIN_BYTES or torch.cuda.is_current_stream_capturing():
+    if nbytes < MIN_BYTES or not enabled() or torch.cuda.is_current_stream_capturing():
         return torch.empty(shape, dtype=dtype, device=device), torch.empty(shape, dtype=dtype, device=device)
 
     def fresh(elems):  # (the front of a block of `elems` elements; the view keeps the block alive)
@@ -126,33 +182,44 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = MAX_SPACER_BYTES
     info.update(probed=True, ratio=ratio, distinct=ratio < DISTINCT_BELOW, candidates=1, spacer_gib=0.0)
     if ratio < DISTINCT_BELOW or (device.index, nbytes) in _gave_up:
         return a, b
-    # walk the allocator on: everything tried stays allocated meanwhile, so that the next candidate is other memory
+    free, _total = torch.cuda.mem_get_info(device)
+    budget = DEFAULT_SPACER_BUDGET if max_spacer_bytes is None else int(max_spacer_bytes)
+    budget = min(budget, free // 4)
+    why = _why_not_walk(device, budget)
+    if why is not None:
+        info["walk"] = why
+        return a, b
+    # walk the allocator on: everything tried stays allocated meanwhile, so that the next candidate is other memory --
+    # all of it in a private pool, which goes back to the driver as a whole
     block_elems = max(numel, CANDIDATE_BLOCK // probe)
     held, walked, tried, found = [], 0, 1, None
+    pool = torch.cuda.MemPool()
     try:
-        while walked < max_spacer_bytes:
+        while walked + SPACER_BYTES <= budget:
             free, _total = torch.cuda.mem_get_info(device)
-            if free < 2 * SPACER_BYTES + 2 * block_elems * a.element_size():
+            if free < 2 * SPACER_BYTES + 2 * block_elems * probe:
+                info["walk"] = "stopped: free memory below two spacers"
                 break
-            held.append(torch.empty(SPACER_BYTES, dtype=torch.uint8, device=device))
+            with torch.cuda.use_mem_pool(pool, device=device):
+                held.append(torch.empty(SPACER_BYTES, dtype=torch.uint8, device=device))
+                cand = fresh(block_elems)  # (a view: keeps its block alive)
             walked += SPACER_BYTES
-            cand = fresh(block_elems)  # (a view: keeps its block alive)
             tried += 1
             r = pair_ratio(a, cand)
-            _verdicts[_key(a, cand)] = r
             if r < DISTINCT_BELOW:
                 found, ratio = cand, r
                 break
             held.append(cand)
             del cand
     except torch.cuda.OutOfMemoryError:
-        pass
+        info["walk"] = "stopped: out of memory"
     if found is not None:
         b = found
+        _verdicts[_key(a, b)] = ratio
     else:
         _gave_up.add((device.index, nbytes))
     held.clear()
-    del held
-    torch.cuda.empty_cache()  # the spacers go back to the driver, not into torch's cache
+    del held, pool  # the pool's unused blocks (spacers, rejected candidates) are released to the driver here; the block
+                    # of a candidate that is kept follows when that tensor dies
     info.update(ratio=ratio, distinct=ratio < DISTINCT_BELOW, candidates=tried, spacer_gib=walked / (1 << 30))
     return a, b

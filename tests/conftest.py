@@ -52,6 +52,9 @@ FULL_FIXTURES = [
     "normal_state_only", "normal_state_inside_ballpos", "normal_state_outside_ballpos",
     "normalize_observation", "record_stats_raw", "full_wrapper_stack", "cfg1_one_env_10k",
 ]
+# wrapper stacks the step kernel cannot fuse: part of the stack runs on the step's outputs (oracle/wrappers_oracle.py,
+# pikazoo_amd/wrappers/*.py)
+UNFUSED_FIXTURES = ["unfused_ballpos_above_normalize", "unfused_stats_between_reward_wrappers", "unfused_doubled_wrappers"]
 DIGEST_FIXTURES = ["digest_human_human", "digest_p2_computer", "digest_both_computer_random_serve"]
 
 

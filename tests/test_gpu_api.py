@@ -95,13 +95,24 @@ def test_batched_api_shapes_and_types():
 def test_step_error_behaviour():
     from pikazoo_amd import pikazoo_v0
 
-    env = pikazoo_v0.env(num_envs=8, seed=1, validate_actions=True)
+    env = pikazoo_v0.env(num_envs=8, seed=1)  # validate_actions is the default
     env.reset()
     ok = torch.zeros(8, dtype=torch.int32, device="cuda:0")
-    with pytest.raises(IndexError):  # the reference's table lookup raises IndexError (pikazoo_env.py:182)
-        env.step({"player_1": ok + 18, "player_2": ok})
+    # the reference's table lookup raises IndexError (pikazoo_env.py:182).  Host values are checked before the launch ...
     with pytest.raises(IndexError):
-        env.step({"player_1": ok, "player_2": ok - 1})
+        env.step({"player_1": [18] * 8, "player_2": [0] * 8})
+    with pytest.raises(IndexError):
+        env.step({"player_1": np.zeros(8, np.int64), "player_2": torch.full((8,), -1)})
+    # ... device tensors inside it: the launch counts, check_actions() asks
+    env.step({"player_1": ok + 18, "player_2": ok})
+    with pytest.raises(IndexError):
+        env.check_actions()
+    env.check_actions()  # (raising cleared the counter)
+    env.step({"player_1": ok, "player_2": ok - 1})
+    with pytest.raises(IndexError):
+        env.check_actions()
+    env.step({"player_1": ok + 17, "player_2": ok})
+    env.check_actions()
     with pytest.raises(KeyError):
         env.step({"player_1": ok})
     with pytest.raises(ValueError):
@@ -114,6 +125,140 @@ def test_step_error_behaviour():
         pikazoo_v0.env(render_mode="human")
     with pytest.raises(RuntimeError):
         pikazoo_v0.env(device="cpu")
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(state_format="packed"), dict(is_player2_computer=True),
+                                dict(is_player2_computer=True, flight_tables=False), dict(num_envs=393216 + 64)])
+def test_out_of_range_actions_are_counted_in_the_launch_and_raised_without_a_sync(kw):
+    """validate_actions (the default): the step kernels count actions outside [0, n_actions) -- every kernel family that
+    reads actions: two waves per 64 games, one wave (the large batch, the scout-wave launch), the packed format, the
+    tape kernels -- and env.step() raises the reference's IndexError (pikazoo_env.py:182) within 2 * validate_every
+    steps without ever blocking on the device; with SimplifyAction the bound is 13."""
+    from pikazoo_amd import pikazoo_v0
+    from pikazoo_amd.wrappers import SimplifyAction
+
+    kw = dict(dict(num_envs=200, seed=2, validate_every=4), **kw)
+    n = kw["num_envs"]
+    env = pikazoo_v0.env(**kw)
+    raw = env.unwrapped
+    env.reset()
+    ok = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    for _ in range(20):
+        env.step({"player_1": ok + 17, "player_2": ok})
+    raw.check_actions()
+    assert int(raw._faults.item()) == 0
+    bad = ok.clone()
+    bad[[3, 70, n - 1]] = torch.tensor([18, -1, 1 << 30], dtype=torch.int32, device="cuda:0")
+    env.step({"player_1": ok, "player_2": bad})
+    assert int(raw._faults.item()) == 3  # one count per offending game
+    with pytest.raises(IndexError):  # nobody asks: it surfaces within 2 * validate_every steps
+        for _ in range(2 * raw.validate_every):
+            env.step({"player_1": ok, "player_2": ok})
+    for _ in range(3 * raw.validate_every):  # ... once
+        env.step({"player_1": ok, "player_2": ok})
+    # the tape launches check what they park
+    if n % 8 == 0 or n == 200:
+        tape = torch.zeros((70, 2, n), dtype=torch.int32, device="cuda:0")
+        raw.step_many(tape)
+        raw.check_actions()
+        tape[66, 0, 5] = 18   # in the second chunk of 64 frames
+        tape[2, 1, 9] = 255   # a byte that would park as an action, 255, and 256 -> 0
+        tape[3, 1, 10] = 256
+        raw.step_many(tape)
+        with pytest.raises(IndexError):
+            raw.check_actions()
+    env = SimplifyAction(pikazoo_v0.env(**kw))
+    env.reset()
+    env.step({"player_1": ok + 12, "player_2": ok})
+    env.unwrapped.check_actions()
+    env.step({"player_1": ok + 13, "player_2": ok})
+    with pytest.raises(IndexError):
+        env.unwrapped.check_actions()
+    # switched off: nothing is counted, nothing raises (the range is then the caller's contract)
+    off = pikazoo_v0.env(**dict(kw, validate_actions=False))
+    off.reset()
+    off.step({"player_1": bad, "player_2": ok})
+    off.check_actions()
+    assert off._faults is None
+
+
+def test_wrappers_outside_the_kernel_second_instances_and_the_scalar_api():
+    """What the reference fixtures do not reach of the wrappers' torch forms (pikazoo_amd/wrappers/*.py, `fused` False):
+    a second RecordEpisodeStatistics and a second SimplifyAction (its map composed with the fused one; an entry the
+    reference would raise IndexError on becomes an out-of-range action), NormalizeObservation on int16 observations and
+    the scalar API's Python arithmetic -- each against the numpy restatement of the reference's classes
+    (oracle/wrappers_oracle.py) on the same stack."""
+    from oracle.wrappers_oracle import WrappedOracle
+    from pikazoo_amd import pikazoo_v0
+    import pikazoo_amd.wrappers as W
+
+    table = [0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01]
+    stack = [("RecordEpisodeStatistics", {}), ("RewardByBallPosition", dict(additional_reward=table, x_line=216, y_line=176)),
+             ("RewardByBallPosition", dict(additional_reward=table, x_line=100, y_line=200)), ("RecordEpisodeStatistics", {}),
+             ("NormalizeObservation", {})]
+    n = 96
+    env = pikazoo_v0.env(num_envs=n, seed=5, winning_score=1, observation_dtype=torch.int16)
+    for name, kw in stack:
+        env = getattr(W, name)(env, **{k: (tuple(v) if isinstance(v, list) else v) for k, v in kw.items()})
+    raw = env.unwrapped
+    assert raw._unfused == ["RewardByBallPosition", "RecordEpisodeStatistics", "NormalizeObservation"]
+    ref = WrappedOracle(n, stack, seed=5, winning_score=1)
+    obs, _ = env.reset()
+    o1, _ = ref.reset()
+    assert obs["player_1"].dtype == torch.float32 and np.array_equal(obs["player_1"].cpu().numpy(), o1.astype(np.float32))
+    for t in range(400):
+        acts = raw.random_actions(3, t)
+        obs, rew, term, trunc, infos = env.step(acts)
+        o, r, tm, ep = ref.step(acts["player_1"].cpu().numpy(), acts["player_2"].cpu().numpy())
+        assert np.array_equal(raw.state.cpu().numpy(), ref.raw_state)
+        assert np.array_equal(obs["player_2"].cpu().numpy(), o[1].astype(np.float32))
+        np.testing.assert_allclose(rew["player_1"].cpu().numpy(), r[0], rtol=0, atol=1e-6)
+        done = tm.astype(bool)
+        assert np.array_equal(term["player_1"].cpu().numpy(), done)
+        if done.any():  # the OUTER statistics (unfused): sums of the doubly wrapped reward
+            assert np.array_equal(infos["player_1"]["episode"]["l"].cpu().numpy()[done], ep["l"][done])
+            np.testing.assert_allclose(infos["player_2"]["episode"]["r"].cpu().numpy()[done], ep["r"][1][done], rtol=0, atol=2e-6)
+    assert int(term["player_1"].sum()) >= 0 and ref.raw_state[42].sum() >= 0
+    # the inner (fused, raw-reward) statistics are still the kernel's
+    assert raw.episode_lengths is not None and env.episode_lengths["player_1"] is not raw.episode_lengths
+
+    # a second SimplifyAction: map(map(a)); a in {5, 6, 9, 11, 12} maps to 13 or more first -> IndexError in the reference
+    env = W.SimplifyAction(W.SimplifyAction(pikazoo_v0.env(num_envs=8, seed=1)))
+    plain = W.SimplifyAction(pikazoo_v0.env(num_envs=8, seed=1))
+    env.reset(), plain.reset()
+    m1 = torch.tensor([0, 1, 2, 3, 4, 6, 7, 10], dtype=torch.int32, device="cuda:0")   # = map_1 of 0..7 except 5, 6
+    a = torch.tensor([0, 1, 2, 3, 4, 7, 8, 10], dtype=torch.int32, device="cuda:0")
+    inner = torch.tensor([0, 1, 2, 3, 4, 10, 11, 13], dtype=torch.int32, device="cuda:0")  # map_1[a]: all < 13 but the last
+    a, inner = a[:7], inner[:7]
+    pad = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    env.step({"player_1": torch.cat([a, pad]), "player_2": torch.cat([a * 0, pad])})
+    plain.step({"player_1": torch.cat([inner, pad]), "player_2": torch.cat([inner * 0, pad])})
+    assert torch.equal(env.unwrapped.state, plain.unwrapped.state)
+    env.unwrapped.check_actions()
+    env.step({"player_1": torch.full((8,), 12, dtype=torch.int32, device="cuda:0"), "player_2": torch.cat([a * 0, pad])})
+    with pytest.raises(IndexError):  # map_1[12] = 16: not an action of the inner SimplifyAction
+        env.unwrapped.check_actions()
+    with pytest.raises(IndexError):  # host values: on the step itself
+        env.step({"player_1": [12] * 8, "player_2": [0] * 8})
+
+    # frozen games and the scalar API: one env, Python numbers, the reference's own loop shape
+    stack = [("RewardByBallPosition", dict(additional_reward=table, x_line=216, y_line=176)), ("RecordEpisodeStatistics", {}),
+             ("RewardInNormalState", dict(reward=0.5))]
+    env = pikazoo_v0.env(num_envs=1, scalar_api=True, seed=11, winning_score=1)
+    for name, kw in stack:
+        env = getattr(W, name)(env, **{k: (tuple(v) if isinstance(v, list) else v) for k, v in kw.items()})
+    ref = WrappedOracle(1, stack, seed=11, winning_score=1)
+    env.reset(), ref.reset()
+    t, raw = 0, env.unwrapped
+    while env.agents:
+        acts = raw.random_actions(3, t)
+        a1, a2 = int(acts["player_1"][0]), int(acts["player_2"][0])
+        obs, rew, term, trunc, infos = env.step({"player_1": a1, "player_2": a2})
+        o, r, tm, ep = ref.step([a1], [a2])
+        assert isinstance(rew["player_1"], float) and abs(rew["player_1"] - r[0][0]) < 1e-6 and abs(rew["player_2"] - r[1][0]) < 1e-6
+        assert term["player_1"] == bool(tm[0]) and ("episode" in infos["player_1"]) == bool(tm[0])
+        t += 1
+    assert infos["player_1"]["episode"]["l"] == t == int(ep["l"][0]) and abs(infos["player_2"]["episode"]["r"] - ep["r"][1][0]) < 2e-6
 
 
 def test_wrappers_surface():
@@ -141,8 +286,8 @@ def test_wrappers_surface():
         assert torch.equal(rew["player_2"], (-base + tab[4 + zone]).float())
     with pytest.raises(AssertionError):
         RewardByBallPosition(pikazoo_v0.env(num_envs=2), additional_reward=(1, 2, 3))
-    with pytest.raises(RuntimeError):
-        SimplifyAction(env)
+    # a second SimplifyAction is what it is in the reference: a second map, applied outside the kernel
+    assert SimplifyAction(env).fused is False and env.unwrapped._unfused == ["SimplifyAction"]
 
 
 def test_remaining_wrappers_surface():
@@ -178,14 +323,13 @@ def test_remaining_wrappers_surface():
     assert seen_done > 0
     assert env.episode_lengths["player_1"].shape == (n,)
 
-    # order rules that cannot be fused are refused, not silently reinterpreted
-    with pytest.raises(NotImplementedError):
-        RewardByBallPosition(NormalizeObservation(pikazoo_v0.env(num_envs=4)), additional_reward=(0,) * 8)
-    with pytest.raises(NotImplementedError):
-        e = RecordEpisodeStatistics(RewardInNormalState(pikazoo_v0.env(num_envs=4), 0.1))
-        RewardByBallPosition(e, additional_reward=(0,) * 8)
-    with pytest.raises(RuntimeError):
-        NormalizeObservation(NormalizeObservation(pikazoo_v0.env(num_envs=4)))
+    # stack orders the kernel cannot fuse are neither refused nor reinterpreted: the wrapper applies itself to the step's
+    # outputs (trajectories against the reference: tests/test_gpu_parity.py, tests/golden/unfused_*.npz)
+    assert RewardByBallPosition(NormalizeObservation(pikazoo_v0.env(num_envs=4)), additional_reward=(0,) * 8).fused is False
+    e = RecordEpisodeStatistics(RewardInNormalState(pikazoo_v0.env(num_envs=4), 0.1))
+    assert e.fused and RewardByBallPosition(e, additional_reward=(0,) * 8).fused is False
+    twice = NormalizeObservation(NormalizeObservation(pikazoo_v0.env(num_envs=4)))
+    assert twice.fused is False and twice.env.fused and twice.unwrapped._unfused == ["NormalizeObservation"]
 
     # single-agent view: the other side plays the seeded device policy
     single = ConvertSingleAgent(pikazoo_v0.env(num_envs=64, seed=4, winning_score=2), "player_2", opponent_seed=9)
@@ -400,6 +544,67 @@ def test_trajectory_tensors_are_placed_by_measurement_and_results_do_not_depend_
     again = a.rollout_random(2, 32, t0=36)
     if {t.data_ptr() for t in again["_obs"]} == ptrs:
         assert a.trajectory_placement.get("cached") is True
+
+
+def test_placement_gives_up_promptly_and_leaves_the_process_memory_alone(monkeypatch):
+    """The allocator walk of placement.alloc_pair is bounded and optional: with no budget, with the free memory 'below
+    two spacers', with another tenant on the device, with ranks sharing it, or switched off by the environment it
+    returns the first pair at once -- no spacer allocated, torch's cached memory untouched, no OOM -- and says why;
+    a walk that does run keeps its spacers in a private pool (the process's reserved memory is what it was, plus at
+    most the one candidate block that is kept)."""
+    import time
+
+    from pikazoo_amd import placement
+
+    dev = torch.device("cuda:0")
+    shape, dt = (32, 65536, 35), torch.int32
+    placement.reset()
+    keep = torch.empty(1 << 28, dtype=torch.uint8, device=dev)  # something of ours in torch's cache
+    del keep
+    cached = torch.cuda.memory_reserved(dev)
+    assert cached >= 1 << 28
+
+    def run(**kw):
+        placement.reset()
+        t0 = time.perf_counter()
+        a, b = placement.alloc_pair(shape, dt, dev, **kw)
+        took, info = time.perf_counter() - t0, dict(placement.last_info)
+        assert a.shape == b.shape == shape and a.data_ptr() != b.data_ptr()
+        return info, took
+
+    info, took = run(max_spacer_bytes=0)
+    assert info["probed"] and info["candidates"] == 1 and info["spacer_gib"] == 0.0 and took < 2.0
+    if not info["distinct"]:
+        assert "budget" in info["walk"]
+    real = torch.cuda.mem_get_info
+    # free memory below two spacers + two candidate blocks: the walk stops before its first allocation
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (9 << 30, real(d)[1]))
+    info, took = run()
+    assert info["candidates"] == 1 and info["spacer_gib"] == 0.0 and took < 2.0
+    # somebody else holds memory on the device
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (real(d)[0] - (8 << 30), real(d)[1]))
+    info, took = run()
+    assert info["candidates"] == 1 and (info["distinct"] or "somebody else" in info["walk"])
+    monkeypatch.setattr(torch.cuda, "mem_get_info", real)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")  # eight ranks on this one GPU
+    info, took = run()
+    assert info["candidates"] == 1 and (info["distinct"] or "shared" in info["walk"])
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    monkeypatch.setenv("PIKAZOO_PLACE_TRAJECTORIES", "0")
+    info, took = run()
+    assert info == {"probed": False, "bytes": 32 * 65536 * 35 * 4}
+    monkeypatch.delenv("PIKAZOO_PLACE_TRAJECTORIES")
+    # a real walk: whatever it held is back with the driver afterwards, torch's own cache was never emptied
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_reserved(dev)
+    placement.reset()
+    a, b = placement.alloc_pair(shape, dt, dev)
+    info = dict(placement.last_info)
+    torch.cuda.synchronize()
+    grown = torch.cuda.memory_reserved(dev) - before
+    assert grown <= 2 * (32 * 65536 * 35 * 4) + (2 << 30), (grown, info)   # the pair (+ one 1 GiB candidate block), no spacer
+    assert torch.cuda.memory_reserved(dev) >= cached                       # (nobody called empty_cache on the process)
+    assert info["spacer_gib"] <= placement.DEFAULT_SPACER_BUDGET / (1 << 30)
 
 
 def test_step_through_the_bound_entry_point_equals_pz_step():

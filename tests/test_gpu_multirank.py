@@ -120,6 +120,29 @@ def test_bench_with_two_ranks_prints_the_aggregate_line():
         assert p["launch_us"] > 0 and p["value"] > 0 and p["parity_bit_exact"] is True  # both ends of the job checked
 
 
+def test_bench_with_four_ranks_on_one_device_shards_like_config_4():
+    """`python bench.py --gpus 4 --num-envs 65536` -- BASELINE config 4's per-rank shard at the largest rank count the
+    one-GPU box allows (six processes may have its card open: four ranks, their launcher and this one -- five ranks were
+    killed by the box's process guard; the eight-rank integers are covered over gloo on the CPU,
+    tests/test_cabi_and_host.py): `per_rank` has a row per rank, rank r's games start at r * 65 536 (the first and the
+    last rank replay theirs on the oracle under those ids), the job counts 4 x 65 536 games."""
+    ranks = 4
+    env = dict(os.environ, PZ_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", str(ranks), "--num-envs", "65536", "--steps", "16", "--warmup", "4",
+           "--burn-in", "64", "--min-time", "0.02", "--dist-backend", "gloo", "--cpu-threads", "2", "--no-configs",
+           "--check-lanes", "256"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(REPO))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == ranks and out["ranks"] == ranks and out["rccl_ranks"] == 0 and out["scaling"] == "weak"
+    assert out["config"]["num_envs_total"] == ranks * 65536 and out["config"]["num_envs_per_gpu"] == 65536
+    assert [p["rank"] for p in out["per_rank"]] == list(range(ranks))
+    assert [p["env_id_base"] for p in out["per_rank"]] == [k * 65536 for k in range(ranks)]
+    assert out["per_rank"][0]["parity_bit_exact"] is True and out["per_rank"][-1]["parity_bit_exact"] is True
+    assert all(p["parity_bit_exact"] is None for p in out["per_rank"][1:-1])
+    assert np.isclose(out["value"], ranks * 65536 / (out["ms_per_step"] * 1e-3), rtol=1e-6)
+
+
 def test_bench_under_the_drivers_launcher_and_rccl_request_on_one_gpu():
     """The driver's own launch line (torch.distributed.run around bench.py), asking for RCCL: two ranks on one GPU is
     what RCCL refuses, so all ranks agree -- before any of them touches RCCL -- to leave the counters on gloo, and the

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import DIGEST_FIXTURES, FULL_FIXTURES, golden_state, load_golden, oracle_config_from_meta
+from conftest import DIGEST_FIXTURES, FULL_FIXTURES, UNFUSED_FIXTURES, golden_state, load_golden, oracle_config_from_meta
 
 pytestmark = pytest.mark.gpu
 
@@ -112,6 +112,51 @@ def test_hip_matches_reference_trajectory(name, tables, fmt):
         np.testing.assert_allclose(h_rew, d["rew"], rtol=0, atol=1e-6)
     else:
         assert np.array_equal(h_rew, d["rew"].astype(np.int32))
+
+
+@pytest.mark.parametrize("fmt", ["int32", "packed"])
+@pytest.mark.parametrize("name", UNFUSED_FIXTURES)
+def test_wrapper_stacks_the_kernel_cannot_fuse_match_the_reference(name, fmt):
+    """The reference composes its wrappers in any order.  Where an order cannot be a kernel branch -- RewardByBallPosition
+    above NormalizeObservation (it then reads the normalized coordinates), RecordEpisodeStatistics between two reward
+    wrappers, a second RewardByBallPosition / RewardInNormalState / NormalizeObservation -- the wrapper class applies
+    itself to the step's outputs with torch operations, outside everything that is fused: same trajectories as the
+    reference's own stack (tests/golden/unfused_*.npz), nothing raises NotImplementedError."""
+    d = load_golden(name)
+    meta = d["meta"]
+    env = make_env(meta, state_format=fmt)
+    raw = env.unwrapped
+    assert raw._unfused, "this stack is expected to leave something outside the kernel"
+    T, L = meta["steps"], meta["lanes"]
+    assert np.array_equal(cpu(raw.state), d["state_ctor"])
+    obs, infos = env.reset()
+    assert np.array_equal(cpu(raw.state), d["state0"])
+    for i, ag in enumerate(raw.possible_agents):
+        np.testing.assert_allclose(cpu(obs[ag]).astype(np.float64), d["obs_reset"][:, i], rtol=0, atol=1e-6)
+    acts = torch.as_tensor(d["actions"].astype(np.int32), device=raw.device)
+    has_stats = "ep_l" in d
+    for t in range(T):
+        obs, rew, term, trunc, infos = env.step({"player_1": acts[t, 0], "player_2": acts[t, 1]})
+        assert np.array_equal(cpu(raw.state), golden_state(d, t)), (name, t)
+        assert np.array_equal(cpu(term["player_1"]).astype(np.uint8), d["term"][t])
+        for i, ag in enumerate(raw.possible_agents):
+            # float32 here, float64 in the reference: a normalized observation is the float32 rounding of its quotient,
+            # a reward within 1e-6
+            assert np.array_equal(cpu(obs[ag]).astype(np.float32), d["obs"][t, i].astype(np.float32)), (name, t)
+            np.testing.assert_allclose(cpu(rew[ag]).astype(np.float64), d["rew"][t, i], rtol=0, atol=1e-6)
+        if has_stats:
+            done = d["ep_l"][t] >= 0
+            if done.any():
+                assert np.array_equal(cpu(infos["player_1"]["episode"]["l"])[done], d["ep_l"][t][done])
+                for i, ag in enumerate(raw.possible_agents):
+                    # float64 sums of float32 rewards (each within half a float32 ulp of the reference's float64 reward:
+                    # 6e-8 relative -- the integer table of the doubled stack pays up to 8 per step, its returns reach 160)
+                    np.testing.assert_allclose(cpu(infos[ag]["episode"]["r"])[done], d["ep_r"][t][i][done], rtol=1e-7, atol=2e-6)
+    # the k-frame launches return the kernel's own outputs: refused while part of the stack runs outside it
+    with pytest.raises(RuntimeError):
+        raw.rollout_random(1, 4)
+    with pytest.raises(RuntimeError):
+        env.step_random(1)
 
 
 @pytest.mark.parametrize("name", DIGEST_FIXTURES)
@@ -608,8 +653,9 @@ def test_step_many_equals_single_steps(oracle):
         a.unwrapped.step_many(torch.zeros((2, 2, n + 1), dtype=torch.int32, device="cuda:0"))
     va = make_env(num_envs=8, validate_actions=True)
     va.reset()
-    with pytest.raises(IndexError):
-        va.unwrapped.step_many(torch.full((2, 2, 8), 18, dtype=torch.int32, device="cuda:0"))
+    va.unwrapped.step_many(torch.full((2, 2, 8), 18, dtype=torch.int32, device="cuda:0"))
+    with pytest.raises(IndexError):  # (counted by the launch as it parks the tape: tests/test_gpu_api.py)
+        va.unwrapped.check_actions()
 
 
 @pytest.mark.parametrize("fmt", ["int32", "packed"])

@@ -8,7 +8,7 @@ and terminations, at every step.
 import numpy as np
 import pytest
 
-from conftest import DIGEST_FIXTURES, FULL_FIXTURES, golden_state, load_golden, oracle_config_from_meta
+from conftest import DIGEST_FIXTURES, FULL_FIXTURES, UNFUSED_FIXTURES, golden_state, load_golden, oracle_config_from_meta
 
 
 def test_philox_known_answers(oracle):
@@ -100,6 +100,50 @@ def test_oracle_matches_reference_trajectory(oracle, name):
                 np.testing.assert_allclose(rew[i], d["rew"][t, i], rtol=0, atol=1e-6)
         else:
             assert np.array_equal(rew[0], d["rew"][t, 0]) and np.array_equal(rew[1], d["rew"][t, 1])
+    assert d["term"].sum() == meta["episodes"]
+
+
+WRAPPED_FUSABLE = ["cfg5_wrappers_float", "wrappers_int_table", "normal_state_inside_ballpos", "normal_state_outside_ballpos",
+                   "normalize_observation", "record_stats_raw", "full_wrapper_stack"]
+
+
+@pytest.mark.parametrize("name", UNFUSED_FIXTURES + WRAPPED_FUSABLE)
+def test_wrapper_restatement_matches_reference_on_any_stack_order(oracle, name):
+    """oracle/wrappers_oracle.py -- every wrapper of a stack applied in numpy to the outputs of the UNWRAPPED oracle, in
+    the stack's own order -- against the reference: on the stacks the kernel cannot fuse (RewardByBallPosition above
+    NormalizeObservation, statistics between two reward wrappers, doubled wrappers: tests/golden/unfused_*.npz) and,
+    to tie it to the fused restatement in pz_oracle.c, on the fusable ones too.  float64 like the reference: observations
+    and rewards must agree to the last bit or two of a double."""
+    from oracle.ref_capture import wrapper_stack
+    from oracle.wrappers_oracle import WrappedOracle
+
+    d = load_golden(name)
+    meta = d["meta"]
+    kw = meta["env_kwargs"]
+    env = WrappedOracle(meta["lanes"], wrapper_stack(meta["wrappers"]), winning_score=kw.get("winning_score", 15),
+                        serve=kw.get("serve", "winner"), is_player1_computer=kw.get("is_player1_computer", False),
+                        is_player2_computer=kw.get("is_player2_computer", False), seed=meta["seed"],
+                        env_id_base=meta["env_id_base"])
+    assert np.array_equal(env.raw_state, d["state_ctor"])
+    o1, o2 = env.reset()
+    assert np.array_equal(env.raw_state, d["state0"])
+    np.testing.assert_allclose(o1, d["obs_reset"][:, 0], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(o2, d["obs_reset"][:, 1], rtol=0, atol=1e-15)
+    has_stats = "ep_l" in d
+    for t in range(meta["steps"]):
+        a = d["actions"][t].astype(np.int32)
+        obs, rew, term, episode = env.step(a[0], a[1])
+        assert np.array_equal(env.raw_state, golden_state(d, t)), (name, t)
+        assert np.array_equal(term, d["term"][t]), (name, t)
+        for i in range(2):
+            np.testing.assert_allclose(obs[i], d["obs"][t, i], rtol=0, atol=1e-15, err_msg=f"{name} step {t}")
+            np.testing.assert_allclose(rew[i], d["rew"][t, i], rtol=0, atol=1e-12, err_msg=f"{name} step {t}")
+        if has_stats:
+            done = d["ep_l"][t] >= 0
+            assert np.array_equal(done, term.astype(bool))
+            if done.any():
+                assert np.array_equal(episode["l"][done], d["ep_l"][t][done])
+                np.testing.assert_allclose(episode["r"][:, done], d["ep_r"][t][:, done], rtol=0, atol=1e-9)
     assert d["term"].sum() == meta["episodes"]
 
 

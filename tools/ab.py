@@ -2,7 +2,7 @@
 """A/B timing of kernel build variants (diagnostic; cdna_hip_programming.md rule 24: interleaved
 rounds in ONE process, median and min reported).
 
-    python tools/ab.py --build name1=-DFLAG1 name2="-DFLAG2 -DFLAG3" ...   # here: cross-compile variants
+    python tools/ab.py --build [--common "-DPZ_DEV_SUBSET=705"] name1=-DFLAG1 name2="-DFLAG2 -DFLAG3" ...   # here: cross-compile variants
     python tools/ab.py [--ai] [--n 65536] [--rollout K] name1 name2 ...    # on the GPU box: time them
                                                                            # (--rollout: pz_rollout_random, K frames/launch)
     a name with the suffix "+t" runs that library WITH the flight look-up tables (pz_flight_tables), "+p" on the
@@ -35,11 +35,20 @@ def build(name, flags):
 def main():
     args = sys.argv[1:]
     if args and args[0] == "--build":
+        # --common "-DPZ_DEV_SUBSET=bits": flags for every variant incl. base (pz_kernels.hip: keep only the kernel
+        # families the run will launch -- seconds instead of 100 s per variant); the variants compile in parallel
+        from concurrent.futures import ThreadPoolExecutor
+
         LIBDIR.mkdir(exist_ok=True)
-        build("base", "")
-        for spec in args[1:]:
-            name, _, flags = spec.partition("=")
-            build(name, flags)
+        specs = args[1:]
+        common = ""
+        if "--common" in specs:
+            at = specs.index("--common")
+            common = specs[at + 1]
+            del specs[at:at + 2]
+        jobs = [("base", common)] + [(name, f"{common} {flags}") for name, _, flags in (s.partition("=") for s in specs)]
+        with ThreadPoolExecutor(max_workers=6) as pool:
+            list(pool.map(lambda j: build(*j), jobs))
         return
     import torch
     from pikazoo_amd import _native
@@ -53,8 +62,11 @@ def main():
     tape = "--tape" in args  # with --rollout K: pz_step_many on an action tape instead of pz_rollout_random
     names = [a for a in args if not a.startswith("--") and not a.isdigit()]
     no_check = "--no-check" in args  # variants that change the stored state legitimately
-    if "base" not in names:
+    # the variant every other one is compared with: "base", or the first "base+..." given (e.g. base+t: with the tables)
+    ref = "base" if "base" in names else next((nm for nm in names if nm.startswith("base+")), None)
+    if ref is None:
         names = ["base"] + names
+        ref = "base"
     dev = torch.device("cuda:0")
     P = C.c_void_p
     libs = {}
@@ -104,7 +116,7 @@ def main():
     slices = int(args[args.index("--slices") + 1]) if "--slices" in args else 64
     acts = torch.randint(0, 13 if wrappers else 18, (slices, 2, n), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    base = libs["base"]
+    base = libs[ref]
     tables = None
     if any("t" in mods(nm) for nm in names):
         t_land = torch.empty(base.pz_flight_table_bytes(0), dtype=torch.uint8, device=dev)
@@ -153,8 +165,9 @@ def main():
             return max(1, steps // rollout) * rollout
         for t in range(steps):
             a = acts[t % slices]
-            lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
-                        obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), None, tb, stream)
+            rc = lib.pz_step(state.data_ptr(), n, n, C.byref(cfg), a[0].data_ptr(), a[1].data_ptr(), obs[0].data_ptr(),
+                             obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), term.data_ptr(), None, tb, stream)
+            assert rc == 0, (nm, rc)  # (-3: a PZ_DEV_SUBSET build without this launch's kernel family)
         return steps
 
     snapshots = {}
@@ -173,8 +186,8 @@ def main():
         finals[nm] = ((t_obs[0].clone(), t_obs[1].clone(), t_rew[0].clone(), t_term.clone()) if rollout
                       else (o[0][:n].to(torch.int32), o[1][:n].to(torch.int32), rew[0].clone(), term.clone()))
     for nm in names:
-        same = all(torch.equal(a, b) for a, b in zip(finals[nm], finals["base"]))
-        print(f"  {nm}: trajectory (observations, rewards, terminations) identical to base: {same}")
+        same = all(torch.equal(a, b) for a, b in zip(finals[nm], finals[ref]))
+        print(f"  {nm}: trajectory (observations, rewards, terminations) identical to {ref}: {same}")
     # The K launches of a round are captured once per variant in a hipGraph and replayed: an eager ctypes launch
     # costs the host ~7 us, which would hide every kernel faster than that ("--eager" keeps the direct calls).
     # (a k-frame round must be long enough for the clocks to settle: 12 launches = 1 ms was not -- 3 200 frames by default)
