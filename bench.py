@@ -473,6 +473,7 @@ def measure_rollout_api(args, shard, device, k=32, tape=False, p2_computer=False
         return raw.step_many(tapes[j % 16], out=out) if tape else raw.rollout_random(ACTION_SEED, k, t0=j * k, out=out)
 
     out = call(0, None)
+    placed = dict(raw.trajectory_placement)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for j in range(8):
@@ -494,7 +495,7 @@ def measure_rollout_api(args, shard, device, k=32, tape=False, p2_computer=False
     torch.cuda.synchronize(device)
     us = ev0.elapsed_time(ev1) * 1e3 / (calls * k)
     return {"us_per_frame": us, "value": raw.num_envs / (us * 1e-6), "host_us_per_call": host / calls * 1e6,
-            "calls": calls, "k": k}
+            "calls": calls, "k": k, "placement": placed}
 
 
 def measure_policy_in_the_loop(args, shard, device, launches=2048, fused=False):

@@ -51,9 +51,6 @@ constexpr int kWaveObsVecs = (int)(kWaveObsBytes / 16);   // 560 16-byte pieces
 #ifndef PZ_DEV_FORCE_PLAIN
 #define PZ_DEV_FORCE_PLAIN false  // (diagnostic: every k-frame kernel compiled as its PLAIN form)
 #endif
-#ifndef PZ_AI_STATE_FIRST
-#define PZ_AI_STATE_FIRST 0  // (A/B switch: a computer-player launch writes its state in front of its observation rows)
-#endif
 #ifndef PZ_EARLY_OWN_STORES
 #define PZ_EARLY_OWN_STORES 2  // pair_body: what the human player's wave stores in front of the exchange barrier (0: nothing)
 #endif
@@ -1388,12 +1385,12 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     // partner (tools/stamps.py): while it waits it puts on their way (1) its own player's columns -- final once it has
     // moved; the collision flag follows behind the barrier -- (interleaved A/B, config 3, cold tape: 8.58 -> 8.44 us per
     // launch; human vs human, where nobody waits, the same stores gained nothing in round 2)
-    // (3, A/B only: the computer's wave stores its player in front of the barrier too)
-    constexpr bool kEarlyOwn = PZ_EARLY_OWN_STORES != 0 && !PACKED && (AI1 != AI2) && (!kOwnAI || PZ_EARLY_OWN_STORES >= 3);
+    // (the computer's wave doing the same with its player costs: 8.36 -> 8.54, profiles/r04_experiments/)
+    constexpr bool kEarlyOwn = PZ_EARLY_OWN_STORES != 0 && !PACKED && (AI1 != AI2) && !kOwnAI;
     // ... and (2) the ball's position, trail and rotation: final once the world step has run (a ball-player collision
     // changes velocities, power-hit flag and punch_effect_x only) -- the human player's wave stores all seven, the
     // computer's wave none of them (8.44 -> 8.40; hot tape 8.30 -> 8.17 -> 8.15: profiles/r04_experiments/)
-    constexpr bool kEarlyBall = kEarlyOwn && !kOwnAI && PZ_EARLY_OWN_STORES >= 2;
+    constexpr bool kEarlyBall = kEarlyOwn && PZ_EARLY_OWN_STORES >= 2;
     constexpr bool kPartnerStoresBall = PZ_EARLY_OWN_STORES >= 2 && !PACKED && (AI1 != AI2) && kOwnAI;
     int coll_before = 0;
     auto before_barrier = [&]() {
@@ -1516,8 +1513,8 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     };
     // Interleaved A/B (tools/ab.py, us per launch, state first | observations first): human vs human 7.14 | 7.27,
     // player 2 = computer 8.58 | 8.41 -- the observation tensors are three quarters of the written bytes, and in the
-    // computer-player launch the waves reach their stores less evenly.
-    if ((AI1 || AI2) && !PZ_AI_STATE_FIRST) {
+    // computer-player launch the waves reach their stores less evenly (again with round 4's early stores: 8.36 | 8.43).
+    if (AI1 || AI2) {
         store_observations();
         store_state();
     } else {

@@ -1314,6 +1314,9 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     bool bold_late = false;       // the computer's round-start boldness, drawn behind the gathers' issue
     uint32_t bold_counter = 0u;
     PZ_FRAME_STAMP(0);
+    // (Moving the ball first and issuing the computer's two gathers in front of the players' round start and the action
+    // decode -- the gathers depend on the ball columns, the round flags and the serve only -- was built in round 4 and
+    // lost: 8.36 -> 8.49 us per launch, packed 7.28 -> 7.54, profiles/r04_experiments/ab_early_gather_*.log.)
     if (active) {
         if (g.e.round_ended) {  // reset (:149-164) or new round (:176-180); game_ended implies round_ended
             if (g.e.game_ended) {

@@ -57,12 +57,22 @@ def _shares_a_gpu(rank: int, world: int, index: int):
     return len(set(everyone)) < world
 
 
-def _start_rccl(rank: int, world: int, index: int):
-    """This rank's attempt at an RCCL group over all ranks: (group or None, why not)."""
+def _device_ready(index: int):
+    """This rank's own precondition for RCCL: (ok, why not)."""
     try:
         if not torch.cuda.is_available():
-            raise RuntimeError("no HIP device visible")
+            return False, "no HIP device visible"
         torch.cuda.set_device(index)
+        return True, None
+    except Exception as exc:  # noqa: BLE001
+        return False, f"{type(exc).__name__}: {exc}"[:300]
+
+
+def _start_rccl(rank: int, world: int, index: int):
+    """This rank's attempt at an RCCL group over all ranks: (group or None, why not).  `dist.new_group` is a collective:
+    every rank calls this or none does (init_from_env agrees on that over gloo first).  A probe all-reduce that HANGS
+    inside RCCL is not caught here: the watchdog of the process group aborts the job after its timeout."""
+    try:
         dev = torch.device("cuda", index)
         group = dist.new_group(backend="nccl", timeout=timedelta(seconds=120))
         probe = torch.ones(1, dtype=torch.int64, device=dev)  # the communicator works before anything is timed
@@ -84,7 +94,10 @@ def init_from_env(backend: str | None = None, device_index: int | None = None) -
     `backend` "nccl" (the default on a GPU box) an RCCL group over all ranks is added for the counters.  Whether
     RCCL is used is decided COLLECTIVELY: every rank reports over gloo whether its communicator came up and its
     probe all-reduce gave the world size, and if any rank failed, all of them leave the counters on gloo and say
-    so (`fallback_note`, `rccl_ranks() == 0`) -- no rank is ever left waiting in a rendezvous the others skipped."""
+    so (`fallback_note`, `rccl_ranks() == 0`).  The preconditions (a usable device on every rank, no two ranks on one GPU)
+    are agreed on over gloo first, so either every rank enters RCCL's rendezvous or none does; what is NOT covered is an
+    RCCL call that hangs instead of failing -- the process group's watchdog then aborts the job.  (`_shares_a_gpu` compares
+    host name, the *_VISIBLE_DEVICES strings and the device index: two hosts of the same name would read as one.)"""
     global _COUNTERS, _FALLBACK_NOTE
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -99,7 +112,14 @@ def init_from_env(backend: str | None = None, device_index: int | None = None) -
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=180))
         if backend == "nccl":
             index = local_rank if device_index is None else int(device_index)
-            if _shares_a_gpu(rank, world, index):
+            # every precondition is agreed on over gloo BEFORE anybody enters RCCL's own rendezvous (dist.new_group is a
+            # collective: a rank that skipped it would leave the others waiting in its store barrier for two minutes)
+            ready, why = _device_ready(index)
+            everyone_ready = torch.tensor([1 if ready else 0], dtype=torch.int64)
+            dist.all_reduce(everyone_ready, op=dist.ReduceOp.MIN)
+            if int(everyone_ready.item()) == 0:
+                group, why = None, why or "another rank has no usable HIP device"
+            elif _shares_a_gpu(rank, world, index):
                 group, why = None, "two ranks share one GPU (RCCL refuses duplicate GPUs)"
             else:
                 group, why = _start_rccl(rank, world, index)

@@ -604,7 +604,9 @@ class raw_env:
         self.agents = self.possible_agents[:]
         self._next_outputs()
         if mask is not None and self._last_traj is not None:
-            self._settle_last_frame()  # (a masked reset rewrites only the masked games' rows)
+            # (pz_reset writes the observation rows of EVERY game from the state -- the unmasked ones unchanged -- but
+            # leaves rewards and flags alone: those must hold the k-frame launch's last frame first)
+            self._settle_last_frame()
         self._last_traj = None
         m = None
         if mask is not None:

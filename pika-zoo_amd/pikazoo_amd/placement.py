@@ -18,6 +18,7 @@ thing off.  No result depends on any of this.
 from __future__ import annotations
 
 import os
+import time
 
 import torch
 
@@ -37,7 +38,10 @@ DISTINCT_BELOW = 0.86          # t(a, b) / (t(a) + t(b)): ~1.0 in one rank, 0.77
                                # straddles two ranks)
 
 _verdicts: dict = {}           # (device index, low ptr, high ptr, bytes) -> ratio measured for that pair
-_gave_up: set = set()          # (device index, bytes): the budget was spent once, later pairs of that size are not walked again
+_far_pools: dict = {}          # (device index, bytes) -> private pools holding one block each that a walk found in another rank
+_gave_up: dict = {}            # (device index, bytes) -> time of a walk that spent its budget: pairs of that size are not
+                               # walked again for RETRY_AFTER_S (a loop that allocates per iteration must not stall per iteration)
+RETRY_AFTER_S = 30.0
 last_info: dict = {}           # what the latest alloc_pair did (diagnostic; bench.py prints it)
 
 
@@ -126,6 +130,26 @@ def reset():
     """Forget every cached verdict (e.g. after the process has returned memory to the driver)."""
     _verdicts.clear()
     _gave_up.clear()
+    _far_pools.clear()
+
+
+def _has_free_block(pool, nbytes: int) -> bool:
+    """Does the private pool hold an unused block of at least `nbytes`?"""
+    try:
+        return any(blk.get("state") == "inactive" and blk.get("size", 0) >= nbytes
+                   for seg in pool.snapshot() for blk in seg.get("blocks", ()))
+    except Exception:  # noqa: BLE001 - an allocator without pool snapshots: no reuse, the walk still works
+        return False
+
+
+def _default_budget() -> int:
+    """``DEFAULT_SPACER_BUDGET``, or ``PIKAZOO_PLACE_MAX_GIB`` from the environment (up to one rank, 96 GiB: the runs of
+    one rank seen on MI355X boxes are 2 - 63 GiB long, so 32 GiB finds the other rank in most allocations, not in all)."""
+    try:
+        gib = float(os.environ["PIKAZOO_PLACE_MAX_GIB"])
+    except (KeyError, ValueError):
+        return DEFAULT_SPACER_BUDGET
+    return int(min(max(gib, 0.0), MAX_SPACER_BYTES / (1 << 30)) * (1 << 30))
 
 
 def _why_not_walk(device, budget: int):
@@ -153,7 +177,7 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = None):
     tried, ``spacer_gib`` walked, ``walk`` (why the allocator was not walked, if it was not).
 
     What the walk may hold, for the few milliseconds it lasts: at most `max_spacer_bytes` (default
-    ``DEFAULT_SPACER_BUDGET`` = 32 GiB, and never more than a quarter of the free memory) -- in a PRIVATE memory pool
+    ``DEFAULT_SPACER_BUDGET`` = 32 GiB or ``PIKAZOO_PLACE_MAX_GIB``, and never more than a quarter of the free memory) -- in a PRIVATE memory pool
     that is released to the driver afterwards, so nothing of the process's own cached memory is touched.  It is not
     walked at all when somebody else holds memory on the device or ranks share it (``_why_not_walk``)."""
     global last_info
@@ -172,7 +196,21 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = None):
         block = torch.empty(elems, dtype=dtype, device=device)
         return block[:numel].view(shape)
 
-    a, b = fresh(numel), fresh(numel)
+    a = fresh(numel)
+    # a block an earlier walk found for this size lives in a private pool of its own (`_far_pools`): when the tensor that
+    # used it has died, the block is free in that pool and is handed out again here -- no second walk
+    b = None
+    for pool in _far_pools.get((device.index, nbytes), ()):
+        if not _has_free_block(pool, max(numel, CANDIDATE_BLOCK // probe) * probe):
+            continue  # (its block is in use: allocating in this pool now would only grow it)
+        with torch.cuda.use_mem_pool(pool, device=device):
+            cand = fresh(max(numel, CANDIDATE_BLOCK // probe))
+        if _verdicts.get(_key(a, cand), 1.0) < DISTINCT_BELOW or pair_ratio(a, cand) < DISTINCT_BELOW:
+            b = cand
+            break
+        del cand
+    if b is None:
+        b = fresh(numel)
     known = _verdicts.get(_key(a, b))
     if known is not None:  # (a pair the allocator hands out again: its blocks came back from torch's cache)
         info.update(probed=True, cached=True, ratio=known, distinct=known < DISTINCT_BELOW, candidates=0, spacer_gib=0.0)
@@ -180,10 +218,13 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = None):
     ratio = pair_ratio(a, b)
     _verdicts[_key(a, b)] = ratio
     info.update(probed=True, ratio=ratio, distinct=ratio < DISTINCT_BELOW, candidates=1, spacer_gib=0.0)
-    if ratio < DISTINCT_BELOW or (device.index, nbytes) in _gave_up:
+    if ratio < DISTINCT_BELOW:
+        return a, b
+    if time.monotonic() - _gave_up.get((device.index, nbytes), -1e9) < RETRY_AFTER_S:
+        info["walk"] = "skipped: a walk for this size spent its budget a moment ago"
         return a, b
     free, _total = torch.cuda.mem_get_info(device)
-    budget = DEFAULT_SPACER_BUDGET if max_spacer_bytes is None else int(max_spacer_bytes)
+    budget = int(max_spacer_bytes) if max_spacer_bytes is not None else _default_budget()
     budget = min(budget, free // 4)
     why = _why_not_walk(device, budget)
     if why is not None:
@@ -192,8 +233,8 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = None):
     # walk the allocator on: everything tried stays allocated meanwhile, so that the next candidate is other memory --
     # all of it in a private pool, which goes back to the driver as a whole
     block_elems = max(numel, CANDIDATE_BLOCK // probe)
-    held, walked, tried, found = [], 0, 1, None
-    pool = torch.cuda.MemPool()
+    held, held_pools, walked, tried, found = [], [], 0, 1, None
+    pool = torch.cuda.MemPool()  # the spacers
     try:
         while walked + SPACER_BYTES <= budget:
             free, _total = torch.cuda.mem_get_info(device)
@@ -202,24 +243,31 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = None):
                 break
             with torch.cuda.use_mem_pool(pool, device=device):
                 held.append(torch.empty(SPACER_BYTES, dtype=torch.uint8, device=device))
+            cand_pool = torch.cuda.MemPool()  # every candidate in a pool of its own: the one that is kept keeps its pool
+            with torch.cuda.use_mem_pool(cand_pool, device=device):
                 cand = fresh(block_elems)  # (a view: keeps its block alive)
             walked += SPACER_BYTES
             tried += 1
             r = pair_ratio(a, cand)
             if r < DISTINCT_BELOW:
                 found, ratio = cand, r
+                _far_pools.setdefault((device.index, nbytes), []).append(cand_pool)
                 break
             held.append(cand)
-            del cand
+            held_pools.append(cand_pool)
+            del cand, cand_pool
     except torch.cuda.OutOfMemoryError:
         info["walk"] = "stopped: out of memory"
     if found is not None:
         b = found
         _verdicts[_key(a, b)] = ratio
     else:
-        _gave_up.add((device.index, nbytes))
+        _gave_up[(device.index, nbytes)] = time.monotonic()
+    # tensors first, pools second: a pool releases the blocks that are unused when it dies (spacers, rejected candidates:
+    # back to the driver here); the block of the candidate that is kept stays in its own pool (`_far_pools`) for the
+    # next pair of this size
     held.clear()
-    del held, pool  # the pool's unused blocks (spacers, rejected candidates) are released to the driver here; the block
-                    # of a candidate that is kept follows when that tensor dies
+    held_pools.clear()
+    del held, held_pools, pool
     info.update(ratio=ratio, distinct=ratio < DISTINCT_BELOW, candidates=tried, spacer_gib=walked / (1 << 30))
     return a, b

@@ -498,7 +498,7 @@ def test_single_frame_views_follow_a_k_frame_launch_lazily(ring):
     for x, y in zip(ra[:3], rb[:3]):
         for ag in a.possible_agents:
             assert torch.equal(x[ag], y[ag])
-    # a masked reset rewrites only the masked games' rows: the others show the k-frame launch's last frame
+    # a masked reset re-derives every game's observation row from the state: the unmasked games still show the k-frame launch's last frame
     tape = torch.stack([torch.stack(list(b.random_actions(5, 2 * k + 1 + t).values())) for t in range(k)])
     traj = a.step_many(tape)
     for t in range(k):
@@ -605,6 +605,12 @@ def test_placement_gives_up_promptly_and_leaves_the_process_memory_alone(monkeyp
     assert grown <= 2 * (32 * 65536 * 35 * 4) + (2 << 30), (grown, info)   # the pair (+ one 1 GiB candidate block), no spacer
     assert torch.cuda.memory_reserved(dev) >= cached                       # (nobody called empty_cache on the process)
     assert info["spacer_gib"] <= placement.DEFAULT_SPACER_BUDGET / (1 << 30)
+    # the block a walk found stays in a private pool of its own: the next pair of this size takes it without walking
+    if info["spacer_gib"] > 0 and info["distinct"]:
+        del a, b
+        a, b = placement.alloc_pair(shape, dt, dev)
+        again = dict(placement.last_info)
+        assert again["distinct"] and again["spacer_gib"] == 0.0, (info, again)
 
 
 def test_step_through_the_bound_entry_point_equals_pz_step():

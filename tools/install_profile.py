@@ -22,21 +22,21 @@ TRAFFIC = {
     "random_random": ("hh", "pz::step_pair_kernel<false, false, false, false>", 65536),
     "random_random_4096": ("cfg2", "pz::step_pair_kernel<false, false, false, false>", 4096),
     "cfg3": ("cfg3", "pz::step_pair_kernel<false, true, false, false>", 65536),
-    "cfg3_compute": ("cfg3c", "pz::step_kernel<false, true, 0, true, 1, false, false>", 65536),
+    "cfg3_compute": ("cfg3c", "pz::step_kernel<false, true, 0, true, 1, false, false, false>", 65536),
     "cfg5": ("cfg5", "pz::step_pair_kernel<false, false, false, false>", 65536),
-    "random_random_524288": ("big", "pz::step_kernel<false, false, 0, true, 0, false, false>", 524288),
+    "random_random_524288": ("big", "pz::step_kernel<false, false, 0, true, 0, false, false, false>", 524288),
     "random_random_int16obs": ("i16", "pz::step_pair_kernel<false, false, false, false>", 65536),
     "packed_random_random": ("pk", "pz::step_pair_kernel<false, false, true, false>", 65536),
     "packed_cfg3": ("pkcfg3", "pz::step_pair_kernel<false, true, true, false>", 65536),
     "packed_random_random_524288": ("pkbig", "pz::step_pair_kernel<false, false, true, false>", 524288),
     "packed_random_random_int16obs": ("ph", "pz::step_pair_kernel<false, false, true, false>", 65536),
     "packed_random_random_524288_int16obs": ("phbig", "pz::step_pair_kernel<false, false, true, false>", 524288),
-    # the k-frame launches (k = 32: bytes per 32-frame launch)
-    "rollout_k32": ("roll", "pz::step_kernel<false, false, 2, false, 0, false, false>", 65536),
-    "step_many_k32": ("roll", "pz::step_kernel<false, false, 3, false, 0, false, false>", 65536),
-    "rollout_k32_p2_computer": ("roll", "pz::rollout_pair_kernel<false, true, 2, false, false>", 65536),
-    "step_many_k32_p2_computer": ("roll", "pz::rollout_pair_kernel<false, true, 3, false, false>", 65536),
-    "rollout_k32_int16obs": ("roll", "pz::rollout_pair_kernel<false, false, 2, false, true>", 65536),
+    # the k-frame launches (k = 32: bytes per 32-frame launch; the last template argument: the PLAIN instantiation)
+    "rollout_k32": ("roll", "pz::step_kernel<false, false, 2, false, 0, false, false, false>", 65536),
+    "step_many_k32": ("roll", "pz::step_kernel<false, false, 3, false, 0, false, false, true>", 65536),
+    "rollout_k32_p2_computer": ("roll", "pz::rollout_pair_kernel<false, true, 2, false, false, true>", 65536),
+    "step_many_k32_p2_computer": ("roll", "pz::rollout_pair_kernel<false, true, 3, false, false, true>", 65536),
+    "rollout_k32_int16obs": ("roll", "pz::rollout_pair_kernel<false, false, 2, false, true, true>", 65536),
 }
 
 

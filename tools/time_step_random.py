@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, "/root/repo/pika-zoo_amd")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent / "pika-zoo_amd"))
 from pikazoo_amd import pikazoo_v0
 for kw in (dict(is_player2_computer=True), dict(is_player1_computer=True, is_player2_computer=True), dict()):
     env = pikazoo_v0.env(num_envs=65536, device="cuda:0", seed=0, **kw)
