@@ -720,12 +720,14 @@ class raw_env:
         ``validate_every`` steps ago: waiting for it is no device synchronisation -- it only keeps the host from
         running more than two poll intervals ahead of the GPU -- and it is what bounds how late the error comes."""
         self._since_poll = 0
+        if torch.cuda.is_current_stream_capturing():
+            return  # (a hipGraph capture records launches only: the counter is looked at by the steps outside it)
         if self._faults_pending:
             self._faults_event.synchronize()
             self._faults_pending = False
             if int(self._faults_host[0]) != 0:
                 self.check_actions()  # (the rare path: confirmed on the device word itself before anything is raised)
-        if not self._faults_pending and not torch.cuda.is_current_stream_capturing():
+        if not self._faults_pending:
             with torch.cuda.device(self.device):
                 self._faults_host.copy_(self._faults, non_blocking=True)
                 self._faults_event.record()
@@ -813,7 +815,7 @@ class raw_env:
         if self._scenery is not None:
             self._track_scenery(resync=True)
         self.steps_done += k
-        if self._faults is not None:  # (the launch range-checked the tape as it parked it: polled, never waited for)
+        if self._faults is not None:  # (the launch range-checked the tape as it parked it; read one call later)
             self._poll_action_faults()
         return self._finish_trajectory(out)
 

@@ -374,7 +374,8 @@ def test_record_episode_statistics_scalar_api():
 def _fresh(n, seed, **kw):
     from pikazoo_amd import pikazoo_v0
 
-    env = pikazoo_v0.env(num_envs=n, seed=seed, validate_actions=False, **kw)
+    kw.setdefault("validate_actions", False)
+    env = pikazoo_v0.env(num_envs=n, seed=seed, **kw)
     env.reset()
     return env
 
@@ -406,9 +407,11 @@ def test_calls_are_ordered_on_the_callers_stream_and_envs_are_independent():
         assert torch.equal(env.state, want)
 
 
-def test_graph_replay_equals_eager_launches():
+@pytest.mark.parametrize("validate", [False, True])
+def test_graph_replay_equals_eager_launches(validate):
     """bench.py replays K captured pz_step launches (hipGraph); the replayed trajectory must be the
-    eager one, including the outputs left in the environment's buffers."""
+    eager one, including the outputs left in the environment's buffers.  With validate_actions (the default) the
+    captured launches count out-of-range actions like eager ones; the env's polling stays out of the capture."""
     n, k = 65536, 64
     acts = torch.randint(0, 18, (k, 2, n), dtype=torch.int32, device="cuda")
     eager = _fresh(n, 9)
@@ -417,7 +420,7 @@ def test_graph_replay_equals_eager_launches():
     want_state = eager.state.clone()
     want_obs, want_rew, want_term = obs["player_1"].clone(), rew["player_1"].clone(), term["player_1"].clone()
 
-    env = _fresh(n, 9)
+    env = _fresh(n, 9, validate_actions=validate, validate_every=16)
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     graph = torch.cuda.CUDAGraph()
@@ -430,6 +433,14 @@ def test_graph_replay_equals_eager_launches():
     assert torch.equal(env.state, want_state)
     assert torch.equal(obs["player_1"], want_obs) and torch.equal(rew["player_1"], want_rew)
     assert torch.equal(term["player_1"], want_term)
+    if validate:
+        env.check_actions()
+        acts[5, 1, 77] = 18  # the graph reads the tape at replay time: a bad action now is counted by the replayed launch
+        with torch.cuda.stream(side):
+            graph.replay()
+        side.synchronize()
+        with pytest.raises(IndexError):
+            env.check_actions()
 
 
 def test_output_ring_keeps_the_previous_results_intact():
