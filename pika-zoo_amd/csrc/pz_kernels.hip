@@ -1389,7 +1389,9 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     constexpr bool kEarlyOwn = PZ_EARLY_OWN_STORES != 0 && !PACKED && (AI1 != AI2) && !kOwnAI;
     // ... and (2) the ball's position, trail and rotation: final once the world step has run (a ball-player collision
     // changes velocities, power-hit flag and punch_effect_x only) -- the human player's wave stores all seven, the
-    // computer's wave none of them (8.44 -> 8.40; hot tape 8.30 -> 8.17 -> 8.15: profiles/r04_experiments/)
+    // computer's wave none of them (8.44 -> 8.40; hot tape 8.30 -> 8.17 -> 8.15: profiles/r04_experiments/).  (Letting the
+    // human player's wave SLEEP 256 - 1 536 cycles before its frame, so that the computer's wave has the SIMD to itself
+    // up to its gathers, changes nothing: 8.38 -> 8.40 - 8.42, and 8.57 when it sleeps past its slack.)
     constexpr bool kEarlyBall = kEarlyOwn && PZ_EARLY_OWN_STORES >= 2;
     constexpr bool kPartnerStoresBall = PZ_EARLY_OWN_STORES >= 2 && !PACKED && (AI1 != AI2) && kOwnAI;
     int coll_before = 0;

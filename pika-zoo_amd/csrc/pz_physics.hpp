@@ -1315,8 +1315,10 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     uint32_t bold_counter = 0u;
     PZ_FRAME_STAMP(0);
     // (Moving the ball first and issuing the computer's two gathers in front of the players' round start and the action
-    // decode -- the gathers depend on the ball columns, the round flags and the serve only -- was built in round 4 and
-    // lost: 8.36 -> 8.49 us per launch, packed 7.28 -> 7.54, profiles/r04_experiments/ab_early_gather_*.log.)
+    // decode -- the gathers depend on the ball columns, the round flags and the serve only -- was built twice in round 4
+    // and lost twice: issued in a block of their own 8.36 -> 8.49 us per launch (the compiler waits for a load where the
+    // branch it was issued in closes), issue and consumption in one block 8.33 -> 8.36, packed 7.25 -> 7.71:
+    // profiles/r04_experiments/ab_early_gather_*.log.  A hundred instructions earlier buys nothing.)
     if (active) {
         if (g.e.round_ended) {  // reset (:149-164) or new round (:176-180); game_ended implies round_ended
             if (g.e.game_ended) {
