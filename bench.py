@@ -675,8 +675,7 @@ def main():
         raise SystemExit(relaunch_with_ranks(args))
     one_device = os.environ.get("PZ_BENCH_ONE_DEVICE") == "1"  # rehearsal: every rank on cuda:0 of a 1-GPU box
     rank, world, local_rank = dist.init_from_env(args.dist_backend, device_index=0 if one_device else None)
-    if one_device:
-        local_rank = 0
+    local_rank = 0 if one_device else dist.local_device_index(local_rank)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():

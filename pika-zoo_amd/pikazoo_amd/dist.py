@@ -57,6 +57,13 @@ def _shares_a_gpu(rank: int, world: int, index: int):
     return len(set(everyone)) < world
 
 
+def local_device_index(local_rank: int) -> int:
+    """The GPU of this rank: LOCAL_RANK when every rank sees all of the node's GPUs (torchrun's default), folded into
+    the visible ones when a launcher narrowed each rank's *_VISIBLE_DEVICES (then usually to one: index 0 everywhere)."""
+    count = torch.cuda.device_count()  # (does not initialise the GPU)
+    return int(local_rank) % count if count > 0 else int(local_rank)
+
+
 def _device_ready(index: int):
     """This rank's own precondition for RCCL: (ok, why not)."""
     try:
@@ -111,7 +118,7 @@ def init_from_env(backend: str | None = None, device_index: int | None = None) -
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=180))
         if backend == "nccl":
-            index = local_rank if device_index is None else int(device_index)
+            index = local_device_index(local_rank) if device_index is None else int(device_index)
             # every precondition is agreed on over gloo BEFORE anybody enters RCCL's own rendezvous (dist.new_group is a
             # collective: a rank that skipped it would leave the others waiting in its store barrier for two minutes)
             ready, why = _device_ready(index)

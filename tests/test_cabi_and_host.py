@@ -135,6 +135,17 @@ def test_sharding_covers_all_lanes_once():
     assert (s.n_local, s.env_id_base, s.n_global) == (65536, 196608, 524288)
 
 
+def test_a_rank_finds_its_gpu_whatever_the_launcher_left_visible(monkeypatch):
+    """LOCAL_RANK is the device index when every rank sees the node's GPUs (torchrun); a launcher that narrows each rank
+    to one visible device leaves index 0 everywhere; without a device the rank number stands (and RCCL is not tried)."""
+    import torch
+    from pikazoo_amd import dist
+
+    for count, expect in ((8, [0, 1, 2, 3, 4, 5, 6, 7]), (1, [0] * 8), (4, [0, 1, 2, 3, 0, 1, 2, 3]), (0, list(range(8)))):
+        monkeypatch.setattr(torch.cuda, "device_count", lambda count=count: count)
+        assert [dist.local_device_index(r) for r in range(8)] == expect
+
+
 _WORKER = r'''
 import os, sys
 import numpy as np
