@@ -620,7 +620,9 @@ BOUND_DETAIL = {
     TRAJ_REGIME: "k-frame launches: every frame's outputs stream to HBM (623 MB per 32-frame launch of int32 rows); "
                  "pure_store_GBps is what the launch's store pattern alone sustains on the entry's own two observation "
                  "tensors (pz_probe_write, >= 20 ms in this run; ~7 TB/s when they lie in different ranks of the HBM, "
-                 "5.6 when they share one: `placement`, DESIGN 4.9); int16 rows are not write-bound",
+                 "5.6 when they share one: `placement`, DESIGN 4.9) -- a REFERENCE rate, not a ceiling: the probe stores "
+                 "`nt` from one wave per 64 games, the launches `sc0 sc1 nt`, and at k = 128 their own stores run 3-5 % "
+                 "above it (frac_of_pure_stores 1.03-1.05); int16 rows are not write-bound",
     "launch-latency": "fewer workgroups than CUs: the launch lasts as long as the dependent-launch chain "
                       "(dispatch + load latency + frame + store acknowledge), not as long as its bytes",
     "infinity-cache-resident": "working set re-touched every launch out of the 256 MiB Infinity Cache: bound by the "
