@@ -61,9 +61,58 @@ struct Args {
 #define VALU_ILP2 0  // 1: the wave's two chains are independent of each other (a lone wave can then fill its own issue slots)
 #endif
 
+#ifndef VALU_KIND
+#define VALU_KIND 0  // what a "dependent instruction" of the stand-in is: 0 one v_mad_u32_u24; 1 the frame's own idiom -- two
+                     // compares into SGPR masks, an s_and_b64, a v_cndmask_b32 on it (3 VALU + 1 SALU per step); 2 the same
+                     // select with the predicate kept in a VGPR (sub, ashr, sub, ashr, and, bfi: 6 VALU, no SALU)
+#endif
+__device__ __forceinline__ void stand_in_step(uint32_t& a, uint32_t b)
+{
+#if VALU_KIND == 0
+    asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(a) : "v"(b));
+#elif VALU_KIND == 1
+    unsigned long long m0, m1;  // (SGPR pairs the compiler allocates: no fixed registers in the asm)
+    asm volatile(
+        "v_cmp_lt_u32_e64 %1, %0, %3\n\t"
+        "v_cmp_gt_i32_e64 %2, %0, 17\n\t"
+        "s_and_b64 %1, %1, %2\n\t"
+        "v_cndmask_b32_e64 %0, %3, %0, %1\n\t"
+        "v_add_u32_e32 %0, 3, %0"
+        : "+v"(a), "=&s"(m0), "=&s"(m1) : "v"(b));
+#else
+    uint32_t t0, t1;
+    asm volatile(
+        "v_sub_u32_e32 %1, %0, %3\n\t"
+        "v_ashrrev_i32_e32 %1, 31, %1\n\t"
+        "v_sub_u32_e32 %2, 17, %0\n\t"
+        "v_ashrrev_i32_e32 %2, 31, %2\n\t"
+        "v_and_b32_e32 %1, %1, %2\n\t"
+        "v_bfi_b32 %0, %1, %0, %3\n\t"
+        "v_add_u32_e32 %0, 3, %0"
+        : "+v"(a), "=&v"(t0), "=&v"(t1) : "v"(b));
+#endif
+}
+constexpr int kValuPerStep = VALU_KIND == 0 ? 1 : (VALU_KIND == 1 ? 4 : 7);
+
 __device__ __forceinline__ uint32_t frame_stand_in(uint32_t acc, uint32_t other, int32_t* mine, const int32_t* theirs, int lane)
 {
     uint32_t a0 = acc, a1 = other;
+#if VALU_KIND != 0
+#pragma unroll
+    for (int k = 0; k < VALU_N / 2 / kValuPerStep / 2; ++k) {
+        stand_in_step(a0, a1);
+        stand_in_step(a1, a0);
+    }
+    mine[lane] = (int32_t)a0;
+    __syncthreads();
+    a1 ^= (uint32_t)theirs[lane];
+#pragma unroll
+    for (int k = 0; k < VALU_N / 2 / kValuPerStep / 2; ++k) {
+        stand_in_step(a0, a1);
+        stand_in_step(a1, a0);
+    }
+    return a0 ^ a1;
+#endif
 #pragma unroll
     for (int k = 0; k < VALU_N / 4; ++k) {
 #if VALU_ILP2
