@@ -361,6 +361,51 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     return res
 
 
+def measure_launch_floor(device, num_envs, frame_steps=102, min_time=0.05):
+    """What one launch of the headline's dependent chain is made of: pz_probe_launch -- the single-frame
+    pair launch's geometry, LDS and buffers with none of its game logic -- replayed from a hipGraph like the headline
+    (2 048 dependent launches per graph, HIP events on the launch stream, >= min_time per figure), on scratch buffers:
+    an empty launch; with the launch's loads; with its loads and stores; with `frame_steps` steps of the frame's own
+    idiom (cmp, cmp, s_and, cndmask, add) per wave in between -- 102 steps = the 408 VALU instructions a wave of the
+    shipped human-vs-human frame issues."""
+    lib = _native.load()
+    n = int(num_envs)
+    with torch.cuda.device(device):
+        state = torch.zeros((44, n), dtype=torch.int32, device=device)
+        acts = torch.zeros((2, n), dtype=torch.int32, device=device)
+        obs = [torch.zeros((n, 35), dtype=torch.int32, device=device) for _ in range(2)]
+        rew = [torch.zeros(n, dtype=torch.int32, device=device) for _ in range(2)]
+        launches = 2048
+        out = {"games": n, "launches_per_graph": launches, "frame_steps": frame_steps}
+        stream = torch.cuda.Stream(device=device)
+        for name, what in (("empty_us", 0), ("loads_us", 1), ("loads_stores_us", 2), ("loads_frame_stand_in_stores_us", 3)):
+            with torch.cuda.stream(stream):
+                stream.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+                    raw_stream = torch.cuda.current_stream(device).cuda_stream
+                    for _ in range(launches):
+                        rc = lib.pz_probe_launch(state.data_ptr(), n, n, acts[0].data_ptr(), acts[1].data_ptr(),
+                                                 obs[0].data_ptr(), obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(),
+                                                 what, frame_steps, raw_stream)
+                        if rc:
+                            _native.check(rc, "pz_probe_launch")
+                t0 = time.perf_counter()
+                graph.replay()
+                stream.synchronize()
+                est = time.perf_counter() - t0
+                reps = max(2, math.ceil(min_time / max(est, 1e-6)))
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(stream)
+                for _ in range(reps):
+                    graph.replay()
+                ev1.record(stream)
+                stream.synchronize()
+            out[name] = ev0.elapsed_time(ev1) * 1e3 / (reps * launches)
+            del graph
+    return out
+
+
 def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_time=0.25, check_lanes=0, obs16=False,
                     num_envs=None):
     """pz_rollout_random (or, tape=True, pz_step_many on a pre-generated action tape): k frames per launch, every
@@ -718,6 +763,11 @@ def main():
             cpu[k] = main_res.get(k)
     del raw_main
 
+    # what the headline launch is made of, with the same batch size (the plain int32 contract only)
+    launch_floor = None
+    if single and args.state_format == "int32" and not args.int16_obs and args.launch == "graph":
+        launch_floor = measure_launch_floor(device, args.num_envs)
+
     # the same workload on the other kind of action tape: K + W distinct slices streamed from HBM (cold: 2 000 slices
     # = 1 GB) vs a few slices re-used out of the caches (hot: what a policy that has just written its actions presents)
     tape_bytes = (args.steps + args.warmup) * 2 * 4 * args.num_envs
@@ -897,6 +947,16 @@ def main():
                 "regime": fr["regime"], "regimes": BOUND_DETAIL,
             },
         }
+        if launch_floor is not None:
+            # the same launch without its game, measured in this run (pz_probe_launch): the part of the
+            # launch's duration that its loads, stores and the dependent-launch chain account for by themselves
+            lf = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in launch_floor.items()}
+            lf["headline_over_loads_stores"] = round(main_res["launch_us"] / launch_floor["loads_stores_us"], 4)
+            lf["note"] = ("pz_probe_launch: the headline's geometry, LDS and buffer shapes with none of its game logic, "
+                          "replayed as a chain of dependent launches like the headline; at one wave pair per 64 games and "
+                          "65 536 games every wave of the launch is in the same phase at the same time, so the launch is the "
+                          "sum of the four parts")
+            out["roofline"]["launch_floor"] = lf
         if configs:
             # the other BASELINE configs and the k-frame launches, condensed (the full entries are in `configs`): every
             # figure the documents quote for them, inside the object the driver's record keeps whole

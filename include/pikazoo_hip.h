@@ -167,6 +167,28 @@ int pz_unpack_state(const void *packed, int64_t n, int64_t packed_stride, int32_
 int pz_probe_write(void *a, void *b, int64_t bytes, void *stream);
 int64_t pz_probe_frame_bytes(void);   /* = 1024 * 8960 */
 
+/* ---- launch-floor probe -------------------------------------------------------------------------
+ * One launch with pz_step's GEOMETRY for n games on int32 columns (ceil(n / 64) workgroups of two waves, the same LDS,
+ * the same seven buffers) and NONE of its game logic -- what a caller (bench.py, tools/launch_floor.hip is the
+ * standalone form) replays as a chain of dependent launches beside the real one to see what that launch is made of
+ * (DESIGN.md section 4.4).  `what`:
+ *   0  nothing at all: what one launch of a dependent chain costs on this runtime;
+ *   1  each wave loads what the pair kernel's waves load (the own player's 13 columns, the ball's 12, the env's 6, both
+ *      action words) and keeps them alive;
+ *   2  ... and stores what a frame always stores: 10 state columns per wave, its agent's reward, its agent's observation
+ *      rows staged in LDS and flushed as 16-byte pieces (`nt`), nothing computed in between;
+ *   3  ... with `frame_steps` steps of the frame's own idiom per wave between the loads and the stores (two compares
+ *      into SGPR masks, an s_and_b64, a v_cndmask_b32 on it, an add: 4 VALU + 1 SALU per step, every step depending on
+ *      the one before), one LDS exchange and one workgroup barrier half way: 102 steps = the 408 VALU instructions a
+ *      wave of the shipped human-vs-human frame issues (that count runs as straight-line code like the frame, any
+ *      other in a loop of ten steps per trip).
+ * The buffers are the shapes pz_step takes (state int32[44][stride >= n], act int32[n], obs int32[n][35], rew int32[n]);
+ * from `what` = 2 on state, rewards and observations are OVERWRITTEN with meaningless values: hand it scratch buffers.
+ * No reference counterpart; nothing in the library calls it. */
+int pz_probe_launch(int32_t *state, int64_t n, int64_t stride, const int32_t *act_p1, const int32_t *act_p2,
+                    int32_t *obs_p1, int32_t *obs_p2, int32_t *rew_p1, int32_t *rew_p2, int32_t what,
+                    int32_t frame_steps, void *stream);
+
 /* ---- flight look-up tables of the computer player (optional; caller-owned device memory) -----
  * The two flight predictors of the rule-based computer player are pure functions of a few small
  * integers, so they can be tabulated once per device and looked up by the step kernels instead of

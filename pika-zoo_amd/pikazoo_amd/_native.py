@@ -80,6 +80,7 @@ _SIGNATURES = {
     "pz_count_packed_misfits": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "pz_probe_write": (C.c_int, [_P, _P, C.c_int64, _P]),
     "pz_probe_frame_bytes": (C.c_int64, []),
+    "pz_probe_launch": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     "pz_step_random": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), C.c_uint64, C.c_uint64,
                                  C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pz_rollout_random": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), C.c_uint64, C.c_uint64,

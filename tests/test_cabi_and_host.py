@@ -307,6 +307,14 @@ def test_argument_validation_without_a_gpu(built_lib):
     assert lib.pz_probe_frame_bytes() == 1024 * 8960
     assert lib.pz_probe_write(None, None, 1 << 30, None) == -1 and lib.pz_probe_write(fake, None, 1024 * 8960 - 1, None) == -2
     assert lib.pz_probe_write(C.c_void_p(4100), fake, 1 << 30, None) == -4
+    # the launch-floor probe: pz_step's seven buffers, `what` in 0..3, at least one game
+    probe = lambda *a: lib.pz_probe_launch(*a)  # noqa: E731
+    assert probe(None, 8, 8, fake, fake, fake, fake, fake, fake, 0, 0, None) == -1
+    assert probe(fake, 0, 0, fake, fake, fake, fake, fake, fake, 0, 0, None) == -2
+    assert probe(fake, 8, 4, fake, fake, fake, fake, fake, fake, 0, 0, None) == -2
+    assert probe(fake, 8, 8, fake, fake, fake, fake, fake, fake, 4, 0, None) == -3
+    assert probe(fake, 8, 8, fake, fake, fake, fake, fake, fake, 3, 5000, None) == -3
+    assert probe(fake, 8, 8, fake, fake, C.c_void_p(4100), fake, fake, fake, 2, 0, None) == -4
     # the landing table: its 2-byte entries (an odd number) + 2 bytes of padding -- the look-up loads whole dwords
     assert lib.pz_flight_table_bytes(0) == 2 * 193 * 23 * 253 * 413 + 2 and lib.pz_flight_table_bytes(1) == 16 * 65 * 192 * 413
 

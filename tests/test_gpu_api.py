@@ -624,6 +624,40 @@ def test_placement_gives_up_promptly_and_leaves_the_process_memory_alone(monkeyp
         assert again["distinct"] and again["spacer_gib"] == 0.0, (info, again)
 
 
+def test_launch_floor_probe_runs_on_scratch_buffers_and_touches_nothing_else():
+    """pz_probe_launch (the headline launch's geometry without its game): every `what` launches for ragged and
+    full batches, writes only inside the buffers it was handed (guard words behind each stay intact), and from `what` = 2 on
+    really stores (the scratch state changes)."""
+    from pikazoo_amd import _native
+
+    lib = _native.load()
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    guard = 0x5A5A5A5A
+    for n in (1, 63, 64, 100, 4096):
+        sizes = {"state": 44 * n, "a1": n, "a2": n, "o1": 35 * n, "o2": 35 * n, "r1": n, "r2": n}
+        bufs = {k: torch.full((v + 64,), guard, dtype=torch.int32, device=dev) for k, v in sizes.items()}
+        # (16-byte alignment of the observation buffers: torch allocations are 512-byte aligned)
+        for k, v in sizes.items():
+            bufs[k][:v] = 0
+        for what in (0, 1, 2, 3):
+            rc = lib.pz_probe_launch(bufs["state"].data_ptr(), n, n, bufs["a1"].data_ptr(), bufs["a2"].data_ptr(),
+                                     bufs["o1"].data_ptr(), bufs["o2"].data_ptr(), bufs["r1"].data_ptr(),
+                                     bufs["r2"].data_ptr(), what, 102, stream)
+            assert rc == 0, (n, what, rc)
+            if what == 3:  # (another step count: the looped form of the stand-in)
+                assert lib.pz_probe_launch(bufs["state"].data_ptr(), n, n, bufs["a1"].data_ptr(), bufs["a2"].data_ptr(),
+                                           bufs["o1"].data_ptr(), bufs["o2"].data_ptr(), bufs["r1"].data_ptr(),
+                                           bufs["r2"].data_ptr(), 3, 46, stream) == 0
+            torch.cuda.synchronize()
+            for k, v in sizes.items():
+                assert bool((bufs[k][v:] == guard).all()), (n, what, k)
+            if what < 2:
+                assert all(bool((bufs[k][:sizes[k]] == 0).all()) for k in sizes), (n, what)
+        assert bool((bufs["o1"][:35 * n] != 0).any()) and bool((bufs["state"][:44 * n] != 0).any())
+        assert bool((bufs["a1"][:n] == 0).all()) and bool((bufs["a2"][:n] == 0).all())  # the actions are only read
+
+
 def test_step_through_the_bound_entry_point_equals_pz_step():
     """raw_env.step goes through pz_step_bind / pz_step_bound (the arguments prepared once per output set and
     configuration); the trajectory must be the one direct pz_step calls produce, wrappers fused later re-bind."""

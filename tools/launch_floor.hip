@@ -78,7 +78,7 @@ __device__ __forceinline__ void stand_in_step(uint32_t& a, uint32_t b)
         "s_and_b64 %1, %1, %2\n\t"
         "v_cndmask_b32_e64 %0, %3, %0, %1\n\t"
         "v_add_u32_e32 %0, 3, %0"
-        : "+v"(a), "=&s"(m0), "=&s"(m1) : "v"(b));
+        : "+v"(a), "=&s"(m0), "=&s"(m1) : "v"(b) : "scc");
 #else
     uint32_t t0, t1;
     asm volatile(
