@@ -766,7 +766,10 @@ def main():
     # what the headline launch is made of, with the same batch size (the plain int32 contract only)
     launch_floor = None
     if single and args.state_format == "int32" and not args.int16_obs and args.launch == "graph":
-        launch_floor = measure_launch_floor(device, args.num_envs)
+        try:
+            launch_floor = measure_launch_floor(device, args.num_envs)
+        except Exception as exc:  # noqa: BLE001 - a diagnostic beside the line, never a reason to lose the line
+            print(f"[bench] launch_floor skipped: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
 
     # the same workload on the other kind of action tape: K + W distinct slices streamed from HBM (cold: 2 000 slices
     # = 1 GB) vs a few slices re-used out of the caches (hot: what a policy that has just written its actions presents)
