@@ -108,6 +108,14 @@ def parse_args():
                          "the N>1 path with every rank on cuda:0 of a 1-GPU box")
     ap.add_argument("--extra", action="store_true", help="also time rollouts, launch modes and a batch sweep")
     ap.add_argument("--rollouts", action="store_true", help="only the k-frame kernels (for profiling runs)")
+    ap.add_argument("--action-tape", choices=["cold", "hot"], default="cold",
+                    help="headline run: every timed launch of a graph replay reads its own action slice (cold: >= 2 048 "
+                         "distinct slices = 1 GB streamed from HBM, whatever --steps is -- the default and what every profile "
+                         "under profiles/ ran) or the K slices are re-used out of the caches (hot: what a policy that has "
+                         "just written its actions presents); the other one is measured beside it")
+    ap.add_argument("--configs-out", default=None,
+                    help="file for the verbose blocks (every config's full entry, --extra, per-rank rows, what the regimes "
+                         "mean); without it they go to stderr as one line.  The stdout line stays below 8 KB")
     return ap.parse_args()
 
 
@@ -147,11 +155,18 @@ def burn_in(raw, frames):
     raw.steps_done = 0
 
 
-def run_gpu(env, acts, warmup, steps, launch, min_time):
-    """W untimed launches, then the K launches repeated until the timed region lasts >= min_time.
+def graph_repeats(steps):
+    """Repetitions of the K-step sequence inside one hipGraph: a replay holds >= GRAPH_MIN_LAUNCHES launches."""
+    return max(1, math.ceil(GRAPH_MIN_LAUNCHES / steps))
 
-    Returns dict(wall, event_ms, timed_steps, passes): `passes` = how many times the K-step action
-    sequence ran in total (untimed calibration pass included) -- what the oracle has to replay."""
+
+def run_gpu(env, acts, warmup, steps, launch, min_time):
+    """W untimed launches, then the timed unit -- `acts.shape[0] - warmup` launches, one per action slice of the tape
+    behind the warm-up slices (a multiple of K: K itself on a hot tape, K x graph_repeats(K) distinct slices on a cold
+    one) -- repeated until the timed region lasts >= min_time.
+
+    Returns dict(wall, event_ms, timed_steps, passes): `passes` = how many times the unit's action sequence ran in
+    total (untimed calibration pass included) -- what the oracle has to replay."""
     raw = env.unwrapped
     lib = _native.load()
     n = raw.num_envs
@@ -171,36 +186,40 @@ def run_gpu(env, acts, warmup, steps, launch, min_time):
                 _native.check(rc, "pz_step")
 
     stream = torch.cuda.Stream(device=raw.device)
-    inner = 1  # repetitions of the K-step sequence inside one timed unit
+    unit_steps = acts.shape[0] - warmup  # launches per timed unit = action slices behind the warm-up ones
+    assert unit_steps >= steps and unit_steps % steps == 0
     with torch.cuda.stream(stream):
         if launch == "api":
             names = raw.possible_agents
             # the per-step action dicts a policy would hand over (views built outside the timed loop)
-            feed = [{names[0]: acts[t, 0], names[1]: acts[t, 1]} for t in range(warmup + steps)]
+            feed = [{names[0]: acts[t, 0], names[1]: acts[t, 1]} for t in range(warmup + unit_steps)]
 
             def unit():
                 step = env.step
-                for t in range(warmup, warmup + steps):
+                for t in range(warmup, warmup + unit_steps):
                     step(feed[t])
             for t in range(warmup):
                 env.step(feed[t])
         else:
             launch_range(0, warmup, stream)
             if launch == "graph":
-                inner = max(1, math.ceil(GRAPH_MIN_LAUNCHES / steps))
+                graph_launches = max(unit_steps, steps * graph_repeats(steps))
                 stream.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: the RCCL watchdog thread of a multi-rank run may poll events while we capture
                 with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
-                    for _ in range(inner):
-                        launch_range(warmup, warmup + steps, torch.cuda.current_stream(raw.device))
+                    for _ in range(graph_launches // unit_steps):  # (hot tape: the K slices again and again)
+                        launch_range(warmup, warmup + unit_steps, torch.cuda.current_stream(raw.device))
                 # (capture records the launches without running them)
+                unit_passes = graph_launches // unit_steps
 
                 def unit():
                     graph.replay()
             else:
+                unit_passes = 1
+
                 def unit():
-                    launch_range(warmup, warmup + steps, stream)
+                    launch_range(warmup, warmup + unit_steps, stream)
         # untimed calibration pass (also the graph upload)
         stream.synchronize()
         t0 = time.perf_counter()
@@ -223,10 +242,12 @@ def run_gpu(env, acts, warmup, steps, launch, min_time):
         dist.barrier()
         wall = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
-    passes = inner * (reps + 1)
-    raw.steps_done = warmup + steps * passes
-    return {"wall": wall, "event_ms": ev_ms, "timed_steps": steps * inner * reps, "passes": passes,
-            "replays": reps, "launches_per_replay": steps * inner}
+    if launch == "api":
+        unit_passes = 1
+    passes = unit_passes * (reps + 1)
+    raw.steps_done = warmup + unit_steps * passes
+    return {"wall": wall, "event_ms": ev_ms, "timed_steps": unit_steps * unit_passes * reps, "passes": passes,
+            "replays": reps, "launches_per_replay": unit_steps * unit_passes, "unit_steps": unit_steps}
 
 
 def usable_cores(requested: int) -> int:
@@ -262,9 +283,9 @@ def oracle_parity(raw, seq, p1_computer, p2_computer, wrappers, lanes, cores):
     if seq["warmup"]:
         chk.rollout_random(ACTION_SEED, 0, seq["warmup"])
     for _ in range(seq["passes"]):
-        chk.rollout_random(ACTION_SEED, seq["warmup"], seq["steps"])
+        chk.rollout_random(ACTION_SEED, seq["warmup"], seq["unit_steps"])
     gpu_state = raw.state[:, :k].cpu().numpy()
-    total = seq["burn_in"] + seq["warmup"] + seq["passes"] * seq["steps"]
+    total = seq["burn_in"] + seq["warmup"] + seq["passes"] * seq["unit_steps"]
     return {"parity_lanes_checked": k, "parity_steps_checked": total,
             "parity_bit_exact": bool((gpu_state == chk.state).all())}
 
@@ -317,7 +338,10 @@ def cpu_baseline(args, raw_gpu, p2_computer, wrappers):
 
 def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=False, launch=None, steps=None,
             warmup=None, burn=None, min_time=None, check_lanes=0, flight_tables=True, state_format="int32", obs16=False,
-            validate_actions=False):
+            validate_actions=False, tape="cold"):
+    """One timed measurement of the single-frame launch.  tape = "cold": every launch of the timed unit reads its own
+    action slice (K x graph_repeats(K) distinct slices behind the warm-up ones: >= 1 GB at 65 536 games, streamed from
+    HBM); "hot": the K slices are re-used."""
     num_envs = args.num_envs if num_envs is None else num_envs
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
@@ -330,7 +354,8 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     raw = env.unwrapped
     env.reset()
     burn_in(raw, burn)
-    acts = pregenerate_actions(raw, warmup + steps)
+    unit_steps = steps * graph_repeats(steps) if (tape == "cold" and launch == "graph") else steps
+    acts = pregenerate_actions(raw, warmup + unit_steps)
     torch.cuda.synchronize(device)
     run = run_gpu(env, acts, warmup, steps, launch, min_time)
     cdev = dist.collective_device(device)  # counters live on the GPU under nccl (RCCL), on the CPU under gloo
@@ -349,12 +374,12 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
         "value": n_total * run["timed_steps"] / wall,
         "launch_us": launch_us, "wall_us_per_step": wall * 1e6 / run["timed_steps"],
         "achieved_GBps": alg / (launch_us * 1e-6) / 1e9, "algorithmic_bytes_per_launch": alg,
-        "raw": raw,
+        "raw": raw, "action_tape": tape, "action_tape_bytes": int(acts.numel() * 4),
     }
     res["frac"] = res["achieved_GBps"] / HBM_PEAK_GBPS
     res["frac_wall"] = alg / (res["wall_us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
     if check_lanes and not args.no_cpu:  # (the caller says which ranks check)
-        seq = {"burn_in": burn, "warmup": warmup, "steps": steps, "passes": run["passes"]}
+        seq = {"burn_in": burn, "warmup": warmup, "unit_steps": run["unit_steps"], "passes": run["passes"]}
         res.update(oracle_parity(raw, seq, args.p1_computer, p2_computer, wrappers, check_lanes,
                                  usable_cores(args.cpu_threads)))
     del acts
@@ -368,7 +393,10 @@ def measure_launch_floor(device, num_envs, frame_steps=102, min_time=0.05):
     an empty launch; with the launch's loads; with its loads and stores; with `frame_steps` steps of the frame's own
     idiom (cmp, cmp, s_and, cndmask, add) per wave in between -- 102 steps = the 408 VALU instructions a wave of the
     shipped human-vs-human frame issues."""
-    lib = _native.load()
+    sys.path.insert(0, str(REPO / "pika-zoo_amd"))
+    import diag  # libpikazoo_diag.so (include/pikazoo_diag.h): not part of the product library
+
+    lib = diag.load()
     n = int(num_envs)
     with torch.cuda.device(device):
         state = torch.zeros((44, n), dtype=torch.int32, device=device)
@@ -378,18 +406,20 @@ def measure_launch_floor(device, num_envs, frame_steps=102, min_time=0.05):
         launches = 2048
         out = {"games": n, "launches_per_graph": launches, "frame_steps": frame_steps}
         stream = torch.cuda.Stream(device=device)
+        def probe(what, raw_stream):
+            return lib.pz_probe_launch(state.data_ptr(), n, n, acts[0].data_ptr(), acts[1].data_ptr(), obs[0].data_ptr(),
+                                       obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(), what, frame_steps, raw_stream)
+
         for name, what in (("empty_us", 0), ("loads_us", 1), ("loads_stores_us", 2), ("loads_frame_stand_in_stores_us", 3)):
             with torch.cuda.stream(stream):
+                # once eagerly, return code checked: a refused launch never aborts a capture in flight
+                _native.check(probe(what, stream.cuda_stream), "pz_probe_launch")
                 stream.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                     raw_stream = torch.cuda.current_stream(device).cuda_stream
                     for _ in range(launches):
-                        rc = lib.pz_probe_launch(state.data_ptr(), n, n, acts[0].data_ptr(), acts[1].data_ptr(),
-                                                 obs[0].data_ptr(), obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(),
-                                                 what, frame_steps, raw_stream)
-                        if rc:
-                            _native.check(rc, "pz_probe_launch")
+                        probe(what, raw_stream)
                 t0 = time.perf_counter()
                 graph.replay()
                 stream.synchronize()
@@ -593,13 +623,129 @@ def measure_policy_in_the_loop(args, shard, device, launches=2048, fused=False):
                      "policy kernel + step kernel per step, both inside the timed region")}
 
 
+def measure_two_chains(args, shard, device, steps=512, p2_computer=False, check_lanes=512):
+    """The one structural lever a dependent-launch chain leaves: the batch as TWO independent sub-batch chains (games
+    share nothing, pikazoo_env.py:96-98) whose launches could overlap -- (a) inside ONE hipGraph (fork once at its start,
+    join once at its end, no per-step event), (b) as two hipGraphs replayed side by side on two streams.  Each step of
+    sub-batch c is one pz_step launch on lanes [c n/2, (c+1) n/2) of the same tensors (pointer offsets, full column
+    pitch, env_id_base moved along).  Timed like the headline (HIP events, >= 0.1 s); both halves' first lanes are
+    replayed on the oracle.  Measured beside the one-launch headline, never instead of it (on MI355X / ROCm
+    7.2 neither form gains -- a 32 768-game launch costs 5.3 us of which only 1.5 scale with its size)."""
+    import ctypes as C
+
+    env = make_env(shard, device, num_envs=args.num_envs, p1_computer=args.p1_computer, p2_computer=p2_computer)
+    raw = env.unwrapped
+    lib = _native.load()
+    n, half = raw.num_envs, raw.num_envs // 2
+    if half % 64 or half == 0:
+        return None
+    env.reset()
+    burn = min(args.burn_in, 512)
+    burn_in(raw, burn)
+    acts = pregenerate_actions(raw, steps)
+    cfgs = []
+    for c in range(2):
+        cfg = _native.PzConfig.from_buffer_copy(raw._cfg)
+        cfg.env_id_base = raw.env_id_base + c * half
+        cfgs.append(cfg)
+    p = raw._ptrs  # state, obs1, obs2, rew1, rew2, terminated
+
+    def launch(c, t, stream):
+        lo = c * half
+        rc = lib.pz_step(p[0] + 4 * lo, half, raw._stride, C.byref(cfgs[c]), acts[t, 0].data_ptr() + 4 * lo,
+                         acts[t, 1].data_ptr() + 4 * lo, p[1] + 140 * lo, p[2] + 140 * lo, p[3] + 4 * lo, p[4] + 4 * lo,
+                         p[5] + lo, None, raw._tables_ref, stream.cuda_stream)
+        if rc:
+            _native.check(rc, "pz_step (sub-batch)")
+
+    passes = 0
+    out = {}
+    main_s, side = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+    torch.cuda.synchronize(device)
+    # (a) one graph, two branches
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(main_s):
+        with torch.cuda.graph(graph, stream=main_s, capture_error_mode="thread_local"):
+            cur = torch.cuda.current_stream(device)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            side.wait_event(fork)
+            for t in range(steps):
+                launch(0, t, cur)
+                launch(1, t, side)
+            join = torch.cuda.Event()
+            join.record(side)
+            cur.wait_event(join)
+        graph.replay()
+        main_s.synchronize()
+        passes += 1
+        t0 = time.perf_counter()
+        graph.replay()
+        main_s.synchronize()
+        reps = max(2, math.ceil(0.1 / max(time.perf_counter() - t0, 1e-6)))
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(main_s)
+        for _ in range(reps):
+            graph.replay()
+        ev1.record(main_s)
+        main_s.synchronize()
+        passes += 1 + reps
+        out["two_chains_one_graph_us"] = ev0.elapsed_time(ev1) * 1e3 / (reps * steps)
+    del graph
+    # (b) two graphs on two streams
+    streams, graphs = (main_s, side), []
+    for c in range(2):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(streams[c]):
+            with torch.cuda.graph(g, stream=streams[c], capture_error_mode="thread_local"):
+                cur = torch.cuda.current_stream(device)
+                for t in range(steps):
+                    launch(c, t, cur)
+        graphs.append(g)
+    torch.cuda.synchronize(device)
+    e0 = torch.cuda.Event(enable_timing=True)
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e0.record(streams[0])
+    streams[1].wait_event(e0)
+    for _ in range(reps):
+        for c in range(2):
+            with torch.cuda.stream(streams[c]):
+                graphs[c].replay()
+    for c in range(2):
+        ends[c].record(streams[c])
+    torch.cuda.synchronize(device)
+    passes += reps
+    out["two_graphs_two_streams_us"] = max(e0.elapsed_time(e) for e in ends) * 1e3 / (reps * steps)
+    if check_lanes and not args.no_cpu:
+        from oracle import pz_oracle as po
+
+        po.build()
+        ok = True
+        for c in range(2):
+            chk = po.OracleEnv(check_lanes, oracle_config(po, raw, args.p1_computer, p2_computer, False,
+                                                          raw.env_id_base + c * half), nthreads=usable_cores(args.cpu_threads))
+            chk.reset()
+            chk.rollout_random(BURN_SEED, 0, burn)
+            for _ in range(passes):
+                chk.rollout_random(ACTION_SEED, 0, steps)
+            ok = ok and bool((raw.state[:, c * half:c * half + check_lanes].cpu().numpy() == chk.state).all())
+        out["two_chains_parity_bit_exact"] = ok
+    return out
+
+
 _TRAFFIC = None
+_TRAFFIC_STATUS = {}  # workload key -> {"build_id", "stale", "why"}: what load_traffic decided, for the line
 
 
 def load_traffic(workload_key, num_envs):
     """Fabric-side bytes per launch from the committed PMC profile (profiles/traffic.json) of this workload at this
     batch size, or None: FETCH_SIZE x 2 + WRITE_SIZE, both calibrated on known-byte kernels of the same access widths
-    (profiles/r03*_calibration.json)."""
+    (profiles/r0*_calibration.json).
+
+    The counters were taken on ONE build (the entry's `build_id`).  They are used when the loaded library is that build,
+    or when the instruction stream of the entry's kernel is unchanged (`kernel_digest`, tools/kernel_digest.py: a
+    change elsewhere in the sources does not invalidate a kernel's counters); otherwise the figure is STALE: the line
+    says so (`traffic_stale`) and carries no `traffic` / `frac_traffic` for it."""
     global _TRAFFIC
     if _TRAFFIC is None:
         try:
@@ -607,7 +753,25 @@ def load_traffic(workload_key, num_envs):
         except Exception:  # noqa: BLE001
             _TRAFFIC = {}
     entry = _TRAFFIC.get(workload_key, {})
-    return entry.get("hbm_bytes_per_launch") if entry.get("num_envs") == num_envs else None
+    if entry.get("num_envs") != num_envs or "hbm_bytes_per_launch" not in entry:
+        return None
+    status = _TRAFFIC_STATUS.get(workload_key)
+    if status is None:
+        status = {"build_id": entry.get("build_id"), "stale": False, "why": "same build"}
+        if entry.get("build_id") != _native.build_id():
+            status.update(stale=True, why="another build and no kernel digest to compare")
+            try:
+                sys.path.insert(0, str(REPO / "tools"))
+                import kernel_digest
+
+                if entry.get("kernel_digest") and kernel_digest.available():
+                    same = kernel_digest.digest(entry["kernel"], _native.LIB_PATH) == entry["kernel_digest"]
+                    status.update(stale=not same, why="another build, kernel instruction stream " +
+                                  ("unchanged" if same else "CHANGED"))
+            except Exception as exc:  # noqa: BLE001 - no disassembler: the figure stays stale
+                status["why"] = f"another build; digest check failed: {type(exc).__name__}"
+        _TRAFFIC_STATUS[workload_key] = status
+    return None if status["stale"] else entry["hbm_bytes_per_launch"]
 
 
 def traffic_key(num_envs, p2_computer=False, wrappers=False, flight_tables=True, state_format="int32", obs16=False):
@@ -747,7 +911,8 @@ def main():
     # the in-run oracle replay: all of it with one rank; with N ranks the first and the last rank check 1 024 lanes each
     check_lanes = args.check_lanes if single else (min(1024, args.check_lanes) if rank in (0, world - 1) else 0)
     main_res = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers,
-                       check_lanes=check_lanes, flight_tables=tables, state_format=args.state_format, obs16=args.int16_obs)
+                       check_lanes=check_lanes, flight_tables=tables, state_format=args.state_format, obs16=args.int16_obs,
+                       tape=args.action_tape)
     raw_main = main_res.pop("raw")
     # every rank's own figures (a straggler GPU is invisible in the MAX-over-ranks wall clock alone)
     parity = main_res.get("parity_bit_exact")
@@ -764,27 +929,33 @@ def main():
     del raw_main
 
     # what the headline launch is made of, with the same batch size (the plain int32 contract only)
-    launch_floor = None
+    launch_floor = launch_floor_error = None
     if single and args.state_format == "int32" and not args.int16_obs and args.launch == "graph":
         try:
             launch_floor = measure_launch_floor(device, args.num_envs)
         except Exception as exc:  # noqa: BLE001 - a diagnostic beside the line, never a reason to lose the line
-            print(f"[bench] launch_floor skipped: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
+            launch_floor_error = f"{type(exc).__name__}: {exc}"  # (and the line says that it was skipped, and why)
+            print(f"[bench] launch_floor skipped: {launch_floor_error}", file=sys.stderr, flush=True)
+    # the batch as two independent 32 768-game chains (beside the headline; a diagnostic, never a reason to lose the line)
+    pipelined = None
+    if single and not args.no_configs and args.state_format == "int32" and not args.int16_obs:
+        try:
+            pipelined = measure_two_chains(args, shard, device, p2_computer=args.p2_computer)
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] two-chain measurement skipped: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
 
-    # the same workload on the other kind of action tape: K + W distinct slices streamed from HBM (cold: 2 000 slices
-    # = 1 GB) vs a few slices re-used out of the caches (hot: what a policy that has just written its actions presents)
-    tape_bytes = (args.steps + args.warmup) * 2 * 4 * args.num_envs
-    tape_kind = "hot" if tape_bytes <= INFINITY_CACHE_BYTES // 4 else "cold"
+    # the same workload on the other kind of action tape (cold: every launch its own slice, >= 1 GB streamed from HBM;
+    # hot: K slices re-used out of the caches, what a policy that has just written its actions presents)
     other_tape = None
     if single and not args.no_configs:
-        o_steps, o_warm = (2000, 200) if tape_kind == "hot" else (20, 5)
+        other = "hot" if args.action_tape == "cold" else "cold"
+        o_steps = min(args.steps, 20) if other == "hot" else args.steps
         r = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers, flight_tables=tables,
-                    state_format=args.state_format, obs16=args.int16_obs, steps=o_steps, warmup=o_warm, burn=512,
-                    min_time=0.1)
+                    state_format=args.state_format, obs16=args.int16_obs, steps=o_steps, warmup=5, burn=512,
+                    min_time=0.1, tape=other)
         r.pop("raw")
-        other_tape = {"action_tape": "cold" if tape_kind == "hot" else "hot", "steps": o_steps, "warmup": o_warm,
-                      "action_tape_bytes": (o_steps + o_warm) * 2 * 4 * args.num_envs, "value": r["value"],
-                      "launch_us": r["launch_us"], "frac": r["frac"]}
+        other_tape = {"action_tape": other, "steps": o_steps, "action_tape_bytes": r["action_tape_bytes"],
+                      "value": r["value"], "launch_us": r["launch_us"], "frac": r["frac"]}
 
     configs = {}
     if single and not args.no_configs:
@@ -904,6 +1075,12 @@ def main():
         alg_bytes = main_res["algorithmic_bytes_per_launch"]
         wl = traffic_key(args.num_envs, args.p2_computer, args.wrappers, tables, args.state_format, args.int16_obs)
         fr = fractions(main_res, args.num_envs, wl)
+        tstat = _TRAFFIC_STATUS.get(wl, {})
+        checked = [p for p in per_rank if p["parity_bit_exact"] is not None]
+        workload = (f"{args.num_envs} games/GPU, random policy both players (Philox stream in HBM), winning_score=15, "
+                    f"serve=winner, auto-reset")  # (kept below the 128 characters the driver's record keeps of a string)
+        if args.p1_computer or args.p2_computer or args.wrappers:
+            workload += f", p1c={int(args.p1_computer)} p2c={int(args.p2_computer)} wrap={int(args.wrappers)}"
         out = {
             "metric": "env-steps/sec (random policy, 65 536 envs per GPU)",
             "value": main_res["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -917,72 +1094,122 @@ def main():
             # ranks = processes in the job; rccl_ranks = ranks of the RCCL group the counters travelled over (0: they
             # went over gloo -- see dist_note -- which does not touch the measurement: no collective on the step path)
             "ranks": dist.world_size(), "rccl_ranks": dist.rccl_ranks(), "dist_backend": dist.backend_name(),
-            "dist_note": dist.fallback_note(), "per_rank": per_rank,
-            "build_id": _native.build_id(),
+            "dist_note": dist.fallback_note(), "build_id": _native.build_id(),
+            # Everything below is FLAT: scalars and short strings only (the driver's record keeps those and drops nested
+            # objects); the full entries go to --configs-out / stderr.
             "config": {
-                "workload": f"{args.num_envs} games per GPU, both players uniform-random actions "
-                            f"(Philox policy stream pre-generated in HBM), winning_score=15, serve=winner, "
-                            f"auto-reset, p1_computer={args.p1_computer}, p2_computer={args.p2_computer}, "
-                            f"fused_wrappers={args.wrappers}",
+                "workload": workload,
                 "num_envs_per_gpu": args.num_envs, "num_envs_total": main_res["n_total"],
-                # the K + W action slices are distinct and streamed from HBM: a long tape (default 1.2 GB) is read cold,
-                # a short one (--steps 20: 13 MB) stays in the caches like actions a policy has just written
-                "action_tape_bytes": tape_bytes, "action_tape": tape_kind,
+                # cold: every launch of a graph replay reads its own action slice (>= 2 048 distinct slices, streamed from
+                # HBM whatever --steps is); hot: the K slices re-used out of the caches
+                "action_tape": main_res["action_tape"], "action_tape_bytes": main_res["action_tape_bytes"],
                 "launch": args.launch,
                 "kernel": kernel_name(args.num_envs, args.p2_computer or args.p1_computer, tables,
                                       args.state_format == "packed"),
+                "state_format": args.state_format, "observation_dtype": "int16" if args.int16_obs else "int32",
+                "build_id": _native.build_id(), "ranks": dist.world_size(), "rccl_ranks": dist.rccl_ranks(),
+                "dist_backend": dist.backend_name(), "dist_note": (dist.fallback_note() or "")[:120],
+                "env_id_base_last_rank": per_rank[-1]["env_id_base"],
             },
             "roofline": {
                 # the bound is HBM-side in every regime; which part of the memory system a launch of this batch size
-                # actually runs against is the regime (`regimes` below says what each name means)
-                "bound": f"hbm ({fr['regime']})", "achieved": main_res["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                # actually runs against is the regime (the configs file says what each name means)
+                "bound": "hbm", "bound_regime": fr["regime"], "achieved": main_res["achieved_GBps"],
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 # `frac` is a CONTRACT-bytes figure: the algorithmic 649 B/game-step over the HIP-event
                 # launch duration over 8 TB/s -- not achieved HBM bandwidth: the changed-only write-back moves fewer
                 # bytes (`traffic`, `frac_traffic`: PMC counters), and at this batch size they move through the
-                # Infinity Cache (`regime`, `bound_detail`)
-                "frac": fr["frac"], "frac_basis": "algorithmic bytes (649 B per game-step) / HIP-event launch time / peak",
+                # Infinity Cache (`bound_regime`)
+                "frac": fr["frac"], "frac_basis": "algorithmic 649 B per game-step / HIP-event launch time / peak",
                 "traffic": fr["traffic"], "traffic_key": fr["traffic_key"],
+                # the build the PMC counters were taken on; stale = another build AND the kernel's instructions changed
+                "traffic_build_id": tstat.get("build_id"), "traffic_stale": bool(tstat.get("stale", False)),
+                "traffic_check": tstat.get("why"),
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_us": main_res["launch_us"],
                 # the same fraction on the wall clock `value` is computed from (launch gaps included)
                 "frac_wall": fr["frac_wall"],
                 # ... and with the PMC-measured bytes instead of the 649 B/game-step contract figure
                 "frac_traffic": fr["frac_traffic"],
-                "regime": fr["regime"], "regimes": BOUND_DETAIL,
+                # every rank's own figures, condensed (rows: the configs file / `per_rank`)
+                "per_rank_min_value": min(p["value"] for p in per_rank),
+                "per_rank_max_launch_us": max(p["launch_us"] for p in per_rank),
+                "parity_ranks_checked": len(checked),
+                "parity_first_last_rank_bit_exact": (all(p["parity_bit_exact"] for p in checked) and
+                                                     per_rank[0]["parity_bit_exact"] is not None and
+                                                     per_rank[-1]["parity_bit_exact"] is not None) if checked else None,
             },
         }
-        if launch_floor is not None:
-            # the same launch without its game, measured in this run (pz_probe_launch): the part of the
-            # launch's duration that its loads, stores and the dependent-launch chain account for by themselves
-            lf = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in launch_floor.items()}
-            lf["headline_over_loads_stores"] = round(main_res["launch_us"] / launch_floor["loads_stores_us"], 4)
-            lf["note"] = ("pz_probe_launch: the headline's geometry, LDS and buffer shapes with none of its game logic, "
-                          "replayed as a chain of dependent launches like the headline; at one wave pair per 64 games and "
-                          "65 536 games every wave of the launch is in the same phase at the same time, so the launch is the "
-                          "sum of the four parts")
-            out["roofline"]["launch_floor"] = lf
-        if configs:
-            # the other BASELINE configs and the k-frame launches, condensed (the full entries are in `configs`): every
-            # figure the documents quote for them, inside the object the driver's record keeps whole
-            keep = ("launch_us", "us_per_frame", "value", "frac", "frac_traffic", "frac_of_pure_stores", "regime",
-                    "parity_bit_exact")
-            names = ("cfg2", "cfg3", "cfg3_compute", "cfg5", "int32_524288", "packed_headline", "packed_cfg3", "packed_524288",
-                     "rollout_k32", "step_many_k32", "rollout_k32_p2_computer", "step_many_k32_p2_computer", "rollout_k128",
-                     "rollout_k32_4096", "policy_fused_into_the_step")
-            out["roofline"]["by_config"] = {
-                name: {k: (round(v, 4) if isinstance(v, float) else v) for k, v in configs[name].items() if k in keep}
-                for name in names if name in configs}
+        roof = out["roofline"]
+        if world > 1:
+            out["per_rank"] = per_rank  # (N rows: small; with one rank the flat figures above say it all)
+
+        def put(prefix, entry, us_key="launch_us", what=("frac", "frac_traffic")):
+            """One config's figures as flat scalars of `roofline`: <prefix>_launch_us (or _us_per_frame), _frac, ..."""
+            if entry is None:
+                return
+            roof[f"{prefix}_{us_key}"] = round(entry[us_key], 4)
+            for k in what:
+                if entry.get(k) is not None:
+                    roof[f"{prefix}_{k}"] = round(entry[k], 4)
+
+        # the two kinds of action tape, whichever of them the headline ran on
+        tapes = {main_res["action_tape"]: {"launch_us": main_res["launch_us"], "frac": fr["frac"]}}
         if other_tape is not None:
-            out["other_action_tape"] = other_tape
+            tapes[other_tape["action_tape"]] = other_tape
+        for kind in ("cold", "hot"):
+            if kind in tapes:
+                put(f"{kind}_tape", tapes[kind], what=("frac",))
+        # what the headline launch is made of (pz_probe_launch of the diagnostics library, DESIGN 4.4)
+        if launch_floor is not None:
+            roof["floor_empty_us"] = round(launch_floor["empty_us"], 4)
+            roof["floor_loads_us"] = round(launch_floor["loads_us"], 4)
+            roof["floor_loads_stores_us"] = round(launch_floor["loads_stores_us"], 4)
+            roof["floor_stand_in_us"] = round(launch_floor["loads_frame_stand_in_stores_us"], 4)
+        elif launch_floor_error is not None:
+            roof["floor_error"] = launch_floor_error[:120]
+        if configs:
+            # every BASELINE config and k-frame launch: the figures README / DESIGN 6 quote, one scalar each
+            for prefix, key in (("cfg2", "cfg2"), ("cfg3", "cfg3"), ("cfg3_compute", "cfg3_compute"), ("cfg5", "cfg5"),
+                                ("n524288", "int32_524288"), ("packed", "packed_headline"), ("packed_cfg3", "packed_cfg3"),
+                                ("packed_524288", "packed_524288"), ("int16obs", "int16obs_headline"),
+                                ("packed_int16obs", "packed_int16obs_headline"),
+                                ("packed_int16obs_524288", "packed_int16obs_524288"),
+                                ("policy_fused", "policy_fused_into_the_step")):
+                put(prefix, configs.get(key))
+            for key in ("rollout_k32", "step_many_k32", "rollout_k32_p2_computer", "step_many_k32_p2_computer",
+                        "rollout_k128", "rollout_k32_4096", "rollout_k32_int16obs"):
+                put(key, configs.get(key), us_key="us_per_frame", what=("frac", "frac_traffic", "frac_of_pure_stores"))
+            if "cfg3" in configs:
+                roof["flight_tables_build_ms_once"] = round(configs["cfg3"]["flight_tables"]["build_ms_once_per_device"], 2)
+            verdicts = [v.get("parity_bit_exact") for v in configs.values() if "parity_bit_exact" in v]
+            roof["configs_parity_checked"] = len(verdicts)
+            roof["configs_parity_all_bit_exact"] = bool(verdicts) and all(verdicts)
+            roof["configs_traffic_stale"] = sum(1 for st in _TRAFFIC_STATUS.values() if st.get("stale"))
+        if pipelined is not None:
+            roof.update({k: (round(v, 4) if isinstance(v, float) else v) for k, v in pipelined.items()})
         if cpu is not None:
             # the reference itself never travels to the GPU box; its own Python step, measured in the survey container
-            cpu["reference_python"] = {"value": 55100, "unit": "env-steps/s/core", "hardware": "Xeon 2.1 GHz, survey "
-                                       "container (1 of 8 vCPU)", "source": "BASELINE.md section 2"}
+            # (BASELINE.md section 2: Xeon 2.1 GHz, 1 of 8 vCPU)
+            cpu["reference_python_steps_per_s_per_core"] = 55100
             out["cpu_baseline"] = cpu
+        verbose = {"per_rank": per_rank, "regimes": BOUND_DETAIL}
+        if launch_floor is not None:
+            verbose["launch_floor"] = launch_floor
+        if other_tape is not None:
+            verbose["other_action_tape"] = other_tape
         if configs:
-            out["configs"] = configs
+            verbose["configs"] = configs
         if extra:
-            out["extra"] = extra
-        print(json.dumps(out), flush=True)
+            verbose["extra"] = extra
+        verbose["traffic_status"] = _TRAFFIC_STATUS
+        if args.configs_out:
+            Path(args.configs_out).write_text(json.dumps(verbose, indent=1))
+            out["configs_file"] = str(args.configs_out)
+        else:
+            print("[bench verbose] " + json.dumps(verbose), file=sys.stderr, flush=True)
+        line = json.dumps(out)
+        assert len(line) < 8000, f"the bench line grew to {len(line)} bytes: the driver's record keeps 8 KB"
+        print(line, flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define PZ_ABI_VERSION 8
+/* 9: the diagnostics pz_probe_launch / pz_selftest_predictor left this library (include/pikazoo_diag.h,
+ *    libpikazoo_diag.so); every other entry point and pz_config are ABI 8's */
+#define PZ_ABI_VERSION 9
 #define PZ_STATE_WORDS 44
 #define PZ_OBS_DIM 35
 
@@ -167,28 +169,6 @@ int pz_unpack_state(const void *packed, int64_t n, int64_t packed_stride, int32_
 int pz_probe_write(void *a, void *b, int64_t bytes, void *stream);
 int64_t pz_probe_frame_bytes(void);   /* = 1024 * 8960 */
 
-/* ---- launch-floor probe -------------------------------------------------------------------------
- * One launch with pz_step's GEOMETRY for n games on int32 columns (ceil(n / 64) workgroups of two waves, the same LDS,
- * the same seven buffers) and NONE of its game logic -- what a caller (bench.py, tools/launch_floor.hip is the
- * standalone form) replays as a chain of dependent launches beside the real one to see what that launch is made of
- * (DESIGN.md section 4.4).  `what`:
- *   0  nothing at all: what one launch of a dependent chain costs on this runtime;
- *   1  each wave loads what the pair kernel's waves load (the own player's 13 columns, the ball's 12, the env's 6, both
- *      action words) and keeps them alive;
- *   2  ... and stores what a frame always stores: 10 state columns per wave, its agent's reward, its agent's observation
- *      rows staged in LDS and flushed as 16-byte pieces (`nt`), nothing computed in between;
- *   3  ... with `frame_steps` steps of the frame's own idiom per wave between the loads and the stores (two compares
- *      into SGPR masks, an s_and_b64, a v_cndmask_b32 on it, an add: 4 VALU + 1 SALU per step, every step depending on
- *      the one before), one LDS exchange and one workgroup barrier half way: 102 steps = the 408 VALU instructions a
- *      wave of the shipped human-vs-human frame issues (that count runs as straight-line code like the frame, any
- *      other in a loop of ten steps per trip).
- * The buffers are the shapes pz_step takes (state int32[44][stride >= n], act int32[n], obs int32[n][35], rew int32[n]);
- * from `what` = 2 on state, rewards and observations are OVERWRITTEN with meaningless values: hand it scratch buffers.
- * No reference counterpart; nothing in the library calls it. */
-int pz_probe_launch(int32_t *state, int64_t n, int64_t stride, const int32_t *act_p1, const int32_t *act_p2,
-                    int32_t *obs_p1, int32_t *obs_p2, int32_t *rew_p1, int32_t *rew_p2, int32_t what,
-                    int32_t frame_steps, void *stream);
-
 /* ---- flight look-up tables of the computer player (optional; caller-owned device memory) -----
  * The two flight predictors of the rule-based computer player are pure functions of a few small
  * integers, so they can be tabulated once per device and looked up by the step kernels instead of
@@ -201,7 +181,7 @@ int pz_probe_launch(int32_t *state, int64_t n, int64_t stride, const int32_t *ac
  *              (x_direction, y_direction) candidates of decide_whether_input_power_hit (:796-816):
  *              uint16 [PZ_FT_HIT_YV_MAX+1 |y velocity|][192 y][413 x][8] (y 61..252; entries 6,7 unused).
  * pz_build_flight_tables fills them with the frame-by-frame iteration of the reference (the form
- * pz_selftest_predictor exposes as out_iter).  A ball state outside a table's domain is computed in
+ * pz_selftest_predictor of the diagnostics library, pikazoo_diag.h, exposes as out_iter).  A ball state outside a table's domain is computed in
  * the kernel as before, so results never depend on whether tables are passed. */
 #define PZ_FT_YV_MAX 96
 #define PZ_FT_HIT_YV_MAX 64
@@ -372,17 +352,6 @@ int pz_scenery_track(int32_t *scenery, const int32_t *state, int64_t n, int64_t 
 int pz_render(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg, const int32_t *lanes, int64_t m,
               const uint32_t *atlas, const pz_sprite *sprites, const uint32_t *background,
               int32_t *scenery, uint8_t *frames, void *stream);
-
-/* ---- self-test hook ------------------------------------------------------------------------
- * The computer player's flight predictors (calculate_expected_landing_point_x_for
- * physics.py:643-686 when full_net != 0, expected_landing_point_x_when_power_hit
- * physics.py:848-884 otherwise) evaluated two ways on n caller-supplied ball states
- * (x, y, x_velocity, y_velocity; for the power-hit form the velocities are the already
- * substituted ones): out_fast = the closed-form fast-forward the step kernel uses, out_iter =
- * the frame-by-frame iteration of the reference.  They must be identical. */
-int pz_selftest_predictor(const int32_t *x, const int32_t *y, const int32_t *xv, const int32_t *yv,
-                          int64_t n, int32_t full_net, int32_t *out_fast, int32_t *out_iter,
-                          void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,9 +1,11 @@
-"""Build libpikazoo_hip.so for gfx950 with hipcc (in-tree, no JIT cache).
+"""Build libpikazoo_hip.so -- and beside it libpikazoo_diag.so -- for gfx950 with hipcc (in-tree, no JIT cache).
 
     python pika-zoo_amd/build.py [--force]
 
-The shared library is plain HIP + a C ABI (include/pikazoo_hip.h); it links only against the
-HIP runtime, not against torch.  hipcc cross-compiles without a GPU present.
+The product library is plain HIP + a C ABI (include/pikazoo_hip.h); it links only against the
+HIP runtime, not against torch.  hipcc cross-compiles without a GPU present.  The diagnostics library
+(include/pikazoo_diag.h: pz_probe_launch, pz_selftest_predictor) is compiled from the product's own headers and is
+loaded by bench.py and tests/ only (pika-zoo_amd/diag.py); it carries the same build id.
 """
 from __future__ import annotations
 
@@ -20,8 +22,11 @@ CSRC = PKG_ROOT / "csrc"
 INCLUDE = REPO / "include"
 LIB_DIR = PKG_ROOT / "lib"
 LIB = LIB_DIR / "libpikazoo_hip.so"
+DIAG_LIB = LIB_DIR / "libpikazoo_diag.so"
 SOURCES = [CSRC / "pz_kernels.hip"]
-DEPS = SOURCES + [CSRC / "pz_physics.hpp", CSRC / "pz_packed.hpp", INCLUDE / "pikazoo_hip.h"]
+DIAG_SOURCES = [CSRC / "pz_diag.hip"]
+DEPS = SOURCES + DIAG_SOURCES + [CSRC / "pz_physics.hpp", CSRC / "pz_packed.hpp", CSRC / "pz_memory.hpp",
+                                 INCLUDE / "pikazoo_hip.h", INCLUDE / "pikazoo_diag.h"]
 ARCH = "gfx950"
 # the step kernels' five leading arguments (10 dwords) are preloaded into SGPRs at wave launch (pz_kernels.hip: HotArgs)
 FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-mllvm", "-amdgpu-kernarg-preload-count=10"]
@@ -64,21 +69,28 @@ def library_id(lib: Path = LIB):
 
 
 def needs_build() -> bool:
-    return library_id() != source_id()
+    return library_id() != source_id() or library_id(DIAG_LIB) != source_id()
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
-    if not force and not extra_flags and not needs_build():
-        return LIB
-    LIB_DIR.mkdir(parents=True, exist_ok=True)
+def _compile(out: Path, sources, extra_flags, verbose: bool) -> None:
     # compile to a temporary name and rename: other ranks / processes never see a half-written library
-    tmp = LIB.with_suffix(f".so.tmp{os.getpid()}")
+    tmp = out.with_suffix(f".so.tmp{os.getpid()}")
     cmd = [hipcc_path(), *FLAGS, "-shared", "-fPIC", f'-DPZ_BUILD_ID="{source_id(tuple(extra_flags))}"',
-           f"-I{INCLUDE}", f"-I{CSRC}", *extra_flags, "-o", str(tmp), *map(str, SOURCES)]
+           f"-I{INCLUDE}", f"-I{CSRC}", *extra_flags, "-o", str(tmp), *map(str, sources)]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.replace(tmp, LIB)
+    os.replace(tmp, out)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
+    """The product library (returned) and the diagnostics library beside it (a few seconds)."""
+    want = source_id(tuple(extra_flags))
+    LIB_DIR.mkdir(parents=True, exist_ok=True)
+    if force or extra_flags or library_id(DIAG_LIB) != want:
+        _compile(DIAG_LIB, DIAG_SOURCES, extra_flags, verbose)
+    if force or extra_flags or library_id() != want:
+        _compile(LIB, SOURCES, extra_flags, verbose)
     return LIB
 
 

@@ -1,0 +1,206 @@
+// pz_diag.hip -- libpikazoo_diag.so: diagnostics kept OUT of the product library (include/pikazoo_diag.h).
+//
+//   pz_probe_launch        the single-frame pair launch's geometry, LDS and buffer traffic without its game: what
+//                          bench.py replays beside the headline as `roofline.floor_*`
+//   pz_selftest_predictor  the computer player's flight predictors evaluated by the closed-form fast-forward the step
+//                          kernels use and by the reference's frame-by-frame iteration (tests/test_gpu_parity.py)
+//
+// Built from the product's own headers (pz_physics.hpp: the predictors; pz_memory.hpp: descriptors and the row flush),
+// so what it measures / checks is the product's code, not a copy of it.  Nothing in libpikazoo_hip.so or in the
+// pikazoo_amd package loads this library.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pikazoo_diag.h"
+#include "pikazoo_hip.h"
+#include "pz_physics.hpp"
+#include "pz_memory.hpp"
+
+namespace pz {
+
+// ---- pz_probe_launch: the single-frame pair launch without its game (see the header) -----------------------------
+struct ProbeLaunchArgs {
+    int32_t* state;
+    int64_t n, stride;
+    const int32_t *act1, *act2;
+    int32_t *obs1, *obs2, *rew1, *rew2;
+    int32_t steps;
+};
+
+// one step of the frame's idiom on a <- f(a, b): the SGPR pairs are the compiler's (no fixed register in the text)
+__device__ __forceinline__ void probe_idiom_step(uint32_t& a, uint32_t b)
+{
+    unsigned long long m0, m1;
+    asm volatile(
+        "v_cmp_lt_u32_e64 %1, %0, %3\n\t"
+        "v_cmp_gt_i32_e64 %2, %0, 17\n\t"
+        "s_and_b64 %1, %1, %2\n\t"
+        "v_cndmask_b32_e64 %0, %3, %0, %1\n\t"
+        "v_add_u32_e32 %0, 3, %0"
+        : "+v"(a), "=&s"(m0), "=&s"(m1)
+        : "v"(b)
+        : "scc");  // (s_and_b64 writes SCC: a loop counter's compare must not be scheduled across it)
+}
+
+// `pairs` times (a <- f(a, b), b <- f(b, a)): five pairs per trip, so that the loop's own scalar instructions stay below
+// a tenth of what it times
+__device__ __forceinline__ void probe_idiom_pairs(uint32_t& a, uint32_t& b, int pairs)
+{
+    int k = 0;
+#pragma unroll 1
+    for (; k + 5 <= pairs; k += 5) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            probe_idiom_step(a, b);
+            probe_idiom_step(b, a);
+        }
+    }
+#pragma unroll 1
+    for (; k < pairs; ++k) {
+        probe_idiom_step(a, b);
+        probe_idiom_step(b, a);
+    }
+}
+
+// WHAT as in the header; 4 = 3 with the shipped frame's 102 steps as straight-line code (a taken branch costs a wave
+// some 50 cycles: twenty loop trips would add 0.3 us to what the steps themselves take)
+constexpr int kProbeShippedFrameSteps = 102;
+template <int WHAT>
+__global__ __launch_bounds__(2 * kLanes) void probe_launch_kernel(ProbeLaunchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & (kLanes - 1);
+    const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
+    const uint32_t n32 = (uint32_t)a.n, pitch = (uint32_t)a.stride * 4u, voff = i < a.n ? (uint32_t)i * 4u : ~0u;
+    const Rsrc st = make_rsrc(a.state, (uint32_t)(a.stride * (PZ_STATE_WORDS * 4)));
+    const int first = role * PZ_P_WORDS;
+    uint32_t acc = (uint32_t)lane, other = (uint32_t)lane * 3u;
+    if (WHAT >= 1) {
+        uint32_t w[33];
+#pragma unroll
+        for (int c = 0; c < 13; ++c) w[c] = __builtin_amdgcn_raw_buffer_load_b32(st, voff, (uint32_t)(first + c) * pitch, 0);
+#pragma unroll
+        for (int c = 0; c < 18; ++c) w[13 + c] = __builtin_amdgcn_raw_buffer_load_b32(st, voff, (uint32_t)(26 + c) * pitch, 0);
+        w[31] = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act1, n32 * 4u), voff, 0, 0);
+        w[32] = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act2, n32 * 4u), voff, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 33; ++c) {
+            if (c & 1)
+                acc ^= w[c] + (uint32_t)c;
+            else
+                other += w[c];
+        }
+    }
+    if (WHAT >= 3) {
+        __shared__ int32_t xchg[2 * kLanes];  // (of its own: no second barrier before the rows are staged)
+        const int half = a.steps / 4;  // pairs of steps in front of the exchange, and again behind it
+        if constexpr (WHAT == 4) {
+#pragma unroll
+            for (int k = 0; k < kProbeShippedFrameSteps / 4; ++k) {
+                probe_idiom_step(acc, other);
+                probe_idiom_step(other, acc);
+            }
+        } else {
+            probe_idiom_pairs(acc, other, half);
+        }
+        xchg[(1 - role) * kLanes + lane] = (int32_t)acc;
+        __syncthreads();
+        other ^= (uint32_t)xchg[role * kLanes + lane];
+        if constexpr (WHAT == 4) {
+#pragma unroll
+            for (int k = 0; k < kProbeShippedFrameSteps / 4; ++k) {
+                probe_idiom_step(acc, other);
+                probe_idiom_step(other, acc);
+            }
+        } else {
+            probe_idiom_pairs(acc, other, half);
+        }
+    }
+    acc ^= other;
+    if (WHAT >= 2) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) __builtin_amdgcn_raw_buffer_store_b32(acc + c, st, voff, (uint32_t)(first + c) * pitch, PZ_STATE_AUX);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            __builtin_amdgcn_raw_buffer_store_b32(acc + 7 + c, st, voff, (uint32_t)(26 + role * 4 + c) * pitch, PZ_STATE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(acc, make_rsrc(role == 0 ? a.rew1 : a.rew2, n32 * 4u), voff, 0, 0);
+        int32_t* rows = lds_obs[role];
+#pragma unroll
+        for (int k = 0; k < PZ_OBS_DIM; ++k) rows[lane * PZ_OBS_DIM + k] = (int32_t)(acc + k);
+        wave_lds_handover<false>();
+        flush_rows(rows, role == 0 ? a.obs1 : a.obs2, n32 * kRowBytes, lane);
+    } else if (WHAT >= 1) {
+        // keep the loads alive: a store that the data this probe reads never triggers
+        if (acc == 0xFFFFFFFFu && i == 0) a.rew1[0] = (int32_t)acc;
+    }
+}
+
+// Self-test hook: both forms of the flight predictor on caller-supplied ball states.
+__global__ __launch_bounds__(256) void predictor_selftest_kernel(const int32_t* x, const int32_t* y, const int32_t* xv,
+                                                                 const int32_t* yv, int64_t n, int full_net,
+                                                                 int32_t* out_fast, int32_t* out_iter)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (full_net) {
+        out_fast[i] = predict_landing_x<true>(x[i], y[i], xv[i], yv[i]);
+        out_iter[i] = predict_landing_x_iterative<true>(x[i], y[i], xv[i], yv[i]);
+    } else {
+        out_fast[i] = predict_landing_x<false>(x[i], y[i], xv[i], yv[i]);
+        out_iter[i] = predict_landing_x_iterative<false>(x[i], y[i], xv[i], yv[i]);
+    }
+}
+
+constexpr int64_t kMaxLanesPerLaunch = (int64_t)0xFFFFFFFFu / (PZ_STATE_WORDS * 4);
+static inline bool misaligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+static inline unsigned int blocks_for(int64_t n, int per) { return (unsigned int)((n + per - 1) / per); }
+
+}  // namespace pz
+
+using namespace pz;
+
+extern "C" {
+
+#ifndef PZ_BUILD_ID
+#define PZ_BUILD_ID "unknown"
+#endif
+// (the same record the product library carries: build.py reads it from the file's bytes)
+static const char kDiagBuildIdRecord[] = "pz_build_id:" PZ_BUILD_ID;
+const char* pz_diag_build_id(void) { return kDiagBuildIdRecord + 12; }
+
+int pz_probe_launch(int32_t* state, int64_t n, int64_t stride, const int32_t* act_p1, const int32_t* act_p2, int32_t* obs_p1,
+                    int32_t* obs_p2, int32_t* rew_p1, int32_t* rew_p2, int32_t what, int32_t frame_steps, void* stream)
+{
+    if (!state || !act_p1 || !act_p2 || !obs_p1 || !obs_p2 || !rew_p1 || !rew_p2) return PZ_E_NULL;
+    if (n < 1 || stride < n || stride > kMaxLanesPerLaunch) return PZ_E_SIZE;
+    if (what < 0 || what > 3 || frame_steps < 0 || frame_steps > 4096) return PZ_E_CONFIG;
+    if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
+    const ProbeLaunchArgs a{state, n, stride, act_p1, act_p2, obs_p1, obs_p2, rew_p1, rew_p2, frame_steps};
+    const dim3 grid(blocks_for(n, kLanes)), block(2 * kLanes);
+    switch (what) {
+        case 0: hipLaunchKernelGGL(probe_launch_kernel<0>, grid, block, 0, (hipStream_t)stream, a); break;
+        case 1: hipLaunchKernelGGL(probe_launch_kernel<1>, grid, block, 0, (hipStream_t)stream, a); break;
+        case 2: hipLaunchKernelGGL(probe_launch_kernel<2>, grid, block, 0, (hipStream_t)stream, a); break;
+        default:
+            if (frame_steps == kProbeShippedFrameSteps)
+                hipLaunchKernelGGL(probe_launch_kernel<4>, grid, block, 0, (hipStream_t)stream, a);
+            else
+                hipLaunchKernelGGL(probe_launch_kernel<3>, grid, block, 0, (hipStream_t)stream, a);
+            break;
+    }
+    return (int)hipGetLastError();
+}
+
+int pz_selftest_predictor(const int32_t* x, const int32_t* y, const int32_t* xv, const int32_t* yv, int64_t n,
+                          int32_t full_net, int32_t* out_fast, int32_t* out_iter, void* stream)
+{
+    if (!x || !y || !xv || !yv || !out_fast || !out_iter) return PZ_E_NULL;
+    if (n < 0) return PZ_E_SIZE;
+    if (n == 0) return PZ_OK;
+    hipLaunchKernelGGL(predictor_selftest_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, xv,
+                       yv, n, (int)full_net, out_fast, out_iter);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -27,21 +27,11 @@
 #include "pikazoo_hip.h"
 #include "pz_physics.hpp"
 #include "pz_packed.hpp"
+#include "pz_memory.hpp"
 
 namespace pz {
 
-constexpr int kLanes = PZ_WAVE_GAMES;  // lanes (games) per workgroup = one wavefront
-constexpr uint32_t kRowBytes = PZ_OBS_DIM * 4;            // 140
-constexpr uint32_t kWaveObsBytes = kLanes * kRowBytes;    // 8 960: a wave's rows are contiguous
-constexpr int kWaveObsVecs = (int)(kWaveObsBytes / 16);   // 560 16-byte pieces
-
-// cache-policy bits of the stores (aux operand: 1 = sc0, 2 = nt, 16 = sc1); tools/ab.py variants
-#ifndef PZ_STATE_AUX
-#define PZ_STATE_AUX 0
-#endif
-#ifndef PZ_OBS_AUX
-#define PZ_OBS_AUX 2  // observations are written once and not re-read by the step chain: nt, -2.4 % per launch
-#endif
+// cache-policy knobs of the k-frame launches (aux operand: 1 = sc0, 2 = nt, 16 = sc1; pz_memory.hpp has the single-frame ones)
 #ifndef PZ_HH_ROLLOUT_GENERIC
 #define PZ_HH_ROLLOUT_GENERIC 1  // launch_step_players: the human-vs-human rollout keeps its generic kernel (measured)
 #endif
@@ -69,14 +59,6 @@ constexpr int kWaveObsVecs = (int)(kWaveObsBytes / 16);   // 560 16-byte pieces
 // from the flight tables (3.13 -> 3.11 us per frame, k = 128: 2.99 -> 2.94), plain otherwise (nt: 2.81 -> 2.94)
 constexpr int traj_small_aux(bool computer_player) { return computer_player ? PZ_TRAJ_SMALL_AUX_AI : 0; }
 
-using Rsrc = __amdgpu_buffer_rsrc_t;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// raw buffer descriptor over [p, p + bytes): stride 0, 32-bit data format (gfx9 family word 3)
-__device__ __forceinline__ Rsrc make_rsrc(const void* p, uint32_t bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
-}
 
 // One game's column accessor: wave-uniform descriptor + column pitch, per-lane byte offset.
 struct StateIO {
@@ -439,26 +421,6 @@ __device__ __forceinline__ void stage_obs(const Game& g, int32_t* __restrict__ s
         stage_obs_t<false>(g, s1, s2, lane);
 }
 
-// Copy the wave's 64 staged rows (8 960 B) to its span of an [n][35] tensor (`tensor_bytes` = n rows):
-// 9 passes of 16 B per lane.  The span gets its own descriptor, which ends at row n, so the rows of
-// lanes past the end of the batch are dropped by the range check -- and the stores carry no SGPR offset.
-// That matters: for a buffer store of more than 64 bits WITH an SGPR offset the compiler assumes no
-// wait state is needed before a VALU write of the store's data registers (LLVM
-// GCNHazardRecognizer::createsVALUHazard) and schedules e.g. the next address computation into
-// them; on gfx950 a quarter of the wave then stores the new value (seen as address bits in
-// observation words).  tests/test_cabi_and_host.py scans the built code object for that pattern.
-__device__ __forceinline__ void flush_rows(const int32_t* __restrict__ lds, const void* tensor, uint32_t tensor_bytes,
-                                           int lane)
-{
-    const uint32_t wave_off = blockIdx.x * kWaveObsBytes;
-    const Rsrc span = make_rsrc(static_cast<const char*>(tensor) + wave_off, tensor_bytes - wave_off);
-    const u32x4* src4 = reinterpret_cast<const u32x4*>(lds);
-#pragma unroll
-    for (int pass = 0; pass < (kWaveObsVecs + kLanes - 1) / kLanes; ++pass) {
-        const int v = pass * kLanes + lane;
-        if (v < kWaveObsVecs) __builtin_amdgcn_raw_buffer_store_b128(src4[v], span, (uint32_t)v * 16u, 0, PZ_OBS_AUX);
-    }
-}
 
 // cfg.normalize_obs == 2: int16 observations.  The rows are staged as int32 like always and narrowed on the way out:
 // a lane reads eight staged values (two 16-byte LDS reads) and writes them as one 16-byte piece of the wave's
@@ -533,37 +495,6 @@ __device__ unsigned long long g_pz_stamps[8192 * 8];
 #define PZ_DRAIN_VMEM()
 #define PZ_PAIR_STAMP(role, k)
 #define PZ_PAIR_WHERE(role)
-#endif
-
-#ifdef PZ_ABLATE
-// timing-only build (tools/ablate.py): cfg.packed_state bits 3.. skip parts of the kernel; results are
-// wrong by construction.  bit3: no game logic; bit4: no observation staging / flush;
-// bits 5,6,7: skip the landing predictor before the players / the power-hit candidates / the
-// landing predictor after a collision (pz_physics.hpp); pair kernel also bit 8: no pre-drawn Philox
-// blocks, bit 9: no computer decision at all.
-#define PZ_SKIP_FRAME ((a.cfg.packed_state & 8) != 0)
-#define PZ_SKIP_OBS ((a.cfg.packed_state & 16) != 0)
-#define PZ_SKIP_STATE_STORES ((a.cfg.packed_state & 1024) != 0)  // pair kernel: no state / reward / flag stores
-#define PZ_SKIP_OBS_STORES ((a.cfg.packed_state & 2048) != 0)    // pair kernel: observations staged but not stored
-#elif defined(PZ_CT_ABLATE)
-// compile-time ablations (tools/ab.py -DPZ_CT_ABLATE=bits, see step_games_pair): 256 no state / reward / flag stores,
-// 512 observations staged but not stored -- behind a condition the compiler cannot fold, so that nothing in front of the
-// stores is removed as dead code
-__device__ __forceinline__ bool ct_never()
-{
-    int z;
-    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
-    return z != 0;
-}
-#define PZ_SKIP_FRAME false
-#define PZ_SKIP_OBS false
-#define PZ_SKIP_STATE_STORES ((((PZ_CT_ABLATE) & 256) != 0) && !pz::ct_never())
-#define PZ_SKIP_OBS_STORES ((((PZ_CT_ABLATE) & 512) != 0) && !pz::ct_never())
-#else
-#define PZ_SKIP_FRAME false
-#define PZ_SKIP_OBS false
-#define PZ_SKIP_STATE_STORES false
-#define PZ_SKIP_OBS_STORES false
 #endif
 
 // PLAIN launches (k-frame kernels): no fused wrapper, no episode statistics, raw integer rows.  The configuration words
@@ -788,7 +719,7 @@ __device__ __forceinline__ void stats_update(EpisodeStats& st, const pz_config& 
 // tensors through the LDS transpose.  `t` = frame index inside a trajectory (0 otherwise).
 __device__ __forceinline__ void emit_outputs(const StepArgs& a, const Game& g, const Rewards& r, bool as_float,
                                              bool live, int64_t i, int lane, int64_t t,
-                                             int32_t (*lds_obs)[kLanes * PZ_OBS_DIM], bool skip_obs)
+                                             int32_t (*lds_obs)[kLanes * PZ_OBS_DIM])
 {
     const uint32_t n32 = (uint32_t)a.n;
     const uint32_t voff = (uint32_t)i * 4u;
@@ -801,14 +732,12 @@ __device__ __forceinline__ void emit_outputs(const StepArgs& a, const Game& g, c
         __builtin_amdgcn_raw_buffer_store_b32(as_float ? __float_as_uint(r.f2) : (unsigned int)r.i2, rew2, voff, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)g.e.game_ended, term, (uint32_t)i, 0, 0);
         PZ_STAMP(3);
-        if (!skip_obs) stage_obs(g, lds_obs[0], lds_obs[1], lane, a.cfg.normalize_obs == 1);
+        stage_obs(g, lds_obs[0], lds_obs[1], lane, a.cfg.normalize_obs == 1);
     }
     __syncthreads();
     PZ_STAMP(4);
-    if (!skip_obs) {
-        flush_obs(lds_obs[0], a.obs_p1, t, a.n, a.cfg.normalize_obs, lane);
-        flush_obs(lds_obs[1], a.obs_p2, t, a.n, a.cfg.normalize_obs, lane);
-    }
+    flush_obs(lds_obs[0], a.obs_p1, t, a.n, a.cfg.normalize_obs, lane);
+    flush_obs(lds_obs[1], a.obs_p2, t, a.n, a.cfg.normalize_obs, lane);
 }
 
 // ---- outputs of one frame of a trajectory launch (kRollout / kTape) ------------------------------------------------
@@ -1128,9 +1057,6 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
     bool frozen = false;
     bool ex_pending = false;  // SCOUT: the scout wave stores this lane's expected_landing_point_x
     unsigned int finished = 0;
-#ifdef PZ_ABLATE
-    g_pz_ablate_bits = a.cfg.packed_state;  // every lane stores the same value; read by the predictor hooks
-#endif
     PZ_STAMP(0);
     int a1 = 0, a2 = 0;
     if (MODE == kActions) {  // rows past n read as 0 through the range check
@@ -1238,7 +1164,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
         // the launch's last recorded boldness draws (physics.py:218)
         if (kDefer1 && bold.pending1) g.p1.bold = rng_integers(id, bold.counter1, 5u);
         if (kDefer2 && bold.pending2) g.p2.bold = rng_integers(id, bold.counter2, 5u);
-    } else if (!PZ_SKIP_FRAME) {
+    } else {
         const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
         reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane, lut,
                                              ScoutLink{cand, hits, posts}, &ex_pending);
@@ -1262,7 +1188,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
         }
         if (with_stats) sio.store(st);
     }
-    if (MODE != kRollout && MODE != kTape) emit_outputs(a, g, rw, as_float, live, i, lane, 0, lds_obs, PZ_SKIP_OBS);
+    if (MODE != kRollout && MODE != kTape) emit_outputs(a, g, rw, as_float, live, i, lane, 0, lds_obs);
     PZ_STAMP(5);
     PZ_DRAIN_VMEM();
     PZ_STAMP(6);
@@ -1321,6 +1247,33 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     const FlightLut lut = make_lut(a.tables);
     PZ_PAIR_STAMP(ROLE, 0);
     PZ_PAIR_WHERE(ROLE);
+    // ---- one computer player: who may store what, and when ("the ordering argument") ----------------------
+    // The human player's wave reaches the exchange barrier ~1 000 cycles before its partner (tools/stamps.py) and stores,
+    // while it waits, columns that are final by then (kEarlyOwn / kEarlyBall below).  The computer's wave LOADS some of
+    // those very columns at the top of the launch -- the ball, and the human player's x / state / diving direction, from
+    // which it re-derives that player's move.  A store in front of the barrier is ordered behind those loads by nothing
+    // but this hand-shake: the human player's wave clears one LDS word before anything else; the computer's wave waits
+    // until every one of its state loads has RETURNED (s_waitcnt vmcnt(0): the values are in its registers) and then sets
+    // the word; the human player's wave reads it in front of the barrier and stores early only if it is set.  If it is
+    // not (the partner was held back: preemption, a debugger, an instruction-cache miss) -- or the set was overtaken by
+    // the clear -- the same stores are issued behind the barrier like every other store of the frame: slower by the
+    // ~2 % the early stores gain, never different.  (tests: -DPZ_DEV_DELAY_PARTNER_LOADS holds the computer's wave back
+    // for ~16 000 cycles in front of its first load; bit-exact with the hand-shake, wrong without it,
+    // profiles/r05_experiments/early_store_edge_*.log.)
+    constexpr bool kOneComputer = PZ_EARLY_OWN_STORES != 0 && !PACKED && (AI1 != AI2);
+    constexpr int kHumanRole = AI1 ? 1 : 0;
+    constexpr int kLoadsDoneAt = 2048;  // word of the human wave's exchange region (rows 0..1151 carry the exchange)
+    constexpr int32_t kLoadsDone = 0x10ADD0E5;
+    static_assert(kLoadsDoneAt >= kEarlyPostAt + 2 * kLanes && kLoadsDoneAt < kLanes * PZ_OBS_DIM, "inside the region, past the posts");
+    // (relaxed workgroup-scope atomics: plain ds_write_b32 / ds_read_b32 that the compiler neither drops nor merges --
+    // a `volatile` pointer would keep the generic address space and turn them into flat_ accesses)
+    int32_t* const partner_loaded = xchg + kHumanRole * (kLanes * PZ_OBS_DIM) + kLoadsDoneAt;
+    if (kOneComputer && !kOwnAI && lane == 0)
+        __hip_atomic_store(partner_loaded, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef PZ_DEV_DELAY_PARTNER_LOADS  // (diagnostic builds only: see above)
+    if (kOneComputer && kOwnAI)
+        for (int nap = 0; nap < (PZ_DEV_DELAY_PARTNER_LOADS); ++nap) __builtin_amdgcn_s_sleep(127);
+#endif
     int a1 = 0, a2 = 0;
     if (!RANDOM) {
         a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.voff, 0, 0);
@@ -1367,6 +1320,11 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         }
         if (with_stats) sio.load(st);
     }
+    if (kOneComputer && kOwnAI) {
+        // every load above has returned -- the gathers' addresses need the ball columns next anyway -- then tell the partner
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(partner_loaded, kLoadsDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     if (RANDOM)  // (issued behind the loads: the block runs while they are in flight)
         policy_actions(id.id_lo, id.id_hi, make_rolling_key(a.action_seed), a.t0, a.cfg.simplify_action ? 13u : 18u, a1, a2);
     const Game loaded = g;  // what the columns held before the frame
@@ -1374,45 +1332,48 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     bool frozen = false;
     PZ_DRAIN_VMEM();
     PZ_PAIR_STAMP(ROLE, 1);
-#ifdef PZ_ABLATE
-    // read by the hooks in pz_physics.hpp; one lane of the launch writes it (131 072 same-address stores would be the
-    // slowest thing in the kernel), the launches of one variant run back to back with the same bits
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_pz_ablate_bits = a.cfg.packed_state;
-#endif
     LandingProbe after_hit{false, false, 0u, 0u};
     bool bold_pending = false;  // a human player's new-round boldness draw, made behind the stores
-    // In a launch with ONE computer player the human player's wave reaches the exchange barrier ~1 000 cycles before its
-    // partner (tools/stamps.py): while it waits it puts on their way (1) its own player's columns -- final once it has
-    // moved; the collision flag follows behind the barrier -- (interleaved A/B, config 3, cold tape: 8.58 -> 8.44 us per
-    // launch; human vs human, where nobody waits, the same stores gained nothing in round 2)
+    // In a launch with ONE computer player the human player's wave puts on their way, while it waits at the barrier,
+    // (1) its own player's columns -- final once it has moved; the collision flag follows behind the barrier --
+    // (interleaved A/B, config 3, cold tape: 8.58 -> 8.44 us per launch; human vs human, where nobody waits, the same
+    // stores gained nothing in round 2)
     // (the computer's wave doing the same with its player costs: 8.36 -> 8.54, profiles/r04_experiments/)
-    constexpr bool kEarlyOwn = PZ_EARLY_OWN_STORES != 0 && !PACKED && (AI1 != AI2) && !kOwnAI;
+    constexpr bool kEarlyOwn = kOneComputer && !kOwnAI;
     // ... and (2) the ball's position, trail and rotation: final once the world step has run (a ball-player collision
     // changes velocities, power-hit flag and punch_effect_x only) -- the human player's wave stores all seven, the
     // computer's wave none of them (8.44 -> 8.40; hot tape 8.30 -> 8.17 -> 8.15: profiles/r04_experiments/).  (Letting the
     // human player's wave SLEEP 256 - 1 536 cycles before its frame, so that the computer's wave has the SIMD to itself
     // up to its gathers, changes nothing: 8.38 -> 8.40 - 8.42, and 8.57 when it sleeps past its slack.)
     constexpr bool kEarlyBall = kEarlyOwn && PZ_EARLY_OWN_STORES >= 2;
-    constexpr bool kPartnerStoresBall = PZ_EARLY_OWN_STORES >= 2 && !PACKED && (AI1 != AI2) && kOwnAI;
-    int coll_before = 0;
+    constexpr bool kPartnerStoresBall = PZ_EARLY_OWN_STORES >= 2 && kOneComputer && kOwnAI;
+    bool stored_early = false;  // wave-uniform: the partner's loads were known to be back in front of the barrier
+    auto store_ball_trail = [&]() {  // the human wave's seven ball columns (kEarlyBall): early, or behind the barrier
+        io.st(PZ_B_X, g.b.x);
+        io.st(PZ_B_Y, g.b.y);
+        io.st(PZ_B_PREVIOUS_X, g.b.px);
+        io.st(PZ_B_PREVIOUS_Y, g.b.py);
+        io.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
+        io.st(PZ_B_PREVIOUS_PREVIOUS_Y, g.b.ppy);
+        io.st(PZ_B_FINE_ROTATION, g.b.rot);
+    };
     auto before_barrier = [&]() {
         if constexpr (kEarlyOwn) {
-            if (live && !PZ_SKIP_STATE_STORES) {
+#ifdef PZ_DEV_UNORDERED_EARLY_STORES  // (diagnostic builds only: round 4's form, no hand-shake)
+            stored_early = true;
+#else
+            asm volatile("" ::: "memory");  // (read here, in front of the barrier: as late as the stores allow)
+            stored_early = __builtin_amdgcn_readfirstlane(__hip_atomic_load(partner_loaded, __ATOMIC_RELAXED,
+                                                                           __HIP_MEMORY_SCOPE_WORKGROUP)) == kLoadsDone;
+#endif
+            if (stored_early && live) {
                 Player& mine = ROLE == 0 ? g.p1 : g.p2;
                 const Player& was = ROLE == 0 ? loaded.p1 : loaded.p2;
-                coll_before = mine.coll;
+                const int coll_now = mine.coll;
                 mine.coll = was.coll;  // (not final yet: stored behind the barrier when it changed)
                 store_player_changed(mine, was, io, kOwn);
-                mine.coll = coll_before;
-                if constexpr (kEarlyBall) {
-                    io.st(PZ_B_X, g.b.x);
-                    io.st(PZ_B_Y, g.b.y);
-                    io.st(PZ_B_PREVIOUS_X, g.b.px);
-                    io.st(PZ_B_PREVIOUS_Y, g.b.py);
-                    io.st(PZ_B_PREVIOUS_PREVIOUS_X, g.b.ppx);
-                    io.st(PZ_B_PREVIOUS_PREVIOUS_Y, g.b.ppy);
-                    io.st(PZ_B_FINE_ROTATION, g.b.rot);
-                }
+                mine.coll = coll_now;
+                if constexpr (kEarlyBall) store_ball_trail();
             }
         }
     };
@@ -1424,23 +1385,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
 
     // the two halves of the write-back; their order is a compile-time choice (below)
     auto store_state = [&]() {
-#ifdef PZ_ABLATE
-        if (live && (a.cfg.packed_state & 4096) != 0 && a.episode_stats != nullptr) {
-            // timing-only: what the always-written part of the state would cost as 16-byte column groups: three groups
-            // per wave into a scratch buffer handed in through the (unused) statistics pointer
-            const Rsrc scratch = make_rsrc(a.episode_stats, (uint32_t)(a.stride * 96));
-            const Player& p = ROLE == 0 ? g.p1 : g.p2;
-            const u32x4 w0 = {(uint32_t)p.x, (uint32_t)p.y, (uint32_t)p.yv, (uint32_t)p.frame};
-            const u32x4 w1 = {(uint32_t)p.delay, (uint32_t)p.hitprev, (uint32_t)p.state, (uint32_t)p.arm};
-            const u32x4 w2 = ROLE == 0 ? u32x4{(uint32_t)g.b.x, (uint32_t)g.b.y, (uint32_t)g.b.yv, (uint32_t)g.b.rot}
-                                       : u32x4{(uint32_t)g.b.px, (uint32_t)g.b.py, (uint32_t)g.b.ppx, (uint32_t)g.b.ppy};
-            const uint32_t pitch = (uint32_t)a.stride * 16u;
-            __builtin_amdgcn_raw_buffer_store_b128(w0, scratch, (uint32_t)i * 16u, (uint32_t)(ROLE * 3 + 0) * pitch, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(w1, scratch, (uint32_t)i * 16u, (uint32_t)(ROLE * 3 + 1) * pitch, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(w2, scratch, (uint32_t)i * 16u, (uint32_t)(ROLE * 3 + 2) * pitch, 0);
-        }
-#endif
-        if (!live || PZ_SKIP_STATE_STORES) return;
+        if (!live) return;
         if constexpr (PACKED) {
             if (ROLE == 0) {
                 pio.st_a(pack_group_a(g, sticky));
@@ -1458,11 +1403,12 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
             return;
         }
         // changed-only write-back of the rarely changing columns, as in store_game_changed
-        if constexpr (kEarlyOwn) {
+        if (kEarlyOwn && stored_early) {
             const Player& mine = ROLE == 0 ? g.p1 : g.p2;
             if (mine.coll != (ROLE == 0 ? loaded.p1 : loaded.p2).coll) io.st(kOwn + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED, mine.coll);
         } else {
             store_player_changed(ROLE == 0 ? g.p1 : g.p2, ROLE == 0 ? loaded.p1 : loaded.p2, io, kOwn);
+            if (kEarlyBall) store_ball_trail();  // (the partner was late: what the early stores would have carried)
         }
         if (ROLE == 0) {
             if (!kEarlyBall && !kPartnerStoresBall) {
@@ -1509,7 +1455,6 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         // so only the compiler has to be kept from reordering them -- no second workgroup barrier (7.24 -> 7.12 us).
         wave_lds_handover<false>();
         PZ_PAIR_STAMP(ROLE, 4);
-        if (PZ_SKIP_OBS_STORES) return;
         flush_obs(lds_obs[ROLE], ROLE == 0 ? a.obs_p1 : a.obs_p2, 0, a.n, a.cfg.normalize_obs, lane);
         PZ_PAIR_STAMP(ROLE, 5);
     };
@@ -1949,123 +1894,6 @@ __global__ __launch_bounds__(64) void probe_write_kernel(char* a, char* b, int32
 }
 
 
-// ---- pz_probe_launch: the single-frame pair launch without its game (see the header) -----------------------------
-struct ProbeLaunchArgs {
-    int32_t* state;
-    int64_t n, stride;
-    const int32_t *act1, *act2;
-    int32_t *obs1, *obs2, *rew1, *rew2;
-    int32_t steps;
-};
-
-// one step of the frame's idiom on a <- f(a, b): the SGPR pairs are the compiler's (no fixed register in the text)
-__device__ __forceinline__ void probe_idiom_step(uint32_t& a, uint32_t b)
-{
-    unsigned long long m0, m1;
-    asm volatile(
-        "v_cmp_lt_u32_e64 %1, %0, %3\n\t"
-        "v_cmp_gt_i32_e64 %2, %0, 17\n\t"
-        "s_and_b64 %1, %1, %2\n\t"
-        "v_cndmask_b32_e64 %0, %3, %0, %1\n\t"
-        "v_add_u32_e32 %0, 3, %0"
-        : "+v"(a), "=&s"(m0), "=&s"(m1)
-        : "v"(b)
-        : "scc");  // (s_and_b64 writes SCC: a loop counter's compare must not be scheduled across it)
-}
-
-// `pairs` times (a <- f(a, b), b <- f(b, a)): five pairs per trip, so that the loop's own scalar instructions stay below
-// a tenth of what it times
-__device__ __forceinline__ void probe_idiom_pairs(uint32_t& a, uint32_t& b, int pairs)
-{
-    int k = 0;
-#pragma unroll 1
-    for (; k + 5 <= pairs; k += 5) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            probe_idiom_step(a, b);
-            probe_idiom_step(b, a);
-        }
-    }
-#pragma unroll 1
-    for (; k < pairs; ++k) {
-        probe_idiom_step(a, b);
-        probe_idiom_step(b, a);
-    }
-}
-
-// WHAT as in the header; 4 = 3 with the shipped frame's 102 steps as straight-line code (a taken branch costs a wave
-// some 50 cycles: twenty loop trips would add 0.3 us to what the steps themselves take)
-constexpr int kProbeShippedFrameSteps = 102;
-template <int WHAT>
-__global__ __launch_bounds__(2 * kLanes) void probe_launch_kernel(ProbeLaunchArgs a)
-{
-    __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & (kLanes - 1);
-    const int64_t i = (int64_t)blockIdx.x * kLanes + lane;
-    const uint32_t n32 = (uint32_t)a.n, pitch = (uint32_t)a.stride * 4u, voff = i < a.n ? (uint32_t)i * 4u : ~0u;
-    const Rsrc st = make_rsrc(a.state, (uint32_t)(a.stride * (PZ_STATE_WORDS * 4)));
-    const int first = role * PZ_P_WORDS;
-    uint32_t acc = (uint32_t)lane, other = (uint32_t)lane * 3u;
-    if (WHAT >= 1) {
-        uint32_t w[33];
-#pragma unroll
-        for (int c = 0; c < 13; ++c) w[c] = __builtin_amdgcn_raw_buffer_load_b32(st, voff, (uint32_t)(first + c) * pitch, 0);
-#pragma unroll
-        for (int c = 0; c < 18; ++c) w[13 + c] = __builtin_amdgcn_raw_buffer_load_b32(st, voff, (uint32_t)(26 + c) * pitch, 0);
-        w[31] = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act1, n32 * 4u), voff, 0, 0);
-        w[32] = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a.act2, n32 * 4u), voff, 0, 0);
-#pragma unroll
-        for (int c = 0; c < 33; ++c) {
-            if (c & 1)
-                acc ^= w[c] + (uint32_t)c;
-            else
-                other += w[c];
-        }
-    }
-    if (WHAT >= 3) {
-        __shared__ int32_t xchg[2 * kLanes];  // (of its own: no second barrier before the rows are staged)
-        const int half = a.steps / 4;  // pairs of steps in front of the exchange, and again behind it
-        if constexpr (WHAT == 4) {
-#pragma unroll
-            for (int k = 0; k < kProbeShippedFrameSteps / 4; ++k) {
-                probe_idiom_step(acc, other);
-                probe_idiom_step(other, acc);
-            }
-        } else {
-            probe_idiom_pairs(acc, other, half);
-        }
-        xchg[(1 - role) * kLanes + lane] = (int32_t)acc;
-        __syncthreads();
-        other ^= (uint32_t)xchg[role * kLanes + lane];
-        if constexpr (WHAT == 4) {
-#pragma unroll
-            for (int k = 0; k < kProbeShippedFrameSteps / 4; ++k) {
-                probe_idiom_step(acc, other);
-                probe_idiom_step(other, acc);
-            }
-        } else {
-            probe_idiom_pairs(acc, other, half);
-        }
-    }
-    acc ^= other;
-    if (WHAT >= 2) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) __builtin_amdgcn_raw_buffer_store_b32(acc + c, st, voff, (uint32_t)(first + c) * pitch, PZ_STATE_AUX);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            __builtin_amdgcn_raw_buffer_store_b32(acc + 7 + c, st, voff, (uint32_t)(26 + role * 4 + c) * pitch, PZ_STATE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b32(acc, make_rsrc(role == 0 ? a.rew1 : a.rew2, n32 * 4u), voff, 0, 0);
-        int32_t* rows = lds_obs[role];
-#pragma unroll
-        for (int k = 0; k < PZ_OBS_DIM; ++k) rows[lane * PZ_OBS_DIM + k] = (int32_t)(acc + k);
-        wave_lds_handover<false>();
-        flush_rows(rows, role == 0 ? a.obs1 : a.obs2, n32 * kRowBytes, lane);
-    } else if (WHAT >= 1) {
-        // keep the loads alive: a store that the data this probe reads never triggers
-        if (acc == 0xFFFFFFFFu && i == 0) a.rew1[0] = (int32_t)acc;
-    }
-}
 
 // ---- int32 columns <-> packed format (pz_pack_state / pz_unpack_state) ----------------------------------------
 __global__ __launch_bounds__(kLanes) void pack_state_kernel(const int32_t* state, int64_t n, int64_t stride, void* packed,
@@ -2376,21 +2204,6 @@ __global__ __launch_bounds__(256) void render_kernel(const int32_t* __restrict__
     out[2] = r2;
 }
 
-// Self-test hook: both forms of the flight predictor on caller-supplied ball states.
-__global__ __launch_bounds__(256) void predictor_selftest_kernel(const int32_t* x, const int32_t* y, const int32_t* xv,
-                                                                 const int32_t* yv, int64_t n, int full_net,
-                                                                 int32_t* out_fast, int32_t* out_iter)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    if (full_net) {
-        out_fast[i] = predict_landing_x<true>(x[i], y[i], xv[i], yv[i]);
-        out_iter[i] = predict_landing_x_iterative<true>(x[i], y[i], xv[i], yv[i]);
-    } else {
-        out_fast[i] = predict_landing_x<false>(x[i], y[i], xv[i], yv[i]);
-        out_iter[i] = predict_landing_x_iterative<false>(x[i], y[i], xv[i], yv[i]);
-    }
-}
 
 // ---- host side ---------------------------------------------------------------------------------
 // Buffer descriptors address with 32-bit byte offsets: one launch handles at most this many games
@@ -2429,9 +2242,7 @@ static int check_common(const void* state, int64_t n, int64_t stride, const pz_c
         cfg->normal_state_mode > 2 || cfg->episode_stats_mode < 0 || cfg->episode_stats_mode > 2 ||
         cfg->normalize_obs < 0 || cfg->normalize_obs > 2)
         return PZ_E_CONFIG;
-#ifndef PZ_ABLATE  // the timing-only build passes its switches in the upper bits of this field
     if (cfg->packed_state != 0 && cfg->packed_state != 1) return PZ_E_CONFIG;
-#endif
     if (is_packed(*cfg)) {
         if (cfg->winning_score > 65535) return PZ_E_CONFIG;  // the scores are 16-bit fields
         if (misaligned16(state)) return PZ_E_ALIGN;
@@ -2562,7 +2373,7 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
         return launch_pair<false, false, true>(a, stream);
     }
 #endif
-#if !defined(PZ_NO_ROLLOUT_PAIR) && !defined(PZ_ABLATE) && !defined(PZ_STAMPS)
+#if !defined(PZ_NO_ROLLOUT_PAIR) && !defined(PZ_STAMPS)
     // pz_rollout_random / pz_step_many with a computer player on the flight tables: two waves per 64 games below the size switch
     // (interleaved A/B, us per frame at k = 32: 3.49 vs 4.34 on one wave; human vs human the single wave is at the
     // write ceiling already: 3.62 on two waves -- player 1's writing all outputs -- vs 3.63 on one, 3.76 with the
@@ -2615,7 +2426,7 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
     // the packed format: pair kernel above, else one wave per workgroup (a computer player without tables computes its
     // flights in that wave: no scout)
     if (is_packed(a.cfg)) return launch_step_ai<MODE, false, true>(a, stream);
-#if !defined(PZ_NO_SCOUT_WAVE) && !defined(PZ_ABLATE) && !defined(PZ_STAMPS)
+#if !defined(PZ_NO_SCOUT_WAVE) && !defined(PZ_STAMPS)
     if (a.n < PZ_TWO_WAVE_MAX_LANES && !tables) {  // a computer player is present (else: pair kernel above)
         constexpr int kScout = MODE == kActions ? kScoutLoads : kScoutPosted;
         constexpr bool kSparse = MODE == kActions || MODE == kRandom;
@@ -2757,28 +2568,6 @@ int pz_probe_write(void* a, void* b, int64_t bytes, void* stream)
 
 int64_t pz_probe_frame_bytes(void) { return kProbeFrameBytes; }
 
-int pz_probe_launch(int32_t* state, int64_t n, int64_t stride, const int32_t* act_p1, const int32_t* act_p2, int32_t* obs_p1,
-                    int32_t* obs_p2, int32_t* rew_p1, int32_t* rew_p2, int32_t what, int32_t frame_steps, void* stream)
-{
-    if (!state || !act_p1 || !act_p2 || !obs_p1 || !obs_p2 || !rew_p1 || !rew_p2) return PZ_E_NULL;
-    if (n < 1 || stride < n || stride > kMaxLanesPerLaunch) return PZ_E_SIZE;
-    if (what < 0 || what > 3 || frame_steps < 0 || frame_steps > 4096) return PZ_E_CONFIG;
-    if (misaligned16(obs_p1) || misaligned16(obs_p2)) return PZ_E_ALIGN;
-    const ProbeLaunchArgs a{state, n, stride, act_p1, act_p2, obs_p1, obs_p2, rew_p1, rew_p2, frame_steps};
-    const dim3 grid(blocks_for(n, kLanes)), block(2 * kLanes);
-    switch (what) {
-        case 0: hipLaunchKernelGGL(probe_launch_kernel<0>, grid, block, 0, (hipStream_t)stream, a); break;
-        case 1: hipLaunchKernelGGL(probe_launch_kernel<1>, grid, block, 0, (hipStream_t)stream, a); break;
-        case 2: hipLaunchKernelGGL(probe_launch_kernel<2>, grid, block, 0, (hipStream_t)stream, a); break;
-        default:
-            if (frame_steps == kProbeShippedFrameSteps)
-                hipLaunchKernelGGL(probe_launch_kernel<4>, grid, block, 0, (hipStream_t)stream, a);
-            else
-                hipLaunchKernelGGL(probe_launch_kernel<3>, grid, block, 0, (hipStream_t)stream, a);
-            break;
-    }
-    return (int)hipGetLastError();
-}
 
 int pz_count_packed_misfits(const void* packed, int64_t n, int64_t packed_stride, int64_t* flagged, void* stream)
 {
@@ -2955,16 +2744,6 @@ int pz_render(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, c
     return (int)hipGetLastError();
 }
 
-int pz_selftest_predictor(const int32_t* x, const int32_t* y, const int32_t* xv, const int32_t* yv, int64_t n,
-                          int32_t full_net, int32_t* out_fast, int32_t* out_iter, void* stream)
-{
-    if (!x || !y || !xv || !yv || !out_fast || !out_iter) return PZ_E_NULL;
-    if (n < 0) return PZ_E_SIZE;
-    if (n == 0) return PZ_OK;
-    hipLaunchKernelGGL(predictor_selftest_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, xv,
-                       yv, n, (int)full_net, out_fast, out_iter);
-    return (int)hipGetLastError();
-}
 
 #ifdef PZ_STAMPS
 int pz_debug_read_stamps(unsigned long long* dst_host, int64_t count)

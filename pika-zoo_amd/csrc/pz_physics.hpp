@@ -22,14 +22,6 @@
 
 namespace pz {
 
-// timing-only ablation hooks (tools/ablate.py builds with -DPZ_ABLATE; never defined in the product)
-#ifdef PZ_ABLATE
-__device__ int g_pz_ablate_bits;
-#define PZ_ABLATE_SKIP(bit) ((g_pz_ablate_bits & (bit)) != 0)
-#else
-#define PZ_ABLATE_SKIP(bit) false
-#endif
-
 // per-wave sub-phase stamps of the frame (tools/stamps.py builds with -DPZ_STAMPS; never in the product)
 #ifdef PZ_STAMPS
 __device__ unsigned long long g_pz_frame_stamps[8192 * 8];
@@ -744,7 +736,7 @@ __device__ __forceinline__ void wave_power_hit_candidates(bool need, const Ball&
             const int xdir = candidate_xdir(c), ydir = candidate_ydir(c);
             const int sxv = (sx < kGroundHalfWidth) ? (xdir + 1) * 10 : -(xdir + 1) * 10;  // :841-844
             const int syv = sayv * ydir * 2;                                              // :845
-            scratch[192 + item] = PZ_ABLATE_SKIP(64) ? sx : predict_landing_x<false>(sx, sy, sxv, syv);
+            scratch[192 + item] = predict_landing_x<false>(sx, sy, sxv, syv);
         }
     }
     wave_lds_handover<LONE_WAVE>();
@@ -1152,7 +1144,7 @@ __device__ __forceinline__ int frame_tail(Game& g, const pz_config& cfg, const R
         if ((AI1 || AI2) && active) {
             // :314-315 recomputes the landing point before each player; the ball does not move
             // between the two calls, so one evaluation serves both.
-            g.b.ex = PZ_ABLATE_SKIP(32) ? g.b.x : lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
+            g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
         }
 
         if (AI1) {
@@ -1228,7 +1220,7 @@ __device__ __forceinline__ int frame_tail(Game& g, const pz_config& cfg, const R
             if (SCOUT == kScoutLoads)
                 hit_for_scout = true;
             else
-                g.b.ex = PZ_ABLATE_SKIP(128) ? g.b.x : lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
+                g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
         }
     }
     if (SCOUT == kScoutLoads) {
@@ -1347,27 +1339,18 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
                 own.bold = keep;
                 bold_pending = true;
             } else {
-#ifdef PZ_CT_ABLATE
-                if (PZ_CT_ABLATE & 16) {
+                if (kOwnAI) {
+                    // the computer's own boldness is read by its decision only: drawn behind the issue of the frame's
+                    // two gathers, whose latency has room for a fourth Philox block (8.62 -> 8.53 us per launch, packed
+                    // 7.46 -> 7.32, with the computer's wave at priority 1; without it, round 2: 8.39 -> 8.48)
                     const int keep = own.bold;
                     player_new_round_undrawn(own, ROLE == 0 ? 36 : kGroundWidth - 36);
                     own.bold = keep;
-                } else
-#endif
-                {
-                    if (kOwnAI) {
-                        // the computer's own boldness is read by its decision only: drawn behind the issue of the frame's
-                        // two gathers, whose latency has room for a fourth Philox block (8.62 -> 8.53 us per launch, packed
-                        // 7.46 -> 7.32, with the computer's wave at priority 1; without it, round 2: 8.39 -> 8.48)
-                        const int keep = own.bold;
-                        player_new_round_undrawn(own, ROLE == 0 ? 36 : kGroundWidth - 36);
-                        own.bold = keep;
-                        bold_late = true;
-                        bold_counter = g.e.rng + (uint32_t)ROLE;
-                    } else {
-                        uint32_t own_draw = g.e.rng + (uint32_t)ROLE;
-                        player_new_round(own, ROLE == 0 ? 36 : kGroundWidth - 36, id, own_draw);
-                    }
+                    bold_late = true;
+                    bold_counter = g.e.rng + (uint32_t)ROLE;
+                } else {
+                    uint32_t own_draw = g.e.rng + (uint32_t)ROLE;
+                    player_new_round(own, ROLE == 0 ? 36 : kGroundWidth - 36, id, own_draw);
                 }
             }
             other.x = ROLE == 0 ? kGroundWidth - 36 : 36;
@@ -1414,22 +1397,9 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             const bool scan = power_hit_scan_needed(own, g.b);
             const int ayv = abs(g.b.yv);
             int ex[6] = {0, 0, 0, 0, 0, 0};
-#ifdef PZ_CT_ABLATE
-            // Timing-only variants decided at COMPILE time (tools/ab.py with -DPZ_CT_ABLATE=bits; results are wrong by
-            // construction): 1 no pre-drawn Philox words, 2 no landing look-up, 4 no candidate look-up, 8 no decision,
-            // 16 no boldness draw at a round start, 32 no look-up after a collision.  (The run-time hooks of PZ_ABLATE read
-            // their bits from memory in front of every part they guard, which costs more than most of the parts.)
-            LandingProbe lp = (PZ_CT_ABLATE & 2) ? LandingProbe{false, false, 0u, (uint32_t)g.b.x}
-                                                 : lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv);
-            CandidateProbe cp = (PZ_CT_ABLATE & 4) ? CandidateProbe{false, false, lut_u32x4{(uint32_t)g.b.x, (uint32_t)g.b.y, 7u, 0u}}
-                                                   : lut.candidates_issue(scan, g.b.x, g.b.y, ayv);
-            PreDrawn pre = (PZ_CT_ABLATE & 1) ? PreDrawn{(uint32_t)g.b.x * 2654435761u, (uint32_t)g.b.y * 2654435761u, 1u}
-                                              : predraw3(id, rng_base + draws_other);
-#else
             LandingProbe lp = lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv);
-            CandidateProbe cp = lut.candidates_issue(scan && !PZ_ABLATE_SKIP(64), g.b.x, g.b.y, ayv);
-            PreDrawn pre = PZ_ABLATE_SKIP(256) ? PreDrawn{1u, 1u, 1u} : predraw3(id, rng_base + draws_other);
-#endif
+            CandidateProbe cp = lut.candidates_issue(scan, g.b.x, g.b.y, ayv);
+            PreDrawn pre = predraw3(id, rng_base + draws_other);
             if (__builtin_amdgcn_ballot_w64(bold_late) != 0ull) {  // (wave-uniform: a lane of the wave starts a round)
                 const int drawn = rng_integers(id, bold_counter, 5u);
                 own.bold = bold_late ? drawn : own.bold;
@@ -1446,15 +1416,9 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
                 const int nx = min(max(other.x + vx, kPlayerHalfLength), kGroundHalfWidth - kPlayerHalfLength);
                 other.x = (other.state == 4) ? other.x : nx;
             }
-            g.b.ex = PZ_ABLATE_SKIP(32) ? g.b.x : lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, 0);
+            g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, 0);
             lut.candidates_finish(cp, g.b.x, g.b.y, ayv, ex);
-#ifdef PZ_CT_ABLATE
-            if (PZ_CT_ABLATE & 8) {  // no decision: the decoded action stands, the inputs are kept alive
-                in_own.xd = (int)((pre.w0 ^ pre.w1 ^ pre.w2 ^ (uint32_t)(ex[0] + ex[5] + g.b.ex)) & 1u);
-            } else
-#endif
-            if (!PZ_ABLATE_SKIP(512))
-                draws_own = computer_decide_predrawn<ROLE == 1>(own, g.b, other.x, pre, scan, ex, in_own);
+            draws_own = computer_decide_predrawn<ROLE == 1>(own, g.b, other.x, pre, scan, ex, in_own);
         }
     }
     if (active) player_move<ROLE == 1>(own, in_own);
@@ -1528,17 +1492,13 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
         g.e.round_ended = ground;
         reward = ground ? (p2_scores ? -1 : 1) : 0;
 
-        hit_processed = (hit1 | hit2) && !PZ_ABLATE_SKIP(128);
+        hit_processed = hit1 | hit2;
     }
     PZ_FRAME_STAMP(6);
     // :331-332 -- predicted again after a processed collision (one evaluation after both collisions leaves what
     // the second of two would).  Nothing in the frame reads it any more: the gather is issued here and taken
     // by the caller behind its other stores (`after_hit`).
-#ifdef PZ_CT_ABLATE
-    if (kKeepsEx && !(PZ_CT_ABLATE & 32)) after_hit = lut.landing_issue(hit_processed, g.b.x, g.b.y, g.b.xv, g.b.yv);
-#else
     if (kKeepsEx) after_hit = lut.landing_issue(hit_processed, g.b.x, g.b.y, g.b.xv, g.b.yv);
-#endif
     PZ_FRAME_STAMP(7);
     return reward;
 }
@@ -1648,15 +1608,9 @@ __device__ __forceinline__ PairHead pair_frame_head(Game& g, const pz_config& cf
     h.rng_base = g.e.rng;
     if (kOwnAI && active) {
         const bool scan = power_hit_scan_needed(own, g.b);
-#ifdef PZ_CT_ABLATE  // (timing only, see step_games_pair: 64 no landing look-up, 128 no candidate look-up in the k-frame pair kernel)
-        h.landing_word = (PZ_CT_ABLATE & 64) ? (uint32_t)g.b.x : lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv).value;
-        h.candidate_row = (PZ_CT_ABLATE & 128) ? lut_u32x4{(uint32_t)g.b.x, (uint32_t)g.b.y, 7u, 0u}
-                                               : lut.candidates_issue(scan, g.b.x, g.b.y, abs(g.b.yv)).value;
-#else
         // (a lane that knows its landing point reads entry 0 like a lane outside the domain: a line the whole wave shares)
         h.landing_word = lut.landing_issue(!h.known, g.b.x, g.b.y, g.b.xv, g.b.yv).value;
         h.candidate_row = lut.candidates_issue(scan, g.b.x, g.b.y, abs(g.b.yv)).value;
-#endif
         // (player 2 behind a computer player 1 learns the counter of its first draw from player 1's early post: tail)
         if (!(ROLE == 1 && AI1)) h.pre = predraw3(id, h.rng_base);
     }

@@ -11,7 +11,7 @@ from pathlib import Path
 PKG_ROOT = Path(__file__).resolve().parent.parent  # .../pika-zoo_amd
 LIB_PATH = PKG_ROOT / "lib" / "libpikazoo_hip.so"
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 PACKED_BYTES_PER_GAME = 36
 SCENERY_WORDS = 75
 STATE_WORDS = 44
@@ -80,7 +80,6 @@ _SIGNATURES = {
     "pz_count_packed_misfits": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
     "pz_probe_write": (C.c_int, [_P, _P, C.c_int64, _P]),
     "pz_probe_frame_bytes": (C.c_int64, []),
-    "pz_probe_launch": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     "pz_step_random": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), C.c_uint64, C.c_uint64,
                                  C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pz_rollout_random": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), C.c_uint64, C.c_uint64,
@@ -88,7 +87,6 @@ _SIGNATURES = {
     "pz_step_many": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P, C.c_int32, _P, _P, _P, _P, _P, _P,
                                _P, _P, _P]),
     "pz_random_actions": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _P]),
-    "pz_selftest_predictor": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     "pz_scenery_init": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.POINTER(PzConfig), _P]),
     "pz_scenery_track": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.POINTER(PzConfig), C.c_int32, _P]),
     # (cfg may be None when no scenery is passed: ctypes passes NULL for None)

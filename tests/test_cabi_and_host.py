@@ -22,10 +22,16 @@ def built_lib():
     return pz_build.build()
 
 
-def header_functions():
-    text = (REPO / "include" / "pikazoo_hip.h").read_text()
+def header_functions(header="pikazoo_hip.h"):
+    text = (REPO / "include" / header).read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(pz_[a-z_]+)\s*\(", text)))
+
+
+def dynamic_pz_symbols(lib_path):
+    """The pz_* functions a shared library really exports (`nm -D`), not what dlsym happens to find."""
+    out = subprocess.run(["nm", "-D", "--defined-only", str(lib_path)], check=True, capture_output=True, text=True).stdout
+    return sorted({ln.split()[-1] for ln in out.splitlines() if ln.split()[-2:-1] == ["T"] and ln.split()[-1].startswith("pz_")})
 
 
 def test_library_exports_every_declared_symbol(built_lib):
@@ -37,13 +43,41 @@ def test_library_exports_every_declared_symbol(built_lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/pikazoo_hip.h but not exported"
     assert sorted(_native.exported_names()) == names, "binding and header disagree"
+    # ... and nothing else: the product library exports exactly the entry points a maintainer of the reference would
+    # bind; diagnostics live in libpikazoo_diag.so behind include/pikazoo_diag.h
+    assert dynamic_pz_symbols(built_lib) == names
+    assert not {"pz_probe_launch", "pz_selftest_predictor"} & set(names)
+
+
+def test_diagnostics_library_is_separate_and_matches_its_header(built_lib):
+    import build as pz_build
+    import diag
+
+    names = header_functions("pikazoo_diag.h")
+    assert names == sorted(diag.SIGNATURES) == dynamic_pz_symbols(pz_build.DIAG_LIB)
+    assert pz_build.library_id(pz_build.DIAG_LIB) == pz_build.source_id()  # one build id for both libraries
+    # nothing in the package binds or loads it
+    for p in (REPO / "pika-zoo_amd" / "pikazoo_amd").rglob("*.py"):
+        assert "pikazoo_diag" not in p.read_text() and "import diag" not in p.read_text(), p
+    lib = diag.load()
+    fake = C.c_void_p(4096)
+    # the launch-floor probe: pz_step's seven buffers, `what` in 0..3, at least one game
+    probe = lib.pz_probe_launch
+    assert probe(None, 8, 8, fake, fake, fake, fake, fake, fake, 0, 0, None) == -1
+    assert probe(fake, 0, 0, fake, fake, fake, fake, fake, fake, 0, 0, None) == -2
+    assert probe(fake, 8, 4, fake, fake, fake, fake, fake, fake, 0, 0, None) == -2
+    assert probe(fake, 8, 8, fake, fake, fake, fake, fake, fake, 4, 0, None) == -3
+    assert probe(fake, 8, 8, fake, fake, fake, fake, fake, fake, 3, 5000, None) == -3
+    assert probe(fake, 8, 8, fake, fake, C.c_void_p(4100), fake, fake, fake, 2, 0, None) == -4
+    assert lib.pz_selftest_predictor(None, fake, fake, fake, 8, 1, fake, fake, None) == -1
+    assert lib.pz_selftest_predictor(fake, fake, fake, fake, 0, 1, fake, fake, None) == 0
 
 
 def test_binding_matches_library_layout(built_lib):
     from pikazoo_amd import _native
 
     lib = _native.load()
-    assert lib.pz_abi_version() == 8 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
+    assert lib.pz_abi_version() == 9 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
     assert lib.pz_config_bytes() == C.sizeof(_native.PzConfig) == 112
     assert lib.pz_error_string(0) == b"ok" and b"NULL" in lib.pz_error_string(-1)
     assert C.sizeof(_native.PzFlightTables) == 16
@@ -63,7 +97,7 @@ def test_library_carries_the_digest_of_the_sources_it_was_built_from(built_lib, 
                                                      b"pz_build_id:" + b"0" * 16))
     assert pz_build.library_id(stale) == "0" * 16 != pz_build.source_id()
     # extra compiler flags are part of the digest: a diagnostic variant written to the product path is not the product
-    assert pz_build.source_id(("-DPZ_ABLATE=1",)) != pz_build.source_id() == pz_build.source_id(())
+    assert pz_build.source_id(("-DPZ_STAMPS=1",)) != pz_build.source_id() == pz_build.source_id(())
     saved, _native._lib, _native.LIB_PATH = (_native._lib, _native.LIB_PATH), None, stale
     try:
         with pytest.raises(_native.PikazooNativeError, match="stale"):
@@ -307,14 +341,6 @@ def test_argument_validation_without_a_gpu(built_lib):
     assert lib.pz_probe_frame_bytes() == 1024 * 8960
     assert lib.pz_probe_write(None, None, 1 << 30, None) == -1 and lib.pz_probe_write(fake, None, 1024 * 8960 - 1, None) == -2
     assert lib.pz_probe_write(C.c_void_p(4100), fake, 1 << 30, None) == -4
-    # the launch-floor probe: pz_step's seven buffers, `what` in 0..3, at least one game
-    probe = lambda *a: lib.pz_probe_launch(*a)  # noqa: E731
-    assert probe(None, 8, 8, fake, fake, fake, fake, fake, fake, 0, 0, None) == -1
-    assert probe(fake, 0, 0, fake, fake, fake, fake, fake, fake, 0, 0, None) == -2
-    assert probe(fake, 8, 4, fake, fake, fake, fake, fake, fake, 0, 0, None) == -2
-    assert probe(fake, 8, 8, fake, fake, fake, fake, fake, fake, 4, 0, None) == -3
-    assert probe(fake, 8, 8, fake, fake, fake, fake, fake, fake, 3, 5000, None) == -3
-    assert probe(fake, 8, 8, fake, fake, C.c_void_p(4100), fake, fake, fake, 2, 0, None) == -4
     # the landing table: its 2-byte entries (an odd number) + 2 bytes of padding -- the look-up loads whole dwords
     assert lib.pz_flight_table_bytes(0) == 2 * 193 * 23 * 253 * 413 + 2 and lib.pz_flight_table_bytes(1) == 16 * 65 * 192 * 413
 
@@ -357,6 +383,70 @@ def test_no_vmem_store_data_hazard_in_device_code(built_lib, tmp_path):
                 hazards += not (b < lo or a > hi)
     assert stores > 100, "the scan did not see the observation stores"
     assert hazards == 0
+
+
+def _kernel_instructions(built_lib, tmp_path, needle):
+    """The instruction texts of the first gfx950 kernel whose demangled name contains `needle`."""
+    import shutil
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    lib = shutil.copy(built_lib, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, cwd=tmp_path, capture_output=True)
+    objs = [p for p in tmp_path.iterdir() if "gfx950" in p.name]
+    asm = subprocess.run([objdump, "-d", "--demangle", str(objs[0])], check=True, capture_output=True, text=True).stdout
+    body, inside = [], False
+    for line in asm.splitlines():
+        head = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+        if head:
+            if inside:
+                break
+            inside = needle in head.group(1)
+        elif inside:
+            m = re.match(r"^\s+([a-z_0-9]+(?: .*?)?)\s*//", line)
+            if m:
+                body.append(m.group(1))
+    assert body, f"no kernel named *{needle}* in the code object"
+    return body
+
+
+@pytest.mark.parametrize("kernel", ["step_pair_kernel<false, true, false, false>", "step_pair_kernel<true, false, false, false>",
+                                    "step_pair_kernel<false, true, false, true>"])
+def test_early_stores_of_the_one_computer_launch_are_ordered_behind_the_partners_loads(built_lib, tmp_path, kernel):
+    """pair_body, one computer player (config 3): the human player's wave stores columns IN FRONT of the exchange barrier
+    that the computer's wave loads at the top of the launch.  The only thing that orders those stores behind those loads
+    is an LDS hand-shake: the computer's wave sets a word after `s_waitcnt vmcnt(0)` on its loads, the human
+    player's wave clears it first thing and stores early only if it reads it set.  This scans the shipped code object for
+    exactly that shape, so that a later kernel change cannot quietly take the edge away:
+      * the word is set (the magic value) with an s_waitcnt vmcnt(0) and no vector-memory load between it and the ds_write;
+      * in the human player's wave every global store in front of the barrier comes after the ds_read of the word and the
+        scalar compare with the magic value."""
+    ins = _kernel_instructions(built_lib, tmp_path, kernel)
+    magic = "0x10add0e5"
+    flag = "offset:8192" if kernel.startswith("step_pair_kernel<false") else "offset:17152"  # word 2048 of the human wave's region
+    sets = [k for k, t in enumerate(ins) if t.startswith("v_mov_b32") and magic in t]
+    assert len(sets) == 1, sets
+    at = sets[0]
+    write = next(k for k in range(at, at + 6) if ins[k].startswith("ds_write_b32") and flag in ins[k])
+    waits = [k for k in range(max(0, at - 12), at) if ins[k].startswith("s_waitcnt vmcnt(0)")]
+    assert waits, "the flag is set without waiting for the wave's loads"
+    assert not any(t.startswith(("buffer_load", "global_load", "flat_load")) for t in ins[waits[-1]:write]), "a load behind the wait"
+    barriers = [k for k, t in enumerate(ins) if t.startswith("s_barrier")]
+    assert len(barriers) == 2  # one per wave: the role branches are laid out one after the other
+    clears = [k for k, t in enumerate(ins) if t.startswith("ds_write_b32") and flag in t and k != write]
+    assert len(clears) == 1, clears
+    clear = clears[0]
+    human_barrier = next(b for b in barriers if b > clear)
+    computer_barrier = next(b for b in barriers if b != human_barrier)
+    assert write < computer_barrier, "the word is set behind the computer's barrier"
+    stores = ("buffer_store", "global_store", "flat_store")
+    reads = [k for k in range(clear, human_barrier) if ins[k].startswith("ds_read_b32") and flag in ins[k]]
+    checks = [k for k in range(clear, human_barrier) if ins[k].startswith("s_cmp") and magic in ins[k]]
+    assert reads and checks and reads[0] < checks[0]
+    early = [k for k in range(clear, human_barrier) if ins[k].startswith(stores)]
+    assert early, "no early stores left: drop the hand-shake with them"
+    assert min(early) > checks[0], "a global store in front of the barrier is not behind the hand-shake"
 
 
 def test_no_scratch_and_bounded_scalar_spills_in_the_step_kernels(built_lib):

@@ -627,10 +627,10 @@ def test_placement_gives_up_promptly_and_leaves_the_process_memory_alone(monkeyp
 def test_launch_floor_probe_runs_on_scratch_buffers_and_touches_nothing_else():
     """pz_probe_launch (the headline launch's geometry without its game): every `what` launches for ragged and
     full batches, writes only inside the buffers it was handed (guard words behind each stay intact), and from `what` = 2 on
-    really stores (the scratch state changes)."""
-    from pikazoo_amd import _native
+    really stores (the scratch state changes).  Lives in libpikazoo_diag.so (include/pikazoo_diag.h), not in the product."""
+    import diag
 
-    lib = _native.load()
+    lib = diag.load()
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     guard = 0x5A5A5A5A

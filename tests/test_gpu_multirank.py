@@ -141,6 +141,16 @@ def test_bench_with_four_ranks_on_one_device_shards_like_config_4():
     assert out["per_rank"][0]["parity_bit_exact"] is True and out["per_rank"][-1]["parity_bit_exact"] is True
     assert all(p["parity_bit_exact"] is None for p in out["per_rank"][1:-1])
     assert np.isclose(out["value"], ranks * 65536 / (out["ms_per_step"] * 1e-3), rtol=1e-6)
+    # the N-rank story once more as FLAT scalars of `config` / `roofline`: a record that keeps scalar members only (the
+    # driver's) still says who ran, over what, how the slowest rank did and that both ends of the job were oracle-checked
+    cfg, roof = out["config"], out["roofline"]
+    assert cfg["ranks"] == ranks and cfg["rccl_ranks"] == 0 and cfg["dist_backend"] == "gloo" and isinstance(cfg["dist_note"], str)
+    assert cfg["env_id_base_last_rank"] == (ranks - 1) * 65536 and len(cfg["build_id"]) == 16
+    assert roof["per_rank_min_value"] == min(p["value"] for p in out["per_rank"]) > 0
+    assert roof["per_rank_max_launch_us"] == max(p["launch_us"] for p in out["per_rank"]) > 0
+    assert roof["parity_first_last_rank_bit_exact"] is True and roof["parity_ranks_checked"] == 2
+    assert all(not isinstance(v, (dict, list)) for v in list(cfg.values()) + list(roof.values()))
+    assert len(json.dumps(out)) < 8000
 
 
 def test_bench_under_the_drivers_launcher_and_rccl_request_on_one_gpu():
@@ -157,3 +167,5 @@ def test_bench_under_the_drivers_launcher_and_rccl_request_on_one_gpu():
     assert out["ranks"] == 2 and out["rccl_ranks"] == 0 and out["dist_backend"] == "gloo"
     assert "share one GPU" in out["dist_note"]
     assert all(p["parity_bit_exact"] is None for p in out["per_rank"])  # --no-cpu: nothing was replayed
+    assert out["roofline"]["parity_first_last_rank_bit_exact"] is None and out["roofline"]["parity_ranks_checked"] == 0
+    assert out["config"]["rccl_ranks"] == 0 and "share one GPU" in out["config"]["dist_note"]

@@ -469,9 +469,9 @@ def test_checkpoint_roundtrip():
 # 5. the closed-form fast-forward of the flight predictors == the reference's iteration
 # ------------------------------------------------------------------------------------------------
 def _selftest(x, y, xv, yv, full_net):
-    from pikazoo_amd import _native
+    import diag  # libpikazoo_diag.so (include/pikazoo_diag.h): the product's predictors, compiled from its own headers
 
-    lib = _native.load()
+    lib = diag.load()
     n = x.numel()
     fast, it = torch.empty_like(x), torch.empty_like(x)
     rc = lib.pz_selftest_predictor(x.data_ptr(), y.data_ptr(), xv.data_ptr(), yv.data_ptr(), n, int(full_net),

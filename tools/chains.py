@@ -3,7 +3,10 @@
 at the graph's ends), against the single chain.  Each step of sub-batch c is one pz_step launch on lane range
 [c*N/C, (c+1)*N/C) of the same state / observation / reward tensors (pointer offsets, full column pitch).
 
-    python tools/chains.py [--n 65536] [--steps 512] [--ai]
+    python tools/chains.py [--n 65536] [--steps 512] [--ai] [--random] [--separate]
+
+--random: every step is pz_step_random(k = 1) -- the uniform random policy drawn inside the step launch -- instead of
+pz_step on a pre-generated action tape.
 """
 import ctypes as C
 import statistics
@@ -22,6 +25,7 @@ def main():
     n = int(args[args.index("--n") + 1]) if "--n" in args else 65536
     K = int(args[args.index("--steps") + 1]) if "--steps" in args else 512
     ai = "--ai" in args
+    fused_policy = "--random" in args
     lib = _native.load()
     dev = torch.device("cuda:0")
     results = {}
@@ -45,11 +49,17 @@ def main():
             cfg = _native.PzConfig.from_buffer_copy(env._cfg)
             cfg.env_id_base = env.env_id_base + lo
             cfgs.append(cfg)
-            rc = lib.pz_step(env.state.data_ptr() + 4 * lo, sub, env._stride, C.byref(cfg),
-                             acts[t, 0].data_ptr() + 4 * lo, acts[t, 1].data_ptr() + 4 * lo,
-                             env._obs[0].data_ptr() + 140 * lo, env._obs[1].data_ptr() + 140 * lo,
-                             env._rew_raw[0].data_ptr() + 4 * lo, env._rew_raw[1].data_ptr() + 4 * lo,
-                             env._term_u8.data_ptr() + lo, None, env._tables_ref, stream.cuda_stream)
+            if fused_policy:
+                rc = lib.pz_step_random(env.state.data_ptr() + 4 * lo, sub, env._stride, C.byref(cfg), 1, t, 1,
+                                        env._obs[0].data_ptr() + 140 * lo, env._obs[1].data_ptr() + 140 * lo,
+                                        env._rew_raw[0].data_ptr() + 4 * lo, env._rew_raw[1].data_ptr() + 4 * lo,
+                                        env._term_u8.data_ptr() + lo, None, None, env._tables_ref, stream.cuda_stream)
+            else:
+                rc = lib.pz_step(env.state.data_ptr() + 4 * lo, sub, env._stride, C.byref(cfg),
+                                 acts[t, 0].data_ptr() + 4 * lo, acts[t, 1].data_ptr() + 4 * lo,
+                                 env._obs[0].data_ptr() + 140 * lo, env._obs[1].data_ptr() + 140 * lo,
+                                 env._rew_raw[0].data_ptr() + 4 * lo, env._rew_raw[1].data_ptr() + 4 * lo,
+                                 env._term_u8.data_ptr() + lo, None, env._tables_ref, stream.cuda_stream)
             assert rc == 0, rc
 
         cfgs = []
@@ -106,11 +116,18 @@ def main():
                     with torch.cuda.graph(g, stream=streams[c], capture_error_mode="thread_local"):
                         cur = torch.cuda.current_stream(dev)
                         for t in range(K):
-                            rc = lib.pz_step(env.state.data_ptr() + 4 * lo, sub, env._stride, C.byref(cfg),
-                                             acts[t, 0].data_ptr() + 4 * lo, acts[t, 1].data_ptr() + 4 * lo,
-                                             env._obs[0].data_ptr() + 140 * lo, env._obs[1].data_ptr() + 140 * lo,
-                                             env._rew_raw[0].data_ptr() + 4 * lo, env._rew_raw[1].data_ptr() + 4 * lo,
-                                             env._term_u8.data_ptr() + lo, None, env._tables_ref, cur.cuda_stream)
+                            if fused_policy:
+                                rc = lib.pz_step_random(env.state.data_ptr() + 4 * lo, sub, env._stride, C.byref(cfg), 1, t, 1,
+                                                        env._obs[0].data_ptr() + 140 * lo, env._obs[1].data_ptr() + 140 * lo,
+                                                        env._rew_raw[0].data_ptr() + 4 * lo, env._rew_raw[1].data_ptr() + 4 * lo,
+                                                        env._term_u8.data_ptr() + lo, None, None, env._tables_ref,
+                                                        cur.cuda_stream)
+                            else:
+                                rc = lib.pz_step(env.state.data_ptr() + 4 * lo, sub, env._stride, C.byref(cfg),
+                                                 acts[t, 0].data_ptr() + 4 * lo, acts[t, 1].data_ptr() + 4 * lo,
+                                                 env._obs[0].data_ptr() + 140 * lo, env._obs[1].data_ptr() + 140 * lo,
+                                                 env._rew_raw[0].data_ptr() + 4 * lo, env._rew_raw[1].data_ptr() + 4 * lo,
+                                                 env._term_u8.data_ptr() + lo, None, env._tables_ref, cur.cuda_stream)
                             assert rc == 0, rc
                 graphs.append(g)
             for c in range(chains):
@@ -135,10 +152,10 @@ def main():
                 torch.cuda.synchronize()
                 times.append(max(e0.elapsed_time(e) for e in ends) * 1e3 / (4 * K))
             med = statistics.median(times)
-            print(f"n={n} ai={ai} {chains} separate graphs on {chains} streams: {med:.3f} us per step (min {min(times):.3f}) -> "
+            print(f"n={n} ai={ai} policy_in_step={fused_policy} {chains} separate graphs on {chains} streams: {med:.3f} us per step (min {min(times):.3f}) -> "
                   f"{n / med / 1e3:.2f} G env-steps/s; same trajectory as one chain: {same}")
     for c, (med, mn) in results.items():
-        print(f"n={n} ai={ai} chains={c}: {med:.3f} us per step (min {mn:.3f})  -> {n / med / 1e3:.2f} G env-steps/s; "
+        print(f"n={n} ai={ai} policy_in_step={fused_policy} chains={c}: {med:.3f} us per step (min {mn:.3f})  -> {n / med / 1e3:.2f} G env-steps/s; "
               f"same trajectory as one chain: {torch.equal(final[c], final[1])}")
 
 

@@ -1,0 +1,95 @@
+#!/bin/bash
+# tools/gpu_suite.sh CASE [TAG] -- the GPU-box runs of a round, one parametrised script (run through gpurun; output under
+# gpurun_out/TAG/, copy what is to be judged into profiles/).  Every step runs under its own `timeout -k 10`, and a step
+# that fails ends the script: no GPU step is started behind a failed one.
+#
+#   check   GPU test suite, __graft_entry__.smoke(), the default bench line (+ its --configs-out file)
+#   bench   the default bench line and the --extra line only
+#   driver  the bench line exactly as the driver runs it (--steps 20 --warmup 5)
+#   edge    config 3's early stores: A/B of the LDS hand-shake against round 4's unordered form and against no
+#           early stores, then the deterministic proof of the edge: the computer's wave held back ~16 000 cycles in front of
+#           its first load must stay bit-exact with the hand-shake and breaks without it.  Variants (build here first):
+#             python tools/ab.py --build --common "-DPZ_DEV_SUBSET=705" unordered=-DPZ_DEV_UNORDERED_EARLY_STORES \
+#                 early0=-DPZ_EARLY_OWN_STORES=0 delayedge=-DPZ_DEV_DELAY_PARTNER_LOADS=2 \
+#                 delayunordered="-DPZ_DEV_DELAY_PARTNER_LOADS=2 -DPZ_DEV_UNORDERED_EARLY_STORES"
+#   chains  one batch as two / four sub-batch chains in ONE hipGraph (fork / join at its ends) and as separate graphs on
+#           separate streams, human vs human and config 3, 65 536 and 131 072 games (tools/chains.py)
+#   soak    long parity runs against the CPU oracle on every lane (tests/soak.py), single-frame and k-frame, both formats
+#   sweep   the randomized C-ABI configuration sweep, PZ_SWEEP_TRIALS (default 40 000) configurations
+#   profile tools/profile.sh TAG (all sections): the rocprofv3 evidence of the round
+set -u
+CASE=${1:?case}
+TAG=${2:-r05_$CASE}
+O=gpurun_out/$TAG
+mkdir -p "$O"
+step() {  # seconds, log, command...: run one step, stop the script when it fails
+    local secs=$1 log=$2
+    shift 2
+    echo "== $*" | tee -a "$O/steps.log"
+    timeout -k 10 "$secs" "$@" > "$O/$log" 2>&1
+    local rc=$?
+    echo "rc=$rc ($log)" | tee -a "$O/steps.log"
+    [ $rc -eq 0 ] || { tail -n 25 "$O/$log"; exit $rc; }
+}
+bench_summary() {
+    python3 - "$@" <<'PY'
+import json, sys
+for path in sys.argv[1:]:
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    r = d["roofline"]
+    print(path, len(json.dumps(d)), "bytes;", json.dumps({k: d[k] for k in ("value", "ms_per_step")}), d["config"].get("build_id"))
+    print("  ", {k: v for k, v in r.items() if isinstance(v, (int, float, bool)) or v is None})
+PY
+}
+case $CASE in
+check)
+    step 1000 gputest.log python3 -m pytest tests -m gpu -x -q
+    tail -n 4 "$O/gputest.log"
+    step 300 smoke.log python3 -c "import __graft_entry__ as g; g.smoke()"
+    tail -n 1 "$O/smoke.log"
+    timeout -k 10 600 python3 bench.py --configs-out "$O/bench_configs.json" > "$O/bench_default.json" 2> "$O/bench_default.err" || { echo "bench failed"; tail "$O/bench_default.err"; exit 1; }
+    bench_summary "$O/bench_default.json"
+    ;;
+bench)
+    timeout -k 10 600 python3 bench.py --configs-out "$O/bench_configs.json" > "$O/bench_default.json" 2> "$O/bench_default.err" || { echo "bench failed"; tail "$O/bench_default.err"; exit 1; }
+    timeout -k 10 900 python3 bench.py --extra --configs-out "$O/bench_extra_configs.json" > "$O/bench_default_extra.json" 2> "$O/bench_extra.err" || { echo "bench --extra failed"; tail "$O/bench_extra.err"; exit 1; }
+    bench_summary "$O/bench_default.json" "$O/bench_default_extra.json"
+    ;;
+driver)
+    timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_driver.json" 2> "$O/bench_driver.err" || { echo "bench failed"; tail "$O/bench_driver.err"; exit 1; }
+    bench_summary "$O/bench_driver.json"
+    ;;
+edge)
+    step 300 ab_early_store_edge_cold_tape.log python3 tools/ab.py --ai --slices 2048 base+t unordered+t early0+t
+    step 300 ab_early_store_edge_hot_tape.log python3 tools/ab.py --ai base+t unordered+t early0+t
+    step 300 early_store_edge_partner_held_back.log python3 tools/ab.py --ai --slices 2048 base+t delayedge+t delayunordered+t
+    tail -n 8 "$O"/*.log
+    ;;
+chains)
+    step 300 chains_65536.log python3 tools/chains.py --separate
+    step 300 chains_65536_cfg3.log python3 tools/chains.py --ai --separate
+    step 300 chains_131072.log python3 tools/chains.py --n 131072 --separate
+    step 300 chains_65536_policy_fused.log python3 tools/chains.py --random --separate
+    tail -n 6 "$O"/chains*.log
+    ;;
+soak)
+    step 500 soak_65536x60000.log python3 tests/soak.py --frames 60000 --every 10000
+    step 200 soak_packed_65536x20000.log python3 tests/soak.py --frames 20000 --every 5000 --packed
+    step 200 soak_kframe_rollout32_65536x19200.log python3 tests/soak.py --frames 19200 --every 4800 --rollout 32
+    step 200 soak_kframe_tape160_65536x19200.log python3 tests/soak.py --frames 19200 --every 4800 --rollout 160 --tape
+    step 200 soak_kframe_tape64_packed_65536x19200.log python3 tests/soak.py --frames 19200 --every 4800 --rollout 64 --tape --packed
+    tail -n 3 "$O"/soak*.log
+    ;;
+sweep)
+    export PZ_SWEEP_TRIALS=${PZ_SWEEP_TRIALS:-40000}
+    step 1100 "config_sweep_${PZ_SWEEP_TRIALS}.log" python3 -m pytest tests/test_gpu_parity.py -x -q -k randomized_config_sweep -s
+    tail -n 4 "$O"/config_sweep*.log
+    ;;
+profile)
+    bash tools/profile.sh "$TAG"
+    ;;
+*)
+    echo "unknown case $CASE"
+    exit 2
+    ;;
+esac

@@ -52,8 +52,14 @@ def main():
         shutil.copy(p, PROFILES / p.name)
     for flag, name in (("--bench", "bench_default"), ("--extra", "bench_default_extra")):
         if flag in args:
-            shutil.copy(args[args.index(flag) + 1], PROFILES / f"{tag}_{name}.json")
-    derived = json.loads((src / f"{tag}_pmc_summary.json").read_text())["derived"]
+            line = Path(args[args.index(flag) + 1])
+            shutil.copy(line, PROFILES / f"{tag}_{name}.json")
+            # the line's verbose blocks (bench.py --configs-out; gpurun_out/... relative to the repo root)
+            side = REPO / json.loads(line.read_text().strip().splitlines()[-1]).get("configs_file", "-")
+            if side.is_file():
+                shutil.copy(side, PROFILES / f"{tag}_{name}_configs.json")
+    summary = json.loads((src / f"{tag}_pmc_summary.json").read_text())
+    derived, build_id, digests = summary["derived"], summary.get("build_id"), summary.get("kernel_digests", {})
     tpath = PROFILES / "traffic.json"
     traffic = json.loads(tpath.read_text())
     for key, (prefix, kernel, games) in TRAFFIC.items():
@@ -63,7 +69,8 @@ def main():
             continue
         traffic.setdefault(key, {}).update(hbm_bytes_per_launch=e["hbm_bytes_per_launch"],
                                            fetch_size_kb_raw=e["fetch_size_kb_raw"], write_size_kb=e["write_size_kb"],
-                                           kernel=kernel, round=tag, num_envs=games)
+                                           kernel=kernel, round=tag, num_envs=games, build_id=build_id,
+                                           kernel_digest=digests.get(kernel))
         print(f"  traffic {key}: {e['hbm_bytes_per_launch'] / 1e6:.2f} MB = 2 x {e['fetch_size_kb_raw']:.0f} KB read + "
               f"{e['write_size_kb']:.0f} KB written")
     tpath.write_text(json.dumps(traffic, indent=1))
@@ -83,17 +90,21 @@ def main():
                           f"({row['Calls']} calls)")
     for flag in ("--bench", "--extra"):
         if flag in args:
-            d = json.loads(Path(args[args.index(flag) + 1]).read_text())
+            d = json.loads(Path(args[args.index(flag) + 1]).read_text().strip().splitlines()[-1])
             if flag == "--bench":
                 r = d["roofline"]
                 print(f"  bench: build {d['build_id']}: {d['value'] / 1e9:.2f} G, {r['launch_us']:.2f} us, frac {r['frac']:.3f}, "
-                      f"frac_wall {r['frac_wall']:.3f}, frac_traffic {r['frac_traffic']}, cpu {d['cpu_baseline']['value'] / 1e6:.0f} M")
-                for k, v in d.get("configs", {}).items():
-                    us = v.get("launch_us", v.get("us_per_frame"))
-                    print(f"    {k}: {v['value'] / 1e9:.2f} G, {us:.2f} us, frac {v['frac']:.3f}, "
-                          f"frac_traffic {v.get('frac_traffic')}, {v.get('regime')}, parity {v.get('parity_bit_exact')}")
+                      f"frac_wall {r['frac_wall']:.3f}, frac_traffic {r['frac_traffic']} (counters of {r.get('traffic_build_id')}, "
+                      f"stale {r.get('traffic_stale')}), cpu {d['cpu_baseline']['value'] / 1e6:.0f} M")
+                for k, v in r.items():  # the flat per-config scalars of the line
+                    if k.endswith(("_launch_us", "_us_per_frame", "_us")) and k != "launch_us":
+                        stem = k.rsplit("_launch_us", 1)[0].rsplit("_us_per_frame", 1)[0]
+                        print(f"    {k}: {v}  frac {r.get(stem + '_frac')}  frac_traffic {r.get(stem + '_frac_traffic')}")
+                print(f"    configs parity: {r.get('configs_parity_all_bit_exact')} ({r.get('configs_parity_checked')} checked)")
             else:
-                for k, v in d.get("extra", {}).items():
+                side = REPO / d.get("configs_file", "-")  # the verbose blocks of the line (bench.py --configs-out)
+                verbose = json.loads(side.read_text()) if side.is_file() else {}
+                for k, v in verbose.get("extra", {}).items():
                     if isinstance(v, dict) and "us_per_frame" in v:
                         print(f"    {k}: {v['us_per_frame']:.2f} us/frame, {v['value'] / 1e9:.2f} G")
                     elif isinstance(v, dict) and "us_per_step" in v:

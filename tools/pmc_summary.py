@@ -204,6 +204,18 @@ def main():
                     v[name.lower() + "_per_launch"] = c[name]
         derived[prefix] = d
     out = {"tag": tag, "derived": derived, "raw_means": summary}
+    # which build the counters were taken on, and the instruction-stream digest of every step kernel of that build:
+    # bench.py accepts these figures on another build only for a kernel whose digest is unchanged (tools/kernel_digest.py)
+    try:
+        sys.path.insert(0, str(REPO / "pika-zoo_amd"))
+        sys.path.insert(0, str(REPO / "tools"))
+        import kernel_digest
+        from pikazoo_amd import _native
+
+        out["build_id"] = _native.build_id()
+        out["kernel_digests"] = {k: d for k, (d, _) in kernel_digest.kernels(_native.LIB_PATH).items() if k.startswith(STEP_KERNELS)}
+    except Exception as exc:  # noqa: BLE001
+        print(f"(no build id / kernel digests: {type(exc).__name__}: {exc})")
     (dst / f"{tag}_pmc_summary.json").write_text(json.dumps(out, indent=1))
     print(json.dumps(derived, indent=1))
 
