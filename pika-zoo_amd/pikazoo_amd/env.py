@@ -114,9 +114,11 @@ class raw_env:
     host before the launch, like the reference checks them before it steps.  For device tensors the range check runs
     INSIDE the step kernel -- a launch cannot raise, so it counts into a device counter the env polls every
     ``validate_every`` steps through an asynchronous copy it only reads one poll later (no device synchronisation on the
-    step path), and the ``IndexError`` then comes up to ``2 * validate_every`` steps late; :meth:`check_actions` asks
-    now (one sync).  The offending game's input for that frame is undefined; no other
-    game and no memory is affected); ``scalar_api`` (``num_envs == 1`` only: return numpy rows / Python
+    step path), and the ``IndexError`` then comes up to ``2 * validate_every`` steps late (:meth:`step_many`: one call
+    late); :meth:`check_actions` asks now (one sync), and ``validate_every=1`` is the STRICT mode: every :meth:`step` /
+    :meth:`step_many` call reads the counter before it returns (one device synchronisation per call), so the error comes
+    from the call that was handed the action, as in the reference -- the frame has run by then, which the reference's
+    has not.  The offending game's input for that frame is undefined; no other game and no memory is affected); ``scalar_api`` (``num_envs == 1`` only: return numpy rows / Python
     scalars and empty ``agents`` on termination, i.e. the reference's exact return types;
     ``auto_reset`` then defaults to False, so that ``while env.agents:`` loops end like they do around
     the reference); ``flight_tables`` (computer players only: look the flight predictions up in the
@@ -698,7 +700,9 @@ class raw_env:
         self.steps_done += 1
         if self._faults is not None:  # validate_actions: the launch counted out-of-range actions (pikazoo_env.py:182)
             self._since_poll += 1
-            if self._since_poll >= self.validate_every:
+            if self.validate_every == 1 and not torch.cuda.is_current_stream_capturing():
+                self.check_actions()  # strict mode: the error comes from the call that was handed the action
+            elif self._since_poll >= self.validate_every:
                 self._poll_action_faults()
         if self.scalar_api:
             self.check_actions()  # (this API synchronises on every step anyway: the reference's error on the step itself)
@@ -793,7 +797,13 @@ class raw_env:
     def step_many(self, actions: torch.Tensor, out: Optional[dict] = None):
         """``k`` frames of GIVEN actions (``int32[k, 2, N]``: frame, agent, game) in ONE launch, keeping
         every frame's outputs; same result dict as :meth:`rollout_random`.  Bit-identical to ``k`` calls
-        of :meth:`step` on the ``k`` slices (a recorded action tape, an open-loop plan ...)."""
+        of :meth:`step` on the ``k`` slices (a recorded action tape, an open-loop plan ...).
+
+        ``validate_actions``: the launch range-checks the tape while it parks it and counts into the env's device
+        counter.  By default that counter is read asynchronously, so an out-of-range action on the tape raises
+        ``IndexError`` from the NEXT call that polls (the next ``step_many`` / a later ``step``) -- a caller whose last
+        call this is asks with :meth:`check_actions` before it trusts the trajectory; with ``validate_every=1`` (strict)
+        this call synchronises and raises itself."""
         self._no_unfused_wrappers("step_many")
         n, dev = self.num_envs, self.device
         if actions.dim() != 3 or actions.shape[1] != 2 or actions.shape[2] != n:
@@ -815,8 +825,11 @@ class raw_env:
         if self._scenery is not None:
             self._track_scenery(resync=True)
         self.steps_done += k
-        if self._faults is not None:  # (the launch range-checked the tape as it parked it; read one call later)
-            self._poll_action_faults()
+        if self._faults is not None:  # (the launch range-checked the tape as it parked it)
+            if self.validate_every == 1 and not torch.cuda.is_current_stream_capturing():
+                self.check_actions()  # strict: this call raises
+            else:
+                self._poll_action_faults()  # read one call later (no synchronisation here)
         return self._finish_trajectory(out)
 
     def _alloc_trajectory(self, k):

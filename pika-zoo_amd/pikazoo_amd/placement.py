@@ -36,6 +36,10 @@ DEFAULT_SPACER_BUDGET = 32 << 30   # what alloc_pair walks by itself (the driver
 OTHER_TENANT_BYTES = 4 << 30   # device memory held by somebody else (another process / rank): above this, no walk
 DISTINCT_BELOW = 0.86          # t(a, b) / (t(a) + t(b)): ~1.0 in one rank, 0.77-0.83 in two (in between: a tensor that
                                # straddles two ranks)
+KEEP_FAR_BYTES = 8 << 30       # blocks a walk found in another rank are kept (reserved, invisible to
+                               # torch.cuda.empty_cache()) for the next pair of their size -- up to this much in all
+                               # (``PIKAZOO_PLACE_KEEP_GIB``); beyond it the oldest kept block that is not in use goes
+                               # back to the driver first
 
 _verdicts: dict = {}           # (device index, low ptr, high ptr, bytes) -> ratio measured for that pair
 _far_pools: dict = {}          # (device index, bytes) -> private pools holding one block each that a walk found in another rank
@@ -127,10 +131,42 @@ def enabled() -> bool:
 
 
 def reset():
-    """Forget every cached verdict (e.g. after the process has returned memory to the driver)."""
+    """Forget every cached verdict and give the kept blocks back to the driver (those no tensor uses any more: a pool
+    dies with its last block)."""
     _verdicts.clear()
     _gave_up.clear()
     _far_pools.clear()
+
+
+def _keep_limit() -> int:
+    try:
+        return int(max(0.0, float(os.environ["PIKAZOO_PLACE_KEEP_GIB"])) * (1 << 30))
+    except (KeyError, ValueError):
+        return KEEP_FAR_BYTES
+
+
+def retained_bytes() -> int:
+    """Device memory the kept far blocks reserve (in use by a live tensor or waiting for the next pair of their size)."""
+    return sum(size for pools in _far_pools.values() for _pool, size in pools)
+
+
+def _keep_far_pool(key, pool, block_bytes: int):
+    """Remember the pool of a block a walk found in another rank -- within ``KEEP_FAR_BYTES`` in all: the oldest kept
+    blocks that no tensor uses are dropped first (their pools die, the memory goes back to the driver); a block that is
+    in use cannot be dropped, so the total may stay above the limit until its tensor has died."""
+    limit = _keep_limit()
+    if block_bytes > limit:
+        return  # (never kept: the pool dies with the tensor that uses its block)
+    entries = [(k, p, size) for k, pools in _far_pools.items() for p, size in pools]  # oldest first
+    total = sum(size for _k, _p, size in entries)
+    _far_pools.clear()
+    for k, p, size in entries:
+        if total + block_bytes > limit and _has_free_block(p, size):
+            total -= size  # dropped: the last reference to its pool goes with `entries`
+        else:
+            _far_pools.setdefault(k, []).append((p, size))
+    del entries
+    _far_pools.setdefault(key, []).append((pool, block_bytes))
 
 
 def _has_free_block(pool, nbytes: int) -> bool:
@@ -200,7 +236,7 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = None):
     # a block an earlier walk found for this size lives in a private pool of its own (`_far_pools`): when the tensor that
     # used it has died, the block is free in that pool and is handed out again here -- no second walk
     b = None
-    for pool in _far_pools.get((device.index, nbytes), ()):
+    for pool, _size in _far_pools.get((device.index, nbytes), ()):
         if not _has_free_block(pool, max(numel, CANDIDATE_BLOCK // probe) * probe):
             continue  # (its block is in use: allocating in this pool now would only grow it)
         with torch.cuda.use_mem_pool(pool, device=device):
@@ -251,7 +287,7 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = None):
             r = pair_ratio(a, cand)
             if r < DISTINCT_BELOW:
                 found, ratio = cand, r
-                _far_pools.setdefault((device.index, nbytes), []).append(cand_pool)
+                _keep_far_pool((device.index, nbytes), cand_pool, block_elems * probe)
                 break
             held.append(cand)
             held_pools.append(cand_pool)
@@ -269,5 +305,6 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = None):
     held.clear()
     held_pools.clear()
     del held, held_pools, pool
-    info.update(ratio=ratio, distinct=ratio < DISTINCT_BELOW, candidates=tried, spacer_gib=walked / (1 << 30))
+    info.update(ratio=ratio, distinct=ratio < DISTINCT_BELOW, candidates=tried, spacer_gib=walked / (1 << 30),
+                retained_gib=retained_bytes() / (1 << 30))
     return a, b

@@ -127,6 +127,38 @@ def test_step_error_behaviour():
         pikazoo_v0.env(device="cpu")
 
 
+def test_strict_action_validation_raises_from_the_call_that_was_handed_the_action():
+    """validate_every=1 is the strict mode: step() and step_many() read the device counter before they return (one
+    synchronisation per call), so the reference's IndexError (pikazoo_env.py:182) comes from the very call that was handed
+    the out-of-range device action -- also from a caller's LAST step_many, which the asynchronous default would never
+    report without a check_actions()."""
+    from pikazoo_amd import pikazoo_v0
+
+    n = 256
+    env = pikazoo_v0.env(num_envs=n, seed=5, validate_every=1)
+    raw = env.unwrapped
+    env.reset()
+    ok = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    bad = ok.clone()
+    bad[77] = 18
+    env.step({"player_1": ok + 17, "player_2": ok})
+    with pytest.raises(IndexError):
+        env.step({"player_1": ok, "player_2": bad})
+    env.step({"player_1": ok, "player_2": ok})  # raised once: the counter was cleared
+    tape = torch.zeros((40, 2, n), dtype=torch.int32, device="cuda:0")
+    raw.step_many(tape)
+    tape[39, 1, 200] = -3
+    with pytest.raises(IndexError):
+        raw.step_many(tape)  # the one and only call with the bad tape
+    raw.check_actions()
+    # the default stays asynchronous: the same last call returns, and check_actions() is how its caller asks
+    lazy = pikazoo_v0.env(num_envs=n, seed=5).unwrapped
+    lazy.reset()
+    lazy.step_many(tape)
+    with pytest.raises(IndexError):
+        lazy.check_actions()
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(state_format="packed"), dict(is_player2_computer=True),
                                 dict(is_player2_computer=True, flight_tables=False), dict(num_envs=393216 + 64)])
 def test_out_of_range_actions_are_counted_in_the_launch_and_raised_without_a_sync(kw):
@@ -240,6 +272,24 @@ def test_wrappers_outside_the_kernel_second_instances_and_the_scalar_api():
         env.unwrapped.check_actions()
     with pytest.raises(IndexError):  # host values: on the step itself
         env.step({"player_1": [12] * 8, "player_2": [0] * 8})
+    with pytest.raises(IndexError):  # ... and a host index past the tuple raises like the reference's `action_map[agent][13]`
+        env.step({"player_1": [13] * 8, "player_2": [0] * 8})
+    # the reference indexes its 13-tuple the Python way (simplify_action.py:23): -13 .. -1 count from the end.  Host and
+    # device values take the same wrap-around through the un-fused wrapper: -9 is index 4 (action 4 for player 1)
+    wrapped, direct = (W.SimplifyAction(W.SimplifyAction(pikazoo_v0.env(num_envs=8, seed=3))) for _ in range(2))
+    viadev = W.SimplifyAction(W.SimplifyAction(pikazoo_v0.env(num_envs=8, seed=3)))
+    for e in (wrapped, direct, viadev):
+        e.reset()
+    wrapped.step({"player_1": [-9] * 8, "player_2": [-13] * 8})
+    direct.step({"player_1": [4] * 8, "player_2": [0] * 8})
+    viadev.step({"player_1": torch.full((8,), -9, dtype=torch.int32, device="cuda:0"),
+                 "player_2": torch.full((8,), -13, dtype=torch.int32, device="cuda:0")})
+    assert torch.equal(wrapped.unwrapped.state, direct.unwrapped.state) and torch.equal(viadev.unwrapped.state, direct.unwrapped.state)
+    viadev.unwrapped.check_actions()
+    viadev.step({"player_1": torch.full((8,), -14, dtype=torch.int32, device="cuda:0"),
+                 "player_2": torch.zeros(8, dtype=torch.int32, device="cuda:0")})
+    with pytest.raises(IndexError):
+        viadev.unwrapped.check_actions()
 
     # frozen games and the scalar API: one env, Python numbers, the reference's own loop shape
     stack = [("RewardByBallPosition", dict(additional_reward=table, x_line=216, y_line=176)), ("RecordEpisodeStatistics", {}),
@@ -622,6 +672,43 @@ def test_placement_gives_up_promptly_and_leaves_the_process_memory_alone(monkeyp
         a, b = placement.alloc_pair(shape, dt, dev)
         again = dict(placement.last_info)
         assert again["distinct"] and again["spacer_gib"] == 0.0, (info, again)
+
+
+def test_placement_keeps_a_bounded_amount_and_reset_returns_it_to_the_driver(monkeypatch):
+    """What placement keeps for the next pair (the block a walk found in another rank, in a private pool that
+    torch.cuda.empty_cache() cannot empty) is bounded -- KEEP_FAR_BYTES / PIKAZOO_PLACE_KEEP_GIB in all, oldest unused
+    block dropped first -- is reported (`retained_gib`, retained_bytes()), and goes back to the driver with reset():
+    the device's free memory returns to where it was."""
+    from pikazoo_amd import placement
+
+    dev = torch.device("cuda:0")
+    placement.reset()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    walked = 0
+    for k in (32, 36, 40):  # three sizes: three kept blocks if every walk finds one
+        a, b = placement.alloc_pair((k, 65536, 35), torch.int32, dev)
+        info = dict(placement.last_info)
+        walked += info.get("spacer_gib", 0) > 0 and info["distinct"]
+        assert placement.retained_bytes() <= placement.KEEP_FAR_BYTES
+        if "retained_gib" in info:
+            assert abs(info["retained_gib"] * (1 << 30) - placement.retained_bytes()) < 1
+        del a, b
+    assert placement.retained_bytes() >= (walked > 0) * (1 << 30)
+    # a limit of 1.5 GiB: a second kept block pushes the first (unused) one out
+    monkeypatch.setenv("PIKAZOO_PLACE_KEEP_GIB", "1.5")
+    for k in (44, 48):
+        a, b = placement.alloc_pair((k, 65536, 35), torch.int32, dev)
+        del a, b
+        assert placement.retained_bytes() <= int(1.5 * (1 << 30)) + 48 * 65536 * 35 * 4
+    monkeypatch.delenv("PIKAZOO_PLACE_KEEP_GIB")
+    placement.reset()
+    assert placement.retained_bytes() == 0
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info(dev)[0]
+    assert free1 >= free0 - (64 << 20), (free0, free1)  # everything the walks and the kept blocks held is back
 
 
 def test_launch_floor_probe_runs_on_scratch_buffers_and_touches_nothing_else():
