@@ -35,12 +35,6 @@ namespace pz {
 #ifndef PZ_HH_ROLLOUT_GENERIC
 #define PZ_HH_ROLLOUT_GENERIC 1  // launch_step_players: the human-vs-human rollout keeps its generic kernel (measured)
 #endif
-#ifndef PZ_TRAJ_STORE_ORDER
-#define PZ_TRAJ_STORE_ORDER 0
-#endif
-#ifndef PZ_DEV_FORCE_PLAIN
-#define PZ_DEV_FORCE_PLAIN false  // (diagnostic: every k-frame kernel compiled as its PLAIN form)
-#endif
 #ifndef PZ_EARLY_OWN_STORES
 #define PZ_EARLY_OWN_STORES 2  // pair_body: what the human player's wave stores in front of the exchange barrier (0: nothing)
 #endif
@@ -841,29 +835,13 @@ struct TrajOut {
             for (int pass = 0; pass < 9; ++pass) p2[pass] = src2[min(pass * kLanes + lane, kWaveObsVecs - 1)];
             between();
             const Rsrc s1 = make_rsrc(obs1, obs_span_bytes), s2 = make_rsrc(obs2, obs_span_bytes);
-#if PZ_TRAJ_STORE_ORDER == 1  // (A/B: the two tensors' pieces alternate)
-#pragma unroll
-            for (int pass = 0; pass < 9; ++pass) {
-                __builtin_amdgcn_raw_buffer_store_b128(p1[pass], s1, piece_off[pass], 0, PZ_TRAJ_AUX);
-                __builtin_amdgcn_raw_buffer_store_b128(p2[pass], s2, piece_off[pass], 0, PZ_TRAJ_AUX);
-            }
-#elif PZ_TRAJ_STORE_ORDER == 2  // (A/B: every other workgroup writes player 2's tensor first)
-            const bool swap = (blockIdx.x & 1u) != 0;
-            const Rsrc sa = swap ? s2 : s1, sb = swap ? s1 : s2;
-#pragma unroll
-            for (int pass = 0; pass < 9; ++pass)
-                __builtin_amdgcn_raw_buffer_store_b128(swap ? p2[pass] : p1[pass], sa, piece_off[pass], 0, PZ_TRAJ_AUX);
-#pragma unroll
-            for (int pass = 0; pass < 9; ++pass)
-                __builtin_amdgcn_raw_buffer_store_b128(swap ? p1[pass] : p2[pass], sb, piece_off[pass], 0, PZ_TRAJ_AUX);
-#else
+            // (the two tensors' pieces alternating, or every other workgroup writing player 2's tensor first: the same)
 #pragma unroll
             for (int pass = 0; pass < 9; ++pass)
                 __builtin_amdgcn_raw_buffer_store_b128(p1[pass], s1, piece_off[pass], 0, PZ_TRAJ_AUX);
 #pragma unroll
             for (int pass = 0; pass < 9; ++pass)
                 __builtin_amdgcn_raw_buffer_store_b128(p2[pass], s2, piece_off[pass], 0, PZ_TRAJ_AUX);
-#endif
         }
     }
     // one tensor's pieces requested from LDS at once (36 VGPRs), `between()`, their stores back to back
@@ -998,7 +976,7 @@ __attribute__((amdgpu_waves_per_eu((MODE == kRollout || MODE == kTape) && SCOUT 
                                    MODE == kRollout ? (SCOUT != kNoScout ? 2 : PZ_TRAJ_WAVES) : (MODE == kTape && SCOUT != kNoScout ? 2 : (MODE == kTape ? PZ_TAPE_WAVES : 8)))))
 void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
 {
-    const StepArgs a = effective_args<PLAIN || PZ_DEV_FORCE_PLAIN, OBS16>(args);
+    const StepArgs a = effective_args<PLAIN, OBS16>(args);
     const HotArgs hot{state, n, stride, act_p1, act_p2};
     static_assert(!PACKED || (SCOUT == kNoScout && !SPARSE), "the packed format has no scout and no changed-only variant");
     static_assert(!OBS16 || MODE == kRollout || MODE == kTape, "the single-frame launches take the row format at run time");
@@ -1127,11 +1105,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
                 a1 = parked[(slot * 2 + 0) * kLanes + lane];
                 a2 = parked[(slot * 2 + 1) * kLanes + lane];
             }
-#ifdef PZ_PREDICT_EVERY_HIT
-            const bool last_frame = true;
-#else
             const bool last_frame = s == a.k - 1;
-#endif
             frozen = head.frozen;
             reward = frame_tail<AI1, AI2, SCOUT, false>(g, a.cfg, id, a1, a2, live, head, lds_obs[0], lane, lut, link,
                                                         nullptr, last_frame);
@@ -1257,9 +1231,12 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     // the word; the human player's wave reads it in front of the barrier and stores early only if it is set.  If it is
     // not (the partner was held back: preemption, a debugger, an instruction-cache miss) -- or the set was overtaken by
     // the clear -- the same stores are issued behind the barrier like every other store of the frame: slower by the
-    // ~2 % the early stores gain, never different.  (tests: -DPZ_DEV_DELAY_PARTNER_LOADS holds the computer's wave back
-    // for ~16 000 cycles in front of its first load; bit-exact with the hand-shake, wrong without it,
-    // profiles/r05_experiments/early_store_edge_*.log.)
+    // ~2 % the early stores gain, never different.  Interleaved A/B, config 3, us per launch (cold | hot tape): no early
+    // stores 8.62 | 8.32, round 4's unordered early stores 8.43 | 8.15, with the hand-shake 8.46 | 8.19
+    // (profiles/r05_experiments/ab_early_store_edge_*.log).  The edge itself, deterministically:
+    // -DPZ_DEV_DELAY_PARTNER_LOADS=2 holds the computer's wave back for ~16 000 cycles in front of its first load -- the
+    // trajectory stays bit-exact with the hand-shake and breaks without it (early_store_edge_partner_held_back.log);
+    // tests/test_cabi_and_host.py scans the shipped code object for the hand-shake's shape.
     constexpr bool kOneComputer = PZ_EARLY_OWN_STORES != 0 && !PACKED && (AI1 != AI2);
     constexpr int kHumanRole = AI1 ? 1 : 0;
     constexpr int kLoadsDoneAt = 2048;  // word of the human wave's exchange region (rows 0..1151 carry the exchange)
@@ -1753,7 +1730,7 @@ template <bool AI1, bool AI2, int MODE, bool PACKED = false, bool OBS16 = false,
 __global__ __launch_bounds__(2 * kLanes) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void rollout_pair_kernel(PZ_HOT_PARAMS, const StepArgs args)
 {
-    const StepArgs a = effective_args<PLAIN || PZ_DEV_FORCE_PLAIN, OBS16>(args);
+    const StepArgs a = effective_args<PLAIN, OBS16>(args);
     const HotArgs hot{state, n, stride, act_p1, act_p2};
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     __shared__ int32_t xchg[kLoopXchgWords];  // the players' exchange: LDS of its own, double-buffered by frame parity
@@ -2226,9 +2203,6 @@ static inline bool is_packed(const pz_config& cfg) { return (cfg.packed_state & 
 // no fused wrapper, no episode statistics, raw integer rows: what the PLAIN k-frame kernels are compiled for
 static inline bool is_plain(const StepArgs& a)
 {
-#ifdef PZ_DEV_NO_PLAIN  // (tools/ab.py: the generic k-frame kernels on a plain configuration)
-    return false;
-#endif
     return a.cfg.simplify_action == 0 && a.cfg.ballpos_reward == 0 && a.cfg.normal_state_mode == 0 &&
            a.cfg.normalize_obs != 1 && (a.cfg.episode_stats_mode == 0 || a.episode_stats == nullptr);
 }
