@@ -385,6 +385,55 @@ def test_no_vmem_store_data_hazard_in_device_code(built_lib, tmp_path):
     assert hazards == 0
 
 
+def test_counted_bytes_carry_their_build_and_go_stale_with_the_kernel(built_lib, monkeypatch):
+    """profiles/traffic.json (the PMC-counted bytes bench.py prints as `roofline.traffic`) names the build its counters
+    were taken on and the digest of each entry's kernel (tools/kernel_digest.py).  bench.load_traffic uses an entry on
+    that build, or on another build whose kernel is instruction-for-instruction the same; after a kernel change without
+    a new profile it returns nothing and the line says `traffic_stale` -- never a stale figure without a warning."""
+    import json
+
+    sys.path.insert(0, str(REPO))
+    sys.path.insert(0, str(REPO / "tools"))
+    import bench
+    import kernel_digest
+    from pikazoo_amd import _native
+
+    committed = json.loads((REPO / "profiles" / "traffic.json").read_text())
+    entries = {k: v for k, v in committed.items() if isinstance(v, dict)}
+    assert len(entries) >= 15
+    for key, e in entries.items():
+        assert re.fullmatch(r"[0-9a-f]{16}", e.get("build_id") or ""), key
+        assert re.fullmatch(r"[0-9a-f]{16}", e.get("kernel_digest") or ""), key
+    if not kernel_digest.available():
+        pytest.skip("llvm-objdump not available")
+    e = dict(entries["random_random"])
+    now = kernel_digest.digest(e["kernel"], built_lib)
+    assert now is not None and kernel_digest.digest("pz::no_such_kernel", built_lib) is None
+
+    def load(entry):
+        monkeypatch.setattr(bench, "_TRAFFIC", {"random_random": entry})
+        monkeypatch.setattr(bench, "_TRAFFIC_STATUS", {})
+        return bench.load_traffic("random_random", entry["num_envs"]), dict(bench._TRAFFIC_STATUS.get("random_random", {}))
+
+    # the same build: used as it is
+    value, st = load(dict(e, build_id=_native.build_id()))
+    assert value == e["hbm_bytes_per_launch"] and st["stale"] is False
+    # another build, the kernel's instruction stream unchanged: still valid, and the line names the counters' build
+    value, st = load(dict(e, build_id="0" * 16, kernel_digest=now))
+    assert value == e["hbm_bytes_per_launch"] and st == {"build_id": "0" * 16, "stale": False,
+                                                          "why": "another build, kernel instruction stream unchanged"}
+    # another build and another kernel: stale, no figure
+    value, st = load(dict(e, build_id="0" * 16, kernel_digest="f" * 16))
+    assert value is None and st["stale"] is True and "CHANGED" in st["why"]
+    # an entry without a digest (round 4's file) on another build: stale too
+    old = {k: v for k, v in e.items() if k != "kernel_digest"}
+    value, st = load(dict(old, build_id="0" * 16))
+    assert value is None and st["stale"] is True
+    # another batch size than the entry's: no figure, no verdict
+    monkeypatch.setattr(bench, "_TRAFFIC", {"random_random": e})
+    assert bench.load_traffic("random_random", 4096) is None
+
+
 def _kernel_instructions(built_lib, tmp_path, needle):
     """The instruction texts of the first gfx950 kernel whose demangled name contains `needle`."""
     import shutil
