@@ -43,6 +43,8 @@ def weak_shard(n_per_gpu: int, rank: int, world_size: int) -> Shard:
 
 _COUNTERS = None       # the RCCL group the counters travel over (None: the gloo control group / no group at all)
 _FALLBACK_NOTE = None
+_LEFT_BEHIND = False   # an RCCL start that did not return in time is still running in a daemon thread of this process
+RCCL_START_TIMEOUT_S = 90.0   # (PIKAZOO_RCCL_START_TIMEOUT_S) how long a rank waits for its communicator + probe all-reduce
 
 
 def _shares_a_gpu(rank: int, world: int, index: int):
@@ -77,11 +79,13 @@ def _device_ready(index: int):
 
 def _start_rccl(rank: int, world: int, index: int):
     """This rank's attempt at an RCCL group over all ranks: (group or None, why not).  `dist.new_group` is a collective:
-    every rank calls this or none does (init_from_env agrees on that over gloo first).  A probe all-reduce that HANGS
-    inside RCCL is not caught here: the watchdog of the process group aborts the job after its timeout."""
+    every rank calls this or none does (init_from_env agrees on that over gloo first).  A call that HANGS inside RCCL is
+    not caught here but by `_start_rccl_bounded`, which runs this in a thread it can give up on; the group's own
+    watchdog timeout is set far beyond that bound (ten minutes), so that it cannot abort a job that has moved on."""
     try:
         dev = torch.device("cuda", index)
-        group = dist.new_group(backend="nccl", timeout=timedelta(seconds=120))
+        torch.cuda.set_device(dev)  # (the current device is per thread)
+        group = dist.new_group(backend="nccl", timeout=timedelta(seconds=600))
         probe = torch.ones(1, dtype=torch.int64, device=dev)  # the communicator works before anything is timed
         dist.all_reduce(probe, group=group)
         if int(probe.item()) != world:
@@ -89,6 +93,57 @@ def _start_rccl(rank: int, world: int, index: int):
         return group, None
     except Exception as exc:  # noqa: BLE001 - RCCL only carries the aggregate counters: keep the job alive
         return None, f"{type(exc).__name__}: {exc}"[:300]
+
+
+def _start_rccl_bounded(rank: int, world: int, index: int, seconds: float | None = None):
+    """`_start_rccl` with a bound on how long it may take.  RCCL's rendezvous and first all-reduce FAIL in most broken
+    set-ups, and then `_start_rccl` returns the reason; in some (a fabric link that never answers, a peer that died in
+    its own start) they HANG.  The attempt therefore runs in a daemon thread: when it has not returned after `seconds`,
+    this rank reports failure like any other -- the ranks then agree over gloo to leave the counters there -- and the
+    thread is left behind (`left_behind()`: the process must then end through `shutdown()`, which does not try to tear
+    the half-made communicator down).  Nothing on the step path ever touches RCCL, so the measurement is not affected."""
+    global _LEFT_BEHIND
+    import threading
+
+    if seconds is None:
+        try:
+            seconds = float(os.environ["PIKAZOO_RCCL_START_TIMEOUT_S"])
+        except (KeyError, ValueError):
+            seconds = RCCL_START_TIMEOUT_S
+    box = {}
+    worker = threading.Thread(target=lambda: box.setdefault("result", _start_rccl(rank, world, index)), daemon=True,
+                              name="pikazoo-rccl-start")
+    worker.start()
+    worker.join(seconds)
+    if worker.is_alive():
+        _LEFT_BEHIND = True
+        return None, f"RCCL did not come up within {seconds:.0f} s on rank {rank} (its start was left behind)"
+    return box.get("result", (None, "the RCCL start thread ended without a result"))
+
+
+def left_behind() -> bool:
+    """True when an RCCL start of this process never returned (see `_start_rccl_bounded`)."""
+    return _LEFT_BEHIND
+
+
+def shutdown(exit_code: int = 0):
+    """End of a job: destroy the process groups -- unless an RCCL start was left behind in this process: tearing its
+    half-made communicator down may block for ever, so the ranks meet at a last gloo barrier, flush their output and
+    leave through `os._exit` (the daemon thread and RCCL's own threads go with the process)."""
+    if not dist.is_initialized():
+        return
+    try:
+        anyone = torch.tensor([1 if _LEFT_BEHIND else 0], dtype=torch.int64)
+        dist.all_reduce(anyone, op=dist.ReduceOp.MAX)  # (over gloo: the default group)
+        hung = int(anyone.item()) != 0
+    except Exception:  # noqa: BLE001
+        hung = _LEFT_BEHIND
+    if not hung:
+        dist.destroy_process_group()
+        return
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(int(exit_code))
 
 
 def init_from_env(backend: str | None = None, device_index: int | None = None) -> tuple[int, int, int]:
@@ -102,8 +157,9 @@ def init_from_env(backend: str | None = None, device_index: int | None = None) -
     RCCL is used is decided COLLECTIVELY: every rank reports over gloo whether its communicator came up and its
     probe all-reduce gave the world size, and if any rank failed, all of them leave the counters on gloo and say
     so (`fallback_note`, `rccl_ranks() == 0`).  The preconditions (a usable device on every rank, no two ranks on one GPU)
-    are agreed on over gloo first, so either every rank enters RCCL's rendezvous or none does; what is NOT covered is an
-    RCCL call that hangs instead of failing -- the process group's watchdog then aborts the job.  (`_shares_a_gpu` compares
+    are agreed on over gloo first, so either every rank enters RCCL's rendezvous or none does; an RCCL start that HANGS
+    instead of failing is given up on after `RCCL_START_TIMEOUT_S` (`_start_rccl_bounded`) and reads as a failure of that
+    rank -- the job goes on over gloo and ends through `shutdown()`.  (`_shares_a_gpu` compares
     host name, the *_VISIBLE_DEVICES strings and the device index: two hosts of the same name would read as one.)"""
     global _COUNTERS, _FALLBACK_NOTE
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,7 +185,7 @@ def init_from_env(backend: str | None = None, device_index: int | None = None) -
             elif _shares_a_gpu(rank, world, index):
                 group, why = None, "two ranks share one GPU (RCCL refuses duplicate GPUs)"
             else:
-                group, why = _start_rccl(rank, world, index)
+                group, why = _start_rccl_bounded(rank, world, index)
             verdict = torch.tensor([1 if group is not None else 0], dtype=torch.int64)
             dist.all_reduce(verdict, op=dist.ReduceOp.MIN)  # over gloo: one failure anywhere moves everybody
             if int(verdict.item()) == 1:

@@ -231,6 +231,47 @@ def test_counters_fall_back_to_gloo_when_rccl_cannot_start(tmp_path):
     assert (backend, world, total, rccl) == ("gloo", "2", "3", "0") and "unavailable" in note
 
 
+_HANG_WORKER = r'''
+import os, sys, threading, time
+sys.path.insert(0, os.path.join(sys.argv[1], "pika-zoo_amd"))
+from pikazoo_amd import dist
+rank = int(os.environ["RANK"])
+# stand-ins for a node whose RCCL rendezvous never answers on rank 1 (no GPU here): the preconditions hold, rank 0's
+# communicator "comes up", rank 1's start blocks for ever
+dist._device_ready = lambda index: (True, None)
+dist._shares_a_gpu = lambda rank, world, index: False
+dist._start_rccl = (lambda r, w, i: threading.Event().wait()) if rank == 1 else (lambda r, w, i: (None, "stand-in: no RCCL on this box"))
+t0 = time.time()
+rank, world, _ = dist.init_from_env("nccl")
+total, = dist.all_reduce_sum([rank + 1])             # the counters still travel: over gloo
+open(os.path.join(sys.argv[2], f"hang_{rank}.txt"), "w").write(
+    f"{dist.backend_name()} {world} {total} {dist.rccl_ranks()} {int(dist.left_behind())} {time.time() - t0:.1f} {dist.fallback_note()}")
+print(f"rank {rank} done", flush=True)
+dist.shutdown()                                      # must not block on the start that was left behind
+raise SystemExit("shutdown() returned although an RCCL start was left behind in the job")
+'''
+
+
+def test_an_rccl_start_that_hangs_is_given_up_on_and_the_job_still_ends(tmp_path):
+    """RCCL's rendezvous / first all-reduce can HANG instead of failing (a fabric link that never answers).  The start
+    runs in a thread the rank can give up on (dist._start_rccl_bounded): after PIKAZOO_RCCL_START_TIMEOUT_S the rank
+    reports failure, every rank agrees over gloo to leave the counters there, the line's `dist_note` says what happened,
+    and `dist.shutdown()` ends every rank without touching the half-made communicator.  Rehearsed here with a start that
+    blocks for ever on rank 1 of 2."""
+    script = tmp_path / "worker.py"
+    script.write_text(_HANG_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563", OMP_NUM_THREADS="1", PIKAZOO_RCCL_START_TIMEOUT_S="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29563", str(script), str(REPO), str(tmp_path)],
+                       env=env, timeout=300, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for rank in (0, 1):
+        backend, world, total, rccl, left, took, note = (tmp_path / f"hang_{rank}.txt").read_text().split(" ", 6)
+        assert (backend, world, total, rccl) == ("gloo", "2", "3", "0") and float(took) < 60
+        assert left == str(rank)  # only rank 1 left a start behind ...
+        assert "unavailable" in note and ("did not come up within 2 s" in note) == (rank == 1)  # ... and says so
+
+
 def test_two_rank_sharding_equals_single_process(tmp_path, oracle):
     """world_size-2 gloo run: shards stepped independently + one counter all-reduce give the same
     trajectories and totals as the single-process batch (env ids are global)."""
