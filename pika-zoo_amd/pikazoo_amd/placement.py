@@ -150,22 +150,29 @@ def retained_bytes() -> int:
     return sum(size for pools in _far_pools.values() for _pool, size in pools)
 
 
-def _keep_far_pool(key, pool, block_bytes: int):
-    """Remember the pool of a block a walk found in another rank -- within ``KEEP_FAR_BYTES`` in all: the oldest kept
-    blocks that no tensor uses are dropped first (their pools die, the memory goes back to the driver); a block that is
-    in use cannot be dropped, so the total may stay above the limit until its tensor has died."""
+def _trim_far_pools(extra: int = 0):
+    """Keep the kept blocks within ``KEEP_FAR_BYTES`` (minus `extra` bytes about to be added): the oldest blocks that no
+    tensor uses are dropped first -- their pools die, the memory goes back to the driver.  A block that is in use cannot
+    be dropped, so the total may stay above the limit until its tensor has died."""
     limit = _keep_limit()
-    if block_bytes > limit:
-        return  # (never kept: the pool dies with the tensor that uses its block)
     entries = [(k, p, size) for k, pools in _far_pools.items() for p, size in pools]  # oldest first
     total = sum(size for _k, _p, size in entries)
+    if total + extra <= limit:
+        return
     _far_pools.clear()
     for k, p, size in entries:
-        if total + block_bytes > limit and _has_free_block(p, size):
+        if total + extra > limit and _has_free_block(p, size):
             total -= size  # dropped: the last reference to its pool goes with `entries`
         else:
             _far_pools.setdefault(k, []).append((p, size))
     del entries
+
+
+def _keep_far_pool(key, pool, block_bytes: int):
+    """Remember the pool of a block a walk found in another rank, within the limit (`_trim_far_pools`)."""
+    if block_bytes > _keep_limit():
+        return  # (never kept: the pool dies with the tensor that uses its block)
+    _trim_far_pools(extra=block_bytes)
     _far_pools.setdefault(key, []).append((pool, block_bytes))
 
 
@@ -232,6 +239,7 @@ def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = None):
         block = torch.empty(elems, dtype=dtype, device=device)
         return block[:numel].view(shape)
 
+    _trim_far_pools()  # (the limit may have been lowered, and blocks kept for other sizes may have become free)
     a = fresh(numel)
     # a block an earlier walk found for this size lives in a private pool of its own (`_far_pools`): when the tensor that
     # used it has died, the block is free in that pool and is handed out again here -- no second walk

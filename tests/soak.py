@@ -3,12 +3,16 @@
 launch (`pz_step`: the pair kernel / scout kernel, actions from HBM) for tens of thousands of frames per
 configuration, full state compared with the CPU oracle every `--every` frames on EVERY lane.
 
-    python tests/soak.py [--frames 20000] [--every 2000] [--n 65536] [--packed] [--rollout K [--tape]]
+    python tests/soak.py [--frames 20000] [--every 2000] [--n 65536] [--packed] [--rollout K [--tape]] [--only TEXT] [--lib FILE]
 
 --rollout K: the same frames through the k-frame launches instead (`pz_rollout_random`: the policy drawn in the
 kernel, every frame's outputs to trajectory tensors; with --tape `pz_step_many` on the same actions as a tape).
 
 --packed: the same on the packed state format (36 bytes per game); its sticky misfit flags are checked with every unpack.
+--only TEXT: the configurations whose name contains TEXT.  --lib FILE: step through a DIAGNOSTIC build of the library
+instead of the product (e.g. pika-zoo_amd/lib/ab_<name>.so of tools/ab.py --build: round 5 ran the one-computer
+configurations on a build whose computer's wave is held back in front of its loads, so that every launch takes the
+late-store path of pair_body's hand-shake); the product's build-id check is bypassed for it, nothing else changes.
 Every run also tracks, frame by frame on the device, the extremes of the values the packed format stores in narrow
 fields (ball y velocity: 13 bits signed; player y velocity: 6 bits signed) -- printed per configuration.
 """
@@ -38,9 +42,21 @@ def main():
     fmt = "packed" if "--packed" in args else "int32"
     rollout = int(args[args.index("--rollout") + 1]) if "--rollout" in args else 0
     tape = "--tape" in args
+    if "--lib" in args:
+        from pikazoo_amd import _native
+
+        class _AnyBuild:  # (a diagnostic library carries another build id than the sources': that is its point)
+            library_id = staticmethod(lambda path: "diagnostic")
+            source_id = staticmethod(lambda: "diagnostic")
+
+        _native.LIB_PATH = Path(args[args.index("--lib") + 1]).resolve()
+        _native._pz_build = lambda: _AnyBuild
+        print(f"stepping through the diagnostic library {_native.LIB_PATH.name}", flush=True)
+    only = args[args.index("--only") + 1] if "--only" in args else ""
     configs = [
         ("human_vs_human", dict(), dict(), None),
         ("config 3: p2 computer, flight tables", dict(is_player2_computer=True), dict(is_player2_computer=True), None),
+        ("p1 computer, flight tables", dict(is_player1_computer=True), dict(is_player1_computer=True), None),
         ("config 3: p2 computer, computed predictors", dict(is_player2_computer=True, flight_tables=False),
          dict(is_player2_computer=True), None),
         ("both computer, random serve, tables", dict(is_player1_computer=True, is_player2_computer=True, serve="random"),
@@ -50,6 +66,8 @@ def main():
     po.build()
     ok = True
     for name, kw, okw, wr in configs:
+        if only not in name:
+            continue
         env = pikazoo_v0.env(num_envs=n, device="cuda:0", seed=123, env_id_base=1 << 34, validate_actions=False,
                              state_format=fmt, **kw)
         ocfg_kw = dict(seed=123, env_id_base=1 << 34, **okw)

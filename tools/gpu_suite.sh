@@ -12,6 +12,9 @@
 #             python tools/ab.py --build --common "-DPZ_DEV_SUBSET=705" unordered=-DPZ_DEV_UNORDERED_EARLY_STORES \
 #                 early0=-DPZ_EARLY_OWN_STORES=0 delayedge=-DPZ_DEV_DELAY_PARTNER_LOADS=2 \
 #                 delayunordered="-DPZ_DEV_DELAY_PARTNER_LOADS=2 -DPZ_DEV_UNORDERED_EARLY_STORES"
+#   edge_soak  the one-computer configurations (config 3, p1 computer) for 60 000 frames against the oracle on a build whose
+#           computer's wave is ALWAYS late (-DPZ_DEV_DELAY_PARTNER_LOADS=1, full library: python tools/ab.py --build
+#           delayfull=-DPZ_DEV_DELAY_PARTNER_LOADS=1): every launch takes the hand-shake's late-store path
 #   chains  one batch as two / four sub-batch chains in ONE hipGraph (fork / join at its ends) and as separate graphs on
 #           separate streams, human vs human and config 3, 65 536 and 131 072 games (tools/chains.py)
 #   soak    long parity runs against the CPU oracle on every lane (tests/soak.py), single-frame and k-frame, both formats
@@ -64,6 +67,10 @@ edge)
     step 300 ab_early_store_edge_hot_tape.log python3 tools/ab.py --ai base+t unordered+t early0+t
     step 300 early_store_edge_partner_held_back.log python3 tools/ab.py --ai --slices 2048 base+t delayedge+t delayunordered+t
     tail -n 8 "$O"/*.log
+    ;;
+edge_soak)
+    step 600 soak_one_computer_partner_always_late_65536x60000.log python3 tests/soak.py --frames 60000 --every 10000 --only "computer, flight tables" --lib pika-zoo_amd/lib/ab_delayfull.so
+    tail -n 4 "$O"/soak_one_computer*.log
     ;;
 chains)
     step 300 chains_65536.log python3 tools/chains.py --separate
