@@ -13,11 +13,13 @@ policy kernel BEFORE the timed region, so every input is resident in HBM when ti
 
 Sequence of one measurement (every part replayed by the CPU oracle for the in-run parity check):
   reset -> BURN-IN (untimed; --burn-in frames of the on-device policy, so that the timed frames are
-  steady-state play: rounds ending, auto-resets, collisions) -> W warm-up launches -> the K launches
-  captured in a hipGraph (repeated inside the graph until it holds >= 2 048 launches) -> one untimed
-  replay (graph upload + calibration) -> R timed replays, R chosen so that the timed region lasts at
-  least --min-time seconds whatever K is.  `steps` in the JSON line is K as given; `timed_steps` = the
-  launches actually timed; value = games * timed_steps / wall.
+  steady-state play: rounds ending, auto-resets, collisions) -> W warm-up launches -> K x ceil(2 048 / K)
+  launches captured in ONE hipGraph, every one on its OWN action slice (a cold tape: >= 2 048 distinct
+  slices = 1 GB streamed from HBM whatever K is, so that the driver's `--steps 20`, the default run and
+  every rocprofv3 trace measure one workload; `--action-tape hot` re-uses the K slices instead) -> one
+  untimed replay (graph upload + calibration) -> R timed replays, R chosen so that the timed region
+  lasts at least --min-time seconds whatever K is.  `steps` in the JSON line is K as given;
+  `timed_steps` = the launches actually timed; value = games * timed_steps / wall.
 
 Multi-GPU (one rank per GPU; under torch.distributed.run as the driver launches it, or plain
 `python bench.py --gpus N`, which starts that launcher as a child process): weak scaling, rank r owns
@@ -26,25 +28,25 @@ after the timed region (RCCL; `rccl_ranks` = 0 and `dist_note` says why when the
 gloo).  Timing: barrier + synchronize on both sides, MAX over ranks; `per_rank` lists every rank's own
 launch duration and rate, and the first and the last rank replay 1 024 of their games on the oracle.
 
-The single JSON line also carries
-  roofline     -- algorithmic HBM bytes per launch (649 B/game-step) / average launch
-                  duration measured with HIP events on the launch stream over the timed region, against
-                  8 TB/s (`frac`: a CONTRACT-bytes figure, see `frac_basis`); the same from the wall clock
-                  `value` is computed from (`frac_wall`); and from the PMC-measured bytes of
-                  profiles/traffic.json (`traffic`, `frac_traffic`); `regime` / `bound_detail`: what the
-                  launch actually runs against at this batch size;
-  other_action_tape -- the same workload on the other kind of action tape (hot <-> cold);
-  cpu_baseline -- the CPU oracle (oracle/pz_oracle.c, a C port of the reference's Python step,
-                  kind="port") timed on this host's cores on a bounded sample of the same workload,
-                  and used to check the GPU trajectories bit-for-bit on a lane subset; the reference's
-                  own Python step as measured in the survey container beside it;
-  configs      -- the other single-GPU BASELINE configs (2: 4 096 games, 3: player 2 = computer,
-                  5: fused wrappers), the packed / int16 formats and the 524 288-game batch, each timed the
-                  same way, oracle-checked, with `regime`, `traffic`, `frac_traffic`; the k-frame
-                  launches (pz_rollout_random, pz_step_many, k = 32; on their own 297 + 352 / k bytes,
-                  with where their two observation tensors were placed and what pure stores of the
-                  launch's pattern reach on those tensors, measured in the run) and the
-                  policy-in-the-step launch.
+The single JSON line is FLAT (scalars and short strings only, < 8 KB: the driver's record drops nested objects) and carries
+  roofline     -- algorithmic HBM bytes per launch (649 B/game-step) / average launch duration measured with
+                  HIP events on the launch stream over the timed region, against 8 TB/s (`frac`: a CONTRACT-bytes
+                  figure, see `frac_basis`); the same from the wall clock `value` is computed from (`frac_wall`); and
+                  from the PMC-measured bytes of profiles/traffic.json (`traffic`, `frac_traffic`, with the build the
+                  counters were taken on: `traffic_build_id`, `traffic_stale`); `bound_regime`: what the launch runs
+                  against at this batch size; and one scalar per figure of every other measurement of the run:
+                  cold_tape_* / hot_tape_* (the same workload on both kinds of action tape), floor_* (what the launch is
+                  made of: pz_probe_launch of the diagnostics library), two_chains_* (the batch as two sub-batch chains),
+                  cfg2_* cfg3_* cfg3_compute_* cfg5_* n524288_* packed_* int16obs_* (the other single-GPU BASELINE configs,
+                  the packed / int16 formats and the 524 288-game batch, each timed like the headline and oracle-checked),
+                  rollout_k32_* step_many_k32_* ..._p2_computer_* rollout_k128_* (the k-frame launches, on their own
+                  297 + 352 / k bytes), policy_fused_*, configs_parity_all_bit_exact, per_rank_* (N ranks);
+  cpu_baseline -- the CPU oracle (oracle/pz_oracle.c, a C port of the reference's Python step, kind="port") timed on
+                  this host's cores on a bounded sample of the same workload, and used to check the GPU trajectories
+                  bit-for-bit on a lane subset; the reference's own Python step as measured in the survey container;
+  config       -- workload, batch, tape, kernel, build id, ranks / rccl_ranks / dist_note.
+The verbose blocks (every config's full entry, --extra, per-rank rows, what the regimes mean) go to --configs-out FILE,
+or to stderr as one line.
 """
 from __future__ import annotations
 
@@ -851,7 +853,7 @@ def fractions(r, num_envs, key):
     reg = regime(num_envs)
     return {"frac": r["frac"], "frac_wall": r["frac_wall"], "traffic": traffic,
             "frac_traffic": (traffic / launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-            "traffic_key": key, "regime": reg}  # (what a regime means: `roofline.regimes`, once per line)
+            "traffic_key": key, "regime": reg}  # (what a regime means: `regimes` of the verbose blocks)
 
 
 def config_entry(r, workload, num_envs, key):
