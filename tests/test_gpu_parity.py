@@ -744,6 +744,8 @@ def test_randomized_config_sweep_vs_oracle(oracle):
     tables_ref = C.byref(flight_tables(dev)[0])
     trials = int(os.environ.get("PZ_SWEEP_TRIALS", "60"))  # a one-off long run is kept under profiles/
     for trial in range(trials):
+        if trial and trial % 5000 == 0:  # (a long run says that it is alive: the GPU box kills a silent command as hung)
+            print(f"[sweep] {trial} of {trials} configurations bit-exact so far", flush=True)
         tb = tables_ref if rnd.random() < 0.5 else None  # flight look-up tables or computed predictors
         n = rnd.choice([1, 2, 3, 31, 63, 64, 65, 100, 127, 128, 129, 255, 300, 511, 640, 700])
         stride = n + rnd.choice([0, 0, 1, 7, 64, 130])
