@@ -6,6 +6,9 @@
 #   check   GPU test suite, __graft_entry__.smoke(), the default bench line (+ its --configs-out file)
 #   bench   the default bench line and the --extra line only
 #   driver  the bench line exactly as the driver runs it (--steps 20 --warmup 5)
+#   variants  the bench line's other workloads and launch modes, headline only (--no-configs): config 3, config 5, packed,
+#           int16 rows, hot tape, direct C-ABI launches, env.step(), two ranks on one device over gloo -- each must print
+#           a line with its in-run oracle parity true
 #   edge    config 3's early stores: A/B of the LDS hand-shake against round 4's unordered form and against no
 #           early stores, then the deterministic proof of the edge: the computer's wave held back ~16 000 cycles in front of
 #           its first load must stay bit-exact with the hand-shake and breaks without it.  Variants (build here first):
@@ -61,6 +64,26 @@ bench)
 driver)
     timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_driver.json" 2> "$O/bench_driver.err" || { echo "bench failed"; tail "$O/bench_driver.err"; exit 1; }
     bench_summary "$O/bench_driver.json"
+    ;;
+variants)
+    for v in "--p2-computer" "--wrappers" "--state-format packed" "--int16-obs" "--action-tape hot --steps 20 --warmup 5" \
+             "--launch cabi --steps 500" "--launch api --steps 500" "--p2-computer --no-flight-tables" "--p1-computer"; do
+        name=$(echo "$v" | tr -c 'a-z0-9\n' '_')
+        step 300 "bench$name.json" python3 bench.py --no-configs --min-time 0.1 --cpu-seconds 2 $v
+    done
+    PZ_BENCH_ONE_DEVICE=1 timeout -k 10 400 python3 bench.py --gpus 2 --no-configs --min-time 0.1 --dist-backend gloo --p2-computer > "$O/bench_two_ranks_cfg3.json" 2> "$O/bench_two_ranks_cfg3.err" || { echo "two ranks failed"; tail "$O/bench_two_ranks_cfg3.err"; exit 1; }
+    python3 - "$O"/bench*.json <<'PY'
+import json, sys
+bad = 0
+for path in sys.argv[1:]:
+    d = json.loads([ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1])
+    r, c = d["roofline"], d["config"]
+    ok = r["parity_first_last_rank_bit_exact"] is True and len(json.dumps(d)) < 8000
+    bad += not ok
+    print(f"{path.rsplit('/', 1)[1]:60s} {d['value'] / 1e9:6.2f} G  {r['launch_us']:6.2f} us  frac {r['frac']:.3f}  traffic {r['traffic']}  stale {r['traffic_stale']}  "
+          f"tape {c['action_tape']}  parity {r['parity_first_last_rank_bit_exact']} ({r['parity_ranks_checked']} ranks)  {len(json.dumps(d))} B")
+sys.exit(1 if bad else 0)
+PY
     ;;
 edge)
     step 300 ab_early_store_edge_cold_tape.log python3 tools/ab.py --ai --slices 2048 base+t unordered+t early0+t
