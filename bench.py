@@ -778,8 +778,12 @@ def load_traffic(workload_key, num_envs):
     return None if status["stale"] else entry["hbm_bytes_per_launch"]
 
 
-def traffic_key(num_envs, p2_computer=False, wrappers=False, flight_tables=True, state_format="int32", obs16=False):
-    """The profiles/traffic.json entry of a single-frame workload."""
+def traffic_key(num_envs, p2_computer=False, wrappers=False, flight_tables=True, state_format="int32", obs16=False,
+                p1_computer=False):
+    """The profiles/traffic.json entry of a single-frame workload (none was profiled with a computer player 1: another
+    kernel, so no counted bytes for it)."""
+    if p1_computer:
+        return "p1_computer_unprofiled"
     wl = (("cfg3" if flight_tables else "cfg3_compute") if p2_computer else ("cfg5" if wrappers else "random_random"))
     if num_envs != 65536:
         wl += f"_{num_envs}"
@@ -1005,7 +1009,8 @@ def main():
             r = measure(args, dist.weak_shard(kw["num_envs"], rank, world), device, **{**sub, **kw})
             r.pop("raw")
             tk = traffic_key(kw["num_envs"], kw.get("p2_computer", False), kw.get("wrappers", False),
-                             kw.get("flight_tables", True), kw.get("state_format", "int32"), kw.get("obs16", False))
+                             kw.get("flight_tables", True), kw.get("state_format", "int32"), kw.get("obs16", False),
+                             args.p1_computer)
             configs[key] = config_entry(r, wl, kw["num_envs"], tk)
         configs["cfg3"]["flight_tables"] = table_info
         # the k-frame launches (state in registers, every frame's outputs to [k][N]... tensors), on
@@ -1028,7 +1033,7 @@ def main():
         for key, (wl, kw) in traj.items():
             r = measure_rollout(args, shard, device, check_lanes=1024, **{"k": 32, **kw})
             # counted bytes of one k-frame launch (profiles/traffic.json: FETCH_SIZE x 2 + WRITE_SIZE of the same kernel)
-            tr = load_traffic(key, kw.get("num_envs", args.num_envs))
+            tr = None if args.p1_computer else load_traffic(key, kw.get("num_envs", args.num_envs))
             r.update(traffic=tr, frac_traffic=None if tr is None else
                      tr / (r["k"] * r["us_per_frame"] * 1e-6) / 1e9 / HBM_PEAK_GBPS)
             r.update(workload=wl, num_envs=kw.get("num_envs", args.num_envs))
@@ -1077,7 +1082,8 @@ def main():
 
     if rank == 0:
         alg_bytes = main_res["algorithmic_bytes_per_launch"]
-        wl = traffic_key(args.num_envs, args.p2_computer, args.wrappers, tables, args.state_format, args.int16_obs)
+        wl = traffic_key(args.num_envs, args.p2_computer, args.wrappers, tables, args.state_format, args.int16_obs,
+                         args.p1_computer)
         fr = fractions(main_res, args.num_envs, wl)
         tstat = _TRAFFIC_STATUS.get(wl, {})
         checked = [p for p in per_rank if p["parity_bit_exact"] is not None]

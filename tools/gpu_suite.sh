@@ -71,6 +71,7 @@ variants)
         name=$(echo "$v" | tr -c 'a-z0-9\n' '_')
         step 300 "bench$name.json" python3 bench.py --no-configs --min-time 0.1 --cpu-seconds 2 $v
     done
+    step 400 quickstart.log python3 examples/quickstart.py
     PZ_BENCH_ONE_DEVICE=1 timeout -k 10 400 python3 bench.py --gpus 2 --no-configs --min-time 0.1 --dist-backend gloo --p2-computer > "$O/bench_two_ranks_cfg3.json" 2> "$O/bench_two_ranks_cfg3.err" || { echo "two ranks failed"; tail "$O/bench_two_ranks_cfg3.err"; exit 1; }
     python3 - "$O"/bench*.json <<'PY'
 import json, sys
