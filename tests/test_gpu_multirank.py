@@ -5,7 +5,8 @@ only collective is a SUM all-reduce of the counters.  Here two fresh child proce
 backend gloo, both on ``cuda:0``, launched before anything in them touches the GPU) each step their shard through
 ``pikazoo_amd``; the concatenated shards must equal the single-process batch bit for bit, and the all-reduced
 counters must equal its totals.  The same launcher then runs ``bench.py --gpus 2`` the way the driver does (with
-gloo standing in for RCCL on a one-GPU box) and checks the line it prints.
+gloo standing in for RCCL on a one-GPU box) and checks the line it prints -- and the one-rank line of the driver's own
+command: flat, below 8 KB, one scalar per BASELINE-config figure.
 """
 import json
 import os
@@ -169,3 +170,53 @@ def test_bench_under_the_drivers_launcher_and_rccl_request_on_one_gpu():
     assert all(p["parity_bit_exact"] is None for p in out["per_rank"])  # --no-cpu: nothing was replayed
     assert out["roofline"]["parity_first_last_rank_bit_exact"] is None and out["roofline"]["parity_ranks_checked"] == 0
     assert out["config"]["rccl_ranks"] == 0 and "share one GPU" in out["config"]["dist_note"]
+
+
+def test_the_default_bench_line_is_flat_below_8_kb_and_carries_every_baseline_config(tmp_path):
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` -- the driver's own command.  Its record keeps the scalar members
+    of `config` / `roofline` / `cpu_baseline` and drops nested objects, and its stdout tail is 8 KB: so the line must be
+    flat, short, and carry one scalar per figure the documents quote for a BASELINE config -- measured on the
+    cold action tape whatever --steps is, with the launch-floor twin of the diagnostics library and the two-chain
+    measurement beside the headline, every oracle replay of the run bit-exact, and the verbose blocks in the side file."""
+    side = tmp_path / "configs.json"
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "2",
+           "--configs-out", str(side)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(REPO))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 8000
+    out = json.loads(lines[0])
+    for block in ("config", "roofline", "cpu_baseline"):
+        nested = {k: v for k, v in out[block].items() if isinstance(v, (dict, list))}
+        assert not nested, (block, list(nested))
+        assert all(not isinstance(v, str) or len(v) <= 128 for v in out[block].values()), block  # (the record cuts strings at 128)
+    cfg, roof, cpu = out["config"], out["roofline"], out["cpu_baseline"]
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5 and out["unit"] == "env-steps/s"
+    assert out["dtype"] == "int32" and out["scaling"] == "weak" and out["vs_baseline"] is None and out["higher_is_better"] is True
+    assert np.isclose(out["value"], 65536 / (out["ms_per_step"] * 1e-3), rtol=1e-6)
+    assert cfg["action_tape"] == "cold" and cfg["action_tape_bytes"] > 1 << 30 and cfg["num_envs_per_gpu"] == 65536
+    assert len(cfg["build_id"]) == 16 and cfg["ranks"] == 1 and "workload" in cfg
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s"
+    assert np.isclose(roof["frac"], roof["achieved"] / roof["peak"]) and 0.5 < roof["frac"] < 1.0
+    assert np.isclose(roof["achieved"], 649 * 65536 / (roof["launch_us"] * 1e-6) / 1e9, rtol=1e-6)
+    # the counted bytes: either of this build (or of a build with the same kernel), or declared stale and absent
+    assert (roof["traffic_stale"] is False and roof["traffic"] > 0 and len(roof["traffic_build_id"]) == 16) or \
+           (roof["traffic_stale"] is True and roof["traffic"] is None and roof["frac_traffic"] is None)
+    want = ["cold_tape_launch_us", "cold_tape_frac", "hot_tape_launch_us", "hot_tape_frac", "floor_empty_us", "floor_loads_us",
+            "floor_loads_stores_us", "floor_stand_in_us", "cfg2_launch_us", "cfg2_frac", "cfg3_launch_us", "cfg3_frac",
+            "cfg3_compute_launch_us", "cfg5_launch_us", "cfg5_frac", "n524288_launch_us", "n524288_frac", "packed_launch_us",
+            "packed_524288_launch_us", "rollout_k32_us_per_frame", "rollout_k32_frac", "step_many_k32_us_per_frame",
+            "rollout_k32_p2_computer_us_per_frame", "step_many_k32_p2_computer_us_per_frame", "rollout_k128_us_per_frame",
+            "rollout_k32_4096_us_per_frame", "policy_fused_launch_us", "two_chains_one_graph_us", "two_graphs_two_streams_us",
+            "per_rank_min_value", "per_rank_max_launch_us"]
+    missing = [k for k in want if not isinstance(roof.get(k), float)]
+    assert not missing, missing
+    assert roof["cold_tape_launch_us"] == round(roof["launch_us"], 4) and roof["hot_tape_launch_us"] < roof["cold_tape_launch_us"] * 1.02
+    assert roof["floor_empty_us"] < roof["floor_loads_us"] < roof["floor_loads_stores_us"] < roof["floor_stand_in_us"] * 1.05
+    assert roof["configs_parity_all_bit_exact"] is True and roof["configs_parity_checked"] >= 18
+    assert roof["two_chains_parity_bit_exact"] is True and roof["parity_first_last_rank_bit_exact"] is True
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["parity_bit_exact"] is True
+    assert cpu["reference_python_steps_per_s_per_core"] == 55100 and "sample" in cpu
+    verbose = json.loads(side.read_text())
+    assert {"configs", "per_rank", "regimes", "launch_floor", "other_action_tape", "traffic_status"} <= set(verbose)
+    assert verbose["configs"]["cfg3"]["parity_bit_exact"] is True and out["configs_file"] == str(side)
