@@ -216,7 +216,9 @@ def main():
         out["kernel_digests"] = {k: d for k, (d, _) in kernel_digest.kernels(_native.LIB_PATH).items() if k.startswith(STEP_KERNELS)}
     except Exception as exc:  # noqa: BLE001
         print(f"(no build id / kernel digests: {type(exc).__name__}: {exc})")
-    (dst / f"{tag}_pmc_summary.json").write_text(json.dumps(out, indent=1))
+    if summary:  # (a run of kernel-trace sections only has no counters: it must not replace a full run's summary, which
+        # gpurun would then overwrite in the caller's gpurun_out/)
+        (dst / f"{tag}_pmc_summary.json").write_text(json.dumps(out, indent=1))
     print(json.dumps(derived, indent=1))
 
 
