@@ -711,6 +711,40 @@ def test_placement_keeps_a_bounded_amount_and_reset_returns_it_to_the_driver(mon
     assert free1 >= free0 - (64 << 20), (free0, free1)  # everything the walks and the kept blocks held is back
 
 
+def test_the_binding_stub_of_integration_md_runs_as_written(oracle):
+    """INTEGRATION.md section 2 shows the ~40-line ctypes stub a maintainer of the reference would add
+    (`pikazoo/env/_hip_backend.py`).  This runs that very text -- the first python block of the file, only the library's
+    path made absolute -- against the oracle: documentation that is executed cannot drift from the ABI it describes."""
+    import re
+    from pathlib import Path
+
+    from pikazoo_amd import _native
+
+    repo = Path(__file__).resolve().parent.parent
+    text = (repo / "INTEGRATION.md").read_text()
+    block = re.search(r"```python\n(.*?)```", text, flags=re.S).group(1)
+    assert 'C.CDLL("libpikazoo_hip.so")' in block and "class HipBackend" in block
+    ns = {}
+    exec(block.replace('C.CDLL("libpikazoo_hip.so")', f'C.CDLL("{_native.LIB_PATH}")'), ns)  # noqa: S102
+    n = 300  # (ragged: not a multiple of 64)
+    cfg = ns["PzConfig"](winning_score=2, serve_mode=0, auto_reset=1, seed=11, env_id_base=5)
+    backend = ns["HipBackend"](n, cfg, device="cuda:0")
+    ref = oracle.OracleEnv(n, oracle.make_config(winning_score=2, seed=11, env_id_base=5))
+    backend.reset()
+    o1, _ = ref.reset()
+    assert np.array_equal(backend.obs[0].cpu().numpy(), o1)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    for _ in range(400):
+        a = torch.randint(0, 18, (2, n), generator=g, dtype=torch.int32)
+        dev = a.to("cuda:0")
+        backend.step(dev[0], dev[1])
+        robs, rrew, rterm = ref.step(a[0].numpy(), a[1].numpy())
+    torch.cuda.synchronize()
+    assert np.array_equal(backend.state.cpu().numpy(), ref.state)
+    assert np.array_equal(backend.obs[1].cpu().numpy(), robs[1]) and np.array_equal(backend.rew[0].cpu().numpy(), rrew[0])
+    assert np.array_equal(backend.term.cpu().numpy(), rterm)
+
+
 def test_launch_floor_probe_runs_on_scratch_buffers_and_touches_nothing_else():
     """pz_probe_launch (the headline launch's geometry without its game): every `what` launches for ragged and
     full batches, writes only inside the buffers it was handed (guard words behind each stay intact), and from `what` = 2 on
