@@ -27,6 +27,13 @@ class SimplifyAction(BaseParallelWrapper):
         self.fused = raw._fuse_simplify_action()
         if not self.fused:
             raw._note_unfused("SimplifyAction")
+            if not raw.validate_actions:
+                import warnings
+
+                warnings.warn("an un-fused SimplifyAction maps a device action outside its 13-tuple to an out-of-range "
+                              "action of the env below, and only that env's validate_actions reports it (as the "
+                              "reference's IndexError): this env was built with validate_actions=False, so such an "
+                              "action will step a game with an undefined input unnoticed", RuntimeWarning, stacklevel=2)
             # entry 13: what an action outside [0, 13) maps to -- invalid below as well
             self._maps = {a: torch.tensor(ACTION_MAP[a] + (255,), dtype=torch.int32, device=raw.device) for a in ACTION_MAP}
 

@@ -274,6 +274,8 @@ def test_wrappers_outside_the_kernel_second_instances_and_the_scalar_api():
         env.step({"player_1": [12] * 8, "player_2": [0] * 8})
     with pytest.raises(IndexError):  # ... and a host index past the tuple raises like the reference's `action_map[agent][13]`
         env.step({"player_1": [13] * 8, "player_2": [0] * 8})
+    with pytest.warns(RuntimeWarning, match="validate_actions=False"):  # nobody would report a bad device action there
+        W.SimplifyAction(W.SimplifyAction(pikazoo_v0.env(num_envs=8, seed=1, validate_actions=False)))
     # the reference indexes its 13-tuple the Python way (simplify_action.py:23): -13 .. -1 count from the end.  Host and
     # device values take the same wrap-around through the un-fused wrapper: -9 is index 4 (action 4 for player 1)
     wrapped, direct = (W.SimplifyAction(W.SimplifyAction(pikazoo_v0.env(num_envs=8, seed=3))) for _ in range(2))
