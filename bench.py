@@ -51,6 +51,7 @@ or to stderr as one line.
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import math
 import os
@@ -95,6 +96,14 @@ def parse_args():
     ap.add_argument("--wrappers", action="store_true", help="config 5: fused SimplifyAction+RewardByBallPosition")
     ap.add_argument("--no-flight-tables", action="store_true",
                     help="computer player: run the flight predictors in the kernel instead of the HBM look-up tables")
+    ap.add_argument("--flight-tables", choices=["both", "power_hit", "none"], default=None,
+                    help="computer players: which flight look-up tables the launches use (both: 927 + 82 MB per device, "
+                         "power_hit: the 82 MB one, none: everything predicted in the kernel); default both")
+    ap.add_argument("--no-landing-reuse", action="store_true",
+                    help="computer players: predict the landing point on every frame like the reference (pz_config."
+                         "landing_fresh = NULL) instead of only on the frames that interrupt a flight")
+    ap.add_argument("--action-dtype", choices=["int32", "int64", "uint8", "int16"], default="int32",
+                    help="element type of the action tensors the launches read (pz_action_format)")
     ap.add_argument("--state-format", choices=["int32", "packed"], default="int32",
                     help="headline run: state as int32[44, N] columns (BASELINE's contract, default) or in the packed "
                          "36-byte format (SURVEY 8(f)-3)")
@@ -122,14 +131,15 @@ def parse_args():
 
 
 def make_env(shard, device, *, num_envs, p1_computer=False, p2_computer=False, wrappers=False, flight_tables=True,
-             state_format="int32", obs16=False, validate_actions=False):
+             state_format="int32", obs16=False, validate_actions=False, landing_reuse=None):
     from pikazoo_amd.wrappers import RewardByBallPosition, SimplifyAction
 
     env = pikazoo_v0.env(winning_score=15, serve="winner", is_player2_computer=p2_computer,
                          is_player1_computer=p1_computer,
                          num_envs=num_envs, device=device, seed=0, env_id_base=shard.env_id_base,
                          auto_reset=True, validate_actions=validate_actions, flight_tables=flight_tables,
-                         state_format=state_format, observation_dtype=torch.int16 if obs16 else torch.int32)
+                         state_format=state_format, observation_dtype=torch.int16 if obs16 else torch.int32,
+                         landing_reuse=landing_reuse)
     if wrappers:
         env = SimplifyAction(env)
         env = RewardByBallPosition(env, WRAPPER_TABLE, 216, 176)
@@ -177,12 +187,17 @@ def run_gpu(env, acts, warmup, steps, launch, min_time):
     r1, r2, tm = raw._rew_raw[0].data_ptr(), raw._rew_raw[1].data_ptr(), raw._term_u8.data_ptr()
     tables = raw._tables_ref
     a_ptr = acts.data_ptr()
-    a_stride = 2 * n * 4
+    elem = acts.element_size()  # the launches read the tape's own element type (pz_config.action_format)
+    a_stride = 2 * n * elem
+    if acts.dtype != torch.int32:
+        cfg_typed = _native.PzConfig.from_buffer_copy(raw._cfg)
+        cfg_typed.action_format = _native.ACTION_FORMATS[str(acts.dtype).replace("torch.", "")]
+        cfg = C.byref(cfg_typed)
 
     def launch_range(t_lo, t_hi, stream):
         s = stream.cuda_stream
         for t in range(t_lo, t_hi):
-            rc = lib.pz_step(st, n, raw._stride, cfg, a_ptr + t * a_stride, a_ptr + t * a_stride + n * 4, o1, o2, r1, r2, tm,
+            rc = lib.pz_step(st, n, raw._stride, cfg, a_ptr + t * a_stride, a_ptr + t * a_stride + n * elem, o1, o2, r1, r2, tm,
                              None, tables, s)
             if rc:
                 _native.check(rc, "pz_step")
@@ -286,7 +301,7 @@ def oracle_parity(raw, seq, p1_computer, p2_computer, wrappers, lanes, cores):
         chk.rollout_random(ACTION_SEED, 0, seq["warmup"])
     for _ in range(seq["passes"]):
         chk.rollout_random(ACTION_SEED, seq["warmup"], seq["unit_steps"])
-    gpu_state = raw.state[:, :k].cpu().numpy()
+    gpu_state = raw.read_state()[:, :k].cpu().numpy()
     total = seq["burn_in"] + seq["warmup"] + seq["passes"] * seq["unit_steps"]
     return {"parity_lanes_checked": k, "parity_steps_checked": total,
             "parity_bit_exact": bool((gpu_state == chk.state).all())}
@@ -340,7 +355,7 @@ def cpu_baseline(args, raw_gpu, p2_computer, wrappers):
 
 def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=False, launch=None, steps=None,
             warmup=None, burn=None, min_time=None, check_lanes=0, flight_tables=True, state_format="int32", obs16=False,
-            validate_actions=False, tape="cold"):
+            validate_actions=False, tape="cold", landing_reuse=None, action_dtype=torch.int32):
     """One timed measurement of the single-frame launch.  tape = "cold": every launch of the timed unit reads its own
     action slice (K x graph_repeats(K) distinct slices behind the warm-up ones: >= 1 GB at 65 536 games, streamed from
     HBM); "hot": the K slices are re-used."""
@@ -352,12 +367,14 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     launch = args.launch if launch is None else launch
     env = make_env(shard, device, num_envs=num_envs, p1_computer=args.p1_computer, p2_computer=p2_computer,
                    wrappers=wrappers, flight_tables=flight_tables, state_format=state_format, obs16=obs16,
-                   validate_actions=validate_actions)
+                   validate_actions=validate_actions, landing_reuse=landing_reuse)
     raw = env.unwrapped
     env.reset()
     burn_in(raw, burn)
     unit_steps = steps * graph_repeats(steps) if (tape == "cold" and launch == "graph") else steps
     acts = pregenerate_actions(raw, warmup + unit_steps)
+    if action_dtype != torch.int32:
+        acts = acts.to(action_dtype)  # (outside every timed region: the tape as a policy of that dtype would leave it)
     torch.cuda.synchronize(device)
     run = run_gpu(env, acts, warmup, steps, launch, min_time)
     cdev = dist.collective_device(device)  # counters live on the GPU under nccl (RCCL), on the CPU under gloo
@@ -376,7 +393,7 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
         "value": n_total * run["timed_steps"] / wall,
         "launch_us": launch_us, "wall_us_per_step": wall * 1e6 / run["timed_steps"],
         "achieved_GBps": alg / (launch_us * 1e-6) / 1e9, "algorithmic_bytes_per_launch": alg,
-        "raw": raw, "action_tape": tape, "action_tape_bytes": int(acts.numel() * 4),
+        "raw": raw, "action_tape": tape, "action_tape_bytes": int(acts.numel() * acts.element_size()),
     }
     res["frac"] = res["achieved_GBps"] / HBM_PEAK_GBPS
     res["frac_wall"] = alg / (res["wall_us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
@@ -533,7 +550,7 @@ def measure_rollout(args, shard, device, k, tape=False, p2_computer=False, min_t
             for j in range(launches):  # (the tape holds the policy stream's slices j * k ..: the same actions)
                 chk.rollout_random(ACTION_SEED, j * k, k)
         res.update(parity_lanes_checked=lanes, parity_steps_checked=burn + k + (reps + 1 + lead_in) * launches * k,
-                   parity_bit_exact=bool((raw.state[:, :lanes].cpu().numpy() == chk.state).all()))
+                   parity_bit_exact=bool((raw.read_state()[:, :lanes].cpu().numpy() == chk.state).all()))
     return res
 
 
@@ -732,7 +749,7 @@ def measure_two_chains(args, shard, device, steps=512, p2_computer=False, check_
             chk.rollout_random(BURN_SEED, 0, burn)
             for _ in range(passes):
                 chk.rollout_random(ACTION_SEED, 0, steps)
-            ok = ok and bool((raw.state[:, c * half:c * half + check_lanes].cpu().numpy() == chk.state).all())
+            ok = ok and bool((raw.read_state()[:, c * half:c * half + check_lanes].cpu().numpy() == chk.state).all())
         out["two_chains_parity_bit_exact"] = ok
     return out
 
@@ -779,12 +796,14 @@ def load_traffic(workload_key, num_envs):
 
 
 def traffic_key(num_envs, p2_computer=False, wrappers=False, flight_tables=True, state_format="int32", obs16=False,
-                p1_computer=False):
+                p1_computer=False, landing_reuse=None):
     """The profiles/traffic.json entry of a single-frame workload (none was profiled with a computer player 1: another
     kernel, so no counted bytes for it)."""
     if p1_computer:
         return "p1_computer_unprofiled"
-    wl = (("cfg3" if flight_tables else "cfg3_compute") if p2_computer else ("cfg5" if wrappers else "random_random"))
+    mode = {True: "cfg3", "both": "cfg3", "power_hit": "cfg3_power_hit", False: "cfg3_compute", None: "cfg3_compute",
+            "none": "cfg3_compute"}[flight_tables] + ("_every_frame" if landing_reuse is False else "")
+    wl = (mode if p2_computer else ("cfg5" if wrappers else "random_random"))
     if num_envs != 65536:
         wl += f"_{num_envs}"
     if state_format == "packed":
@@ -903,7 +922,9 @@ def main():
     torch.cuda.set_device(device)
     dist.barrier()  # rank 0 may have rebuilt the library: nobody loads it earlier
     shard = dist.weak_shard(args.num_envs, rank, world)
-    tables = not args.no_flight_tables
+    tables = args.flight_tables if args.flight_tables is not None else ("none" if args.no_flight_tables else "both")
+    reuse = False if args.no_landing_reuse else None  # (None: the env's default = on with a computer player)
+    action_dtype = getattr(torch, args.action_dtype)
     single = rank == 0 and world == 1
     cdev = dist.collective_device(device)
 
@@ -920,7 +941,7 @@ def main():
     check_lanes = args.check_lanes if single else (min(1024, args.check_lanes) if rank in (0, world - 1) else 0)
     main_res = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers,
                        check_lanes=check_lanes, flight_tables=tables, state_format=args.state_format, obs16=args.int16_obs,
-                       tape=args.action_tape)
+                       tape=args.action_tape, landing_reuse=reuse, action_dtype=action_dtype)
     raw_main = main_res.pop("raw")
     # every rank's own figures (a straggler GPU is invisible in the MAX-over-ranks wall clock alone)
     parity = main_res.get("parity_bit_exact")
@@ -960,7 +981,7 @@ def main():
         o_steps = min(args.steps, 20) if other == "hot" else args.steps
         r = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers, flight_tables=tables,
                     state_format=args.state_format, obs16=args.int16_obs, steps=o_steps, warmup=5, burn=512,
-                    min_time=0.1, tape=other)
+                    min_time=0.1, tape=other, landing_reuse=reuse, action_dtype=action_dtype)
         r.pop("raw")
         other_tape = {"action_tape": other, "steps": o_steps, "action_tape_bytes": r["action_tape_bytes"],
                       "value": r["value"], "launch_us": r["launch_us"], "frac": r["frac"]}
@@ -971,10 +992,23 @@ def main():
         sub = dict(steps=1000, warmup=100, burn=2048, min_time=0.1, check_lanes=1024, launch="graph")
         specs = {
             "cfg2": ("4 096 games, random/random, winning_score=15, serve=winner", dict(num_envs=4096)),
-            "cfg3": ("65 536 games, player 2 = rule-based computer (flight look-up tables in HBM)",
+            "cfg3": ("65 536 games, player 2 = rule-based computer (both flight look-up tables in HBM: 927 + 82 MB)",
                      dict(num_envs=65536, p2_computer=True)),
+            "cfg3_power_hit": ("65 536 games, player 2 = rule-based computer, the 82 MB power-hit table only (the landing "
+                               "point predicted in the kernel on the frames that interrupt a flight)",
+                               dict(num_envs=65536, p2_computer=True, flight_tables="power_hit")),
             "cfg3_compute": ("65 536 games, player 2 = rule-based computer, flight predictors computed in the kernel",
-                             dict(num_envs=65536, p2_computer=True, flight_tables=False)),
+                             dict(num_envs=65536, p2_computer=True, flight_tables="none")),
+            # the same three with the reference's own rule -- predict the landing point on EVERY frame (physics.py:314-315:
+            # pz_config.landing_fresh = NULL) -- what the freshness bytes buy in each mode
+            "cfg3_every_frame": ("config 3, both tables, the landing point looked up on every frame",
+                                 dict(num_envs=65536, p2_computer=True, landing_reuse=False, check_lanes=0)),
+            "cfg3_power_hit_every_frame": ("config 3, power-hit table only, the landing point predicted on every frame",
+                                           dict(num_envs=65536, p2_computer=True, flight_tables="power_hit",
+                                                landing_reuse=False, check_lanes=0)),
+            "cfg3_compute_every_frame": ("config 3, no tables, the landing point predicted on every frame",
+                                         dict(num_envs=65536, p2_computer=True, flight_tables="none", landing_reuse=False,
+                                              check_lanes=0)),
             "cfg5": ("65 536 games, fused SimplifyAction + RewardByBallPosition",
                      dict(num_envs=65536, wrappers=True)),
             # the same workloads on the packed state format (36 instead of 176 bytes of state per game;
@@ -1004,15 +1038,25 @@ def main():
         tables_struct, t_landing, t_power_hit = _env.flight_tables(device)
         torch.cuda.synchronize(device)
         table_info = {"build_ms_once_per_device": (time.perf_counter() - t0) * 1e3,
-                      "bytes": int(t_landing.numel() + t_power_hit.numel())}
+                      "bytes": int(t_landing.numel() + t_power_hit.numel()),
+                      "bytes_power_hit_only": int(t_power_hit.numel())}
         for key, (wl, kw) in specs.items():
             r = measure(args, dist.weak_shard(kw["num_envs"], rank, world), device, **{**sub, **kw})
             r.pop("raw")
             tk = traffic_key(kw["num_envs"], kw.get("p2_computer", False), kw.get("wrappers", False),
                              kw.get("flight_tables", True), kw.get("state_format", "int32"), kw.get("obs16", False),
-                             args.p1_computer)
+                             args.p1_computer, kw.get("landing_reuse"))
             configs[key] = config_entry(r, wl, kw["num_envs"], tk)
         configs["cfg3"]["flight_tables"] = table_info
+        # env.step() with the action tensors a policy hands over: torch's default integer dtype (int64: argmax, multinomial,
+        # Categorical.sample, randint) goes into the launch as it is, like int32 (pz_action_format) -- eager, HIP events
+        # around the timed loop, the env built with the constructor's defaults (validate_actions on)
+        for name, dt in (("api_int32", torch.int32), ("api_int64", torch.int64)):
+            r = measure(args, shard, device, launch="api", steps=500, warmup=50, burn=512, min_time=0.1,
+                        validate_actions=True, action_dtype=dt)
+            r.pop("raw")
+            configs[name] = {"workload": f"env.step() eagerly, {dt} action tensors, validate_actions=True",
+                             "num_envs": args.num_envs, "launch_us": r["launch_us"], "wall_us_per_step": r["wall_us_per_step"]}
         # the k-frame launches (state in registers, every frame's outputs to [k][N]... tensors), on
         # their own 297 + 352 / k algorithmic bytes per game-step; write-dominated, so the rate a pure fill reaches
         # on this box is printed beside them
@@ -1083,7 +1127,7 @@ def main():
     if rank == 0:
         alg_bytes = main_res["algorithmic_bytes_per_launch"]
         wl = traffic_key(args.num_envs, args.p2_computer, args.wrappers, tables, args.state_format, args.int16_obs,
-                         args.p1_computer)
+                         args.p1_computer, reuse)
         fr = fractions(main_res, args.num_envs, wl)
         tstat = _TRAFFIC_STATUS.get(wl, {})
         checked = [p for p in per_rank if p["parity_bit_exact"] is not None]
@@ -1114,8 +1158,9 @@ def main():
                 # HBM whatever --steps is); hot: the K slices re-used out of the caches
                 "action_tape": main_res["action_tape"], "action_tape_bytes": main_res["action_tape_bytes"],
                 "launch": args.launch,
-                "kernel": kernel_name(args.num_envs, args.p2_computer or args.p1_computer, tables,
+                "kernel": kernel_name(args.num_envs, args.p2_computer or args.p1_computer, tables != "none",
                                       args.state_format == "packed"),
+                "flight_tables": tables, "landing_reuse": not args.no_landing_reuse, "action_dtype": args.action_dtype,
                 "state_format": args.state_format, "observation_dtype": "int16" if args.int16_obs else "int32",
                 "build_id": _native.build_id(), "ranks": dist.world_size(), "rccl_ranks": dist.rccl_ranks(),
                 "dist_backend": dist.backend_name(), "dist_note": (dist.fallback_note() or "")[:120],
@@ -1180,6 +1225,7 @@ def main():
         if configs:
             # every BASELINE config and k-frame launch: the figures README / DESIGN 6 quote, one scalar each
             for prefix, key in (("cfg2", "cfg2"), ("cfg3", "cfg3"), ("cfg3_compute", "cfg3_compute"), ("cfg5", "cfg5"),
+                                ("cfg3_power_hit", "cfg3_power_hit"),
                                 ("n524288", "int32_524288"), ("packed", "packed_headline"), ("packed_cfg3", "packed_cfg3"),
                                 ("packed_524288", "packed_524288"), ("int16obs", "int16obs_headline"),
                                 ("packed_int16obs", "packed_int16obs_headline"),
@@ -1191,6 +1237,15 @@ def main():
                 put(key, configs.get(key), us_key="us_per_frame", what=("frac", "frac_traffic", "frac_of_pure_stores"))
             if "cfg3" in configs:
                 roof["flight_tables_build_ms_once"] = round(configs["cfg3"]["flight_tables"]["build_ms_once_per_device"], 2)
+                # config 3 in the three table modes (flight_tables= of the env) and what each costs in device memory
+                for mode, key in (("both", "cfg3"), ("power_hit", "cfg3_power_hit"), ("none", "cfg3_compute")):
+                    roof[f"cfg3_tables_{mode}_us"] = round(configs[key]["launch_us"], 4)
+                    roof[f"cfg3_tables_{mode}_every_frame_us"] = round(configs[key + "_every_frame"]["launch_us"], 4)
+                roof["flight_tables_bytes_both"] = configs["cfg3"]["flight_tables"]["bytes"]
+                roof["flight_tables_bytes_power_hit"] = configs["cfg3"]["flight_tables"]["bytes_power_hit_only"]
+            for name in ("api_int32", "api_int64"):
+                if name in configs:
+                    roof[f"{name}_us"] = round(configs[name]["launch_us"], 4)
             verdicts = [v.get("parity_bit_exact") for v in configs.values() if "parity_bit_exact" in v]
             roof["configs_parity_checked"] = len(verdicts)
             roof["configs_parity_all_bit_exact"] = bool(verdicts) and all(verdicts)

@@ -19,8 +19,9 @@
  *    cfg->packed_state, the bit-packed format below (36 bytes per game instead of 176);
  *  - observations are int32[n][35] row-major per agent (pikazoo_env.py:576-624), or float32 / int16 rows as
  *    cfg->normalize_obs names;
- *  - out-of-range actions are undefined behaviour here (the reference raises IndexError at
- *    pikazoo_env.py:182); the Python host validates them unless told not to.
+ *  - actions are int32 / int64 / uint8 / int16 vectors as cfg->action_format names (what the caller's policy
+ *    produced: nothing is cast on the way in); an action outside the range is counted into cfg->action_faults on its
+ *    FULL value (the reference raises IndexError at pikazoo_env.py:182), see pz_config.
  */
 #ifndef PIKAZOO_HIP_H
 #define PIKAZOO_HIP_H
@@ -31,9 +32,13 @@
 extern "C" {
 #endif
 
-/* 9: the diagnostics pz_probe_launch / pz_selftest_predictor left this library (include/pikazoo_diag.h,
- *    libpikazoo_diag.so); every other entry point and pz_config are ABI 8's */
-#define PZ_ABI_VERSION 9
+/* 10: pz_config grows to 128 bytes: landing_fresh (the per-game "the stored landing point belongs to the stored ball"
+ *     bytes that let a launch skip the computer player's landing prediction along a free flight) and action_format
+ *     (int64 / uint8 / int16 action vectors straight into the launch, range-checked on the full value); the landing
+ *     table of pz_flight_tables is optional on its own (power_hit alone is a supported mode).
+ *  9: the diagnostics pz_probe_launch / pz_selftest_predictor left this library (include/pikazoo_diag.h,
+ *     libpikazoo_diag.so) */
+#define PZ_ABI_VERSION 10
 #define PZ_STATE_WORDS 44
 #define PZ_OBS_DIM 35
 
@@ -61,6 +66,12 @@ enum pz_env_field {
 
 enum pz_serve_mode { PZ_SERVE_WINNER = 0, PZ_SERVE_ALTERNATE = 1, PZ_SERVE_RANDOM = 2 };
 
+/* element type of the action vectors (pz_config.action_format).  The reference indexes a Python list with whatever
+ * integer it is handed (pikazoo_env.py:182); torch's default integer dtype is int64 (argmax, multinomial,
+ * Categorical.sample, randint), small policies emit uint8 / int16.  The launch loads the element as it is and checks
+ * the FULL value against [0, n_actions): an int64 of 2**32 + 3 or -1 is a fault, never action 3. */
+enum pz_action_format { PZ_ACT_I32 = 0, PZ_ACT_I64 = 1, PZ_ACT_U8 = 2, PZ_ACT_I16 = 3 };
+
 enum pz_error {
     PZ_OK = 0,
     PZ_E_NULL = -1,       /* a required pointer is NULL */
@@ -72,8 +83,8 @@ enum pz_error {
 /* Constructor kwargs of pikazoo_v0.env (pikazoo_env.py:79-86) + the fused wrappers
  * (wrappers/simplify_action.py, reward_by_ball_position.py, reward_in_normal_state.py,
  * normalize_observation.py, record_episode_statistics.py) + the batched-env additions
- * (auto_reset, seed, env_id_base, action_faults). POD, 112 bytes, passed by pointer from the host and by
- * value to the kernels.
+ * (auto_reset, seed, env_id_base, action_faults, landing_fresh, action_format). POD, 128 bytes, passed by pointer
+ * from the host and by value to the kernels.
  *
  * Reward pipeline of one frame, in the order the reference's wrapper stack would apply it:
  *   r = +1/-1/0 (pikazoo_env.py:217-228)
@@ -116,6 +127,22 @@ typedef struct pz_config {
                                      shifts bit tables): that game's input for the frame is undefined, no memory is
                                      touched out of bounds, every other game is unaffected.  With NULL nothing is
                                      checked (the range is then the caller's contract, as in ABI 7). */
+    uint8_t *landing_fresh;       /* NULL, or `stride` bytes of device memory owned by the caller, one per game: non-zero =
+                                     "ball.expected_landing_point_x of the stored state IS the landing prediction of the
+                                     stored ball".  The reference recomputes that prediction on every frame with a computer
+                                     player (physics.py:314-315) although a ball keeps its landing point along a free flight
+                                     (pz_physics.hpp: flight_keeps_landing_point; tests/flight_rule.c checks the statement on
+                                     every ball of the landing table's domain); a launch that finds the byte set takes the
+                                     stored value instead of a table look-up / a prediction loop -- the 44 state words it
+                                     leaves are the reference's bit for bit either way.  Maintained by the library: every
+                                     step launch with a computer player sets / clears the bytes of the games it stepped,
+                                     pz_init and pz_reset clear the games they touch.  The CALLER clears it (hipMemsetAsync)
+                                     after anything else wrote the state: its own writes, pz_unpack_state into it, a step
+                                     launch under a configuration WITHOUT a computer player (those launches neither read nor
+                                     write it).  NULL = every frame predicts, as in ABI 9. */
+    int32_t action_format;        /* enum pz_action_format: element type of act_p1 / act_p2 (pz_step, pz_step_bound) and of
+                                     the tape of pz_step_many (PZ_ACT_I32 or PZ_ACT_I64 there) */
+    int32_t reserved0;            /* 0 */
 } pz_config;
 
 /* ---- the packed state format (cfg->packed_state = 1) -----------------------------------------------
@@ -186,8 +213,10 @@ int64_t pz_probe_frame_bytes(void);   /* = 1024 * 8960 */
 #define PZ_FT_YV_MAX 96
 #define PZ_FT_HIT_YV_MAX 64
 typedef struct pz_flight_tables {
-    const uint16_t *landing;     /* pz_flight_table_bytes(0) bytes (the entries + 2 bytes of padding), 4-byte aligned, or NULL */
-    const uint16_t *power_hit;   /* pz_flight_table_bytes(1) bytes, 16-byte aligned, or NULL */
+    const uint16_t *landing;     /* pz_flight_table_bytes(0) bytes (the entries + 2 bytes of padding: 927 MB), 4-byte
+                                    aligned, or NULL: the landing point is then predicted in the kernel (closed-form
+                                    fast-forward; with cfg->landing_fresh only on the frames that interrupt a flight) */
+    const uint16_t *power_hit;   /* pz_flight_table_bytes(1) bytes (82 MB), 16-byte aligned, or NULL */
 } pz_flight_tables;
 int64_t pz_flight_table_bytes(int32_t which);   /* 0: landing, 1: power_hit */
 int pz_build_flight_tables(uint16_t *landing, uint16_t *power_hit, void *stream);
@@ -219,7 +248,7 @@ int pz_observe(const int32_t *state, int64_t n, int64_t stride, int32_t normaliz
                int32_t *obs_p1, int32_t *obs_p2, void *stream);
 
 /* ---- raw_env.step : pikazoo_env.py:175-240 (one frame of every game, one launch) ---------
- * act_p1/act_p2: int32[n] in [0,18) (or [0,13) with simplify_action).
+ * act_p1/act_p2: [n] elements of cfg->action_format (int32 by default) in [0,18) (or [0,13) with simplify_action).
  * rew_p1/rew_p2: int32[n] (+1/-1/0), or float32[n] when cfg->ballpos_reward or cfg->normal_state_mode.
  * terminated:    uint8[n] = game_ended after this frame (terminations of both agents);
  *                truncations are always False in the reference (:234) and are not written.
@@ -232,7 +261,7 @@ int pz_observe(const int32_t *state, int64_t n, int64_t stride, int32_t normaliz
  * With cfg->normalize_obs == 1 the observation buffers receive float32 bit patterns, with 2 int16 rows.
  * tables: NULL, or the flight look-up tables above (used when a player is the computer). */
 int pz_step(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
-            const int32_t *act_p1, const int32_t *act_p2,
+            const void *act_p1, const void *act_p2,
             int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
             uint8_t *terminated, void *episode_stats, const pz_flight_tables *tables,
             void *stream);
@@ -249,7 +278,7 @@ int64_t pz_step_bound_bytes(void);
 int pz_step_bind(void *bound, int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
                  int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
                  uint8_t *terminated, void *episode_stats, const pz_flight_tables *tables);
-int pz_step_bound(const void *bound, const int32_t *act_p1, const int32_t *act_p2, void *stream);
+int pz_step_bound(const void *bound, const void *act_p1, const void *act_p2, void *stream);
 
 /* ---- the same frame with the uniform random policy drawn on device ----------------------
  * actions of game g at step t come from Philox4x32-10(key=action_seed,
@@ -279,11 +308,12 @@ int pz_rollout_random(int32_t *state, int64_t n, int64_t stride, const pz_config
                       const pz_flight_tables *tables, void *stream);
 
 /* ---- k frames of GIVEN actions in one launch, every frame's outputs kept -------------------
- * actions: int32[k][2][n] (frame, agent, game) -- e.g. a recorded action tape or an open-loop
- * plan; outputs as in pz_rollout_random.  Identical to k calls of pz_step on the k slices.
+ * actions: int32[k][2][n] (frame, agent, game), or int64[k][2][n] with cfg->action_format = PZ_ACT_I64 (the other
+ * formats: PZ_E_CONFIG -- widen a uint8 / int16 tape to int32 first, which cannot wrap) -- e.g. a recorded action tape
+ * or an open-loop plan; outputs as in pz_rollout_random.  Identical to k calls of pz_step on the k slices.
  * n must be a multiple of 4 when k > 1. */
 int pz_step_many(int32_t *state, int64_t n, int64_t stride, const pz_config *cfg,
-                 const int32_t *actions, int32_t k,
+                 const void *actions, int32_t k,
                  int32_t *obs_p1, int32_t *obs_p2, void *rew_p1, void *rew_p2,
                  uint8_t *terminated, void *episode_stats, int64_t *episodes_done,
                  const pz_flight_tables *tables, void *stream);

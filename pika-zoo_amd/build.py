@@ -25,11 +25,11 @@ LIB = LIB_DIR / "libpikazoo_hip.so"
 DIAG_LIB = LIB_DIR / "libpikazoo_diag.so"
 SOURCES = [CSRC / "pz_kernels.hip"]
 DIAG_SOURCES = [CSRC / "pz_diag.hip"]
-DEPS = SOURCES + DIAG_SOURCES + [CSRC / "pz_physics.hpp", CSRC / "pz_packed.hpp", CSRC / "pz_memory.hpp",
+DEPS = SOURCES + DIAG_SOURCES + [CSRC / "pz_physics.hpp", CSRC / "pz_packed.hpp", CSRC / "pz_memory.hpp", CSRC / "pz_diagnostic.hpp",
                                  INCLUDE / "pikazoo_hip.h", INCLUDE / "pikazoo_diag.h"]
 ARCH = "gfx950"
-# the step kernels' five leading arguments (10 dwords) are preloaded into SGPRs at wave launch (pz_kernels.hip: HotArgs)
-FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-mllvm", "-amdgpu-kernarg-preload-count=10"]
+# the step kernels' six leading arguments (11 dwords) are preloaded into SGPRs at wave launch (pz_kernels.hip: HotArgs)
+FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-mllvm", "-amdgpu-kernarg-preload-count=11"]
 
 
 def hipcc_path() -> str:
@@ -42,7 +42,7 @@ def hipcc_path() -> str:
 def source_id(extra_flags=()) -> str:
     """Digest of the sources and compiler flags the library is built from; baked into the library as
     ``pz_build_id()`` so that a stale prebuilt .so (git-ignored, but shipped to the GPU box) is never run.
-    `extra_flags` are part of it: a diagnostic variant (``-DPZ_ABLATE`` ...) written to the product path carries
+    `extra_flags` are part of it: a variant compiled with other flags and copied to the product path carries
     another id than the product and is refused by ``_native.load()`` / rebuilt by ``needs_build()``."""
     h = hashlib.sha256()
     for d in DEPS:
@@ -85,6 +85,10 @@ def _compile(out: Path, sources, extra_flags, verbose: bool) -> None:
 
 def build(force: bool = False, verbose: bool = False, extra_flags=()) -> Path:
     """The product library (returned) and the diagnostics library beside it (a few seconds)."""
+    if any("PZ_DIAGNOSTIC_BUILD" in f for f in extra_flags):
+        # csrc/pz_diagnostic.hpp: the one compile-time switch of the kernels -- tools/ab.py builds such variants into
+        # tools/bin/; the product path never holds one (and _native.load() would refuse its build id "diagnostic")
+        raise ValueError("a diagnostic build (-DPZ_DIAGNOSTIC_BUILD) is never written to the product library's path")
     want = source_id(tuple(extra_flags))
     LIB_DIR.mkdir(parents=True, exist_ok=True)
     if force or extra_flags or library_id(DIAG_LIB) != want:

@@ -120,10 +120,10 @@ __global__ __launch_bounds__(2 * kLanes) void probe_launch_kernel(ProbeLaunchArg
     acc ^= other;
     if (WHAT >= 2) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) __builtin_amdgcn_raw_buffer_store_b32(acc + c, st, voff, (uint32_t)(first + c) * pitch, PZ_STATE_AUX);
+        for (int c = 0; c < 6; ++c) __builtin_amdgcn_raw_buffer_store_b32(acc + c, st, voff, (uint32_t)(first + c) * pitch, kStateAux);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            __builtin_amdgcn_raw_buffer_store_b32(acc + 7 + c, st, voff, (uint32_t)(26 + role * 4 + c) * pitch, PZ_STATE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(acc + 7 + c, st, voff, (uint32_t)(26 + role * 4 + c) * pitch, kStateAux);
         __builtin_amdgcn_raw_buffer_store_b32(acc, make_rsrc(role == 0 ? a.rew1 : a.rew2, n32 * 4u), voff, 0, 0);
         int32_t* rows = lds_obs[role];
 #pragma unroll

@@ -31,27 +31,27 @@
 
 namespace pz {
 
-// cache-policy knobs of the k-frame launches (aux operand: 1 = sc0, 2 = nt, 16 = sc1; pz_memory.hpp has the single-frame ones)
-#ifndef PZ_HH_ROLLOUT_GENERIC
-#define PZ_HH_ROLLOUT_GENERIC 1  // launch_step_players: the human-vs-human rollout keeps its generic kernel (measured)
-#endif
-#ifndef PZ_EARLY_OWN_STORES
-#define PZ_EARLY_OWN_STORES 2  // pair_body: what the human player's wave stores in front of the exchange barrier (0: nothing)
-#endif
-#ifndef PZ_TRAJ_AUX
+// ---- measured choices (closed experiments: the value and its one-line result; logs under profiles/) -----------------
+// cache policies of the k-frame launches (aux operand: 1 = sc0, 2 = nt, 16 = sc1; pz_memory.hpp has the single-frame ones)
 // The k-frame launches' observation rows (623 MB per 32-frame launch): sc0 sc1 nt.  With a computer player, rows written
 // `nt` alone (the single-frame launches' policy) push the flight tables' hot lines out of the caches and the look-ups
 // come from HBM: pz_rollout_random, k = 32, interleaved on one box: nt 3.21-3.25 us per frame, sc1 nt 3.13-3.15,
 // sc0 sc1 nt 3.12-3.14 (plain 4.2, sc1 alone 4.3); human vs human 2.83 / 2.82 / 2.82.  A single-frame launch keeps
 // `nt` (sc1 nt: 6.99 -> 7.08 us; with a computer player 8.87 -> 8.82).
-#define PZ_TRAJ_AUX 19
-#endif
-#ifndef PZ_TRAJ_SMALL_AUX_AI
-#define PZ_TRAJ_SMALL_AUX_AI 18
-#endif
+constexpr int kTrajAux = 19;
 // the k-frame launches' rewards / flags / actions (17 of a game-step's 297 bytes): sc1 nt where the launch gathers
 // from the flight tables (3.13 -> 3.11 us per frame, k = 128: 2.99 -> 2.94), plain otherwise (nt: 2.81 -> 2.94)
-constexpr int traj_small_aux(bool computer_player) { return computer_player ? PZ_TRAJ_SMALL_AUX_AI : 0; }
+constexpr int traj_small_aux(bool computer_player) { return computer_player ? 18 : 0; }
+// launch_step_players: the human-vs-human rollout on one wave keeps its generic kernel -- it runs at the write ceiling of
+// its two tensors either way and its leaner PLAIN form measured 0.6-3.4 % slower (profiles/r04_experiments/ab_rollout_hh_*)
+constexpr bool kHhRolloutGeneric = true;
+// launch_step: which human-vs-human k-frame launches run on two waves per 64 games: 1 = those on int16 rows (2.47 -> 2.23 us
+// per frame), 2 = all (3.62 vs 3.63 on one wave: no gain; profiles/r03_experiments/)
+constexpr int kHhPairRollout = 1;
+// pair_body: what the human player's wave of a one-computer launch stores in front of the exchange barrier: 2 = its own
+// player's columns and the ball's position / trail / rotation (8.62 -> 8.46 us per launch behind the LDS hand-shake,
+// profiles/r05_experiments/ab_early_store_edge_*.log); 0 = nothing
+constexpr int kEarlyOwnStores = diag::kNoEarlyStores ? 0 : 2;
 
 
 // One game's column accessor: wave-uniform descriptor + column pitch, per-lane byte offset.
@@ -65,7 +65,7 @@ struct StateIO {
     }
     __device__ __forceinline__ void st(int col, int v) const
     {
-        __builtin_amdgcn_raw_buffer_store_b32((unsigned int)v, rsrc, voff, (uint32_t)col * pitch, PZ_STATE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned int)v, rsrc, voff, (uint32_t)col * pitch, kStateAux);
     }
 };
 
@@ -77,16 +77,16 @@ struct PackedIO {
     __device__ __forceinline__ pk_u32x4 ld_a() const { return __builtin_amdgcn_raw_buffer_load_b128(a, v16, 0, 0); }
     __device__ __forceinline__ pk_u32x4 ld_b() const { return __builtin_amdgcn_raw_buffer_load_b128(b, v16, 0, 0); }
     __device__ __forceinline__ uint32_t ld_tail() const { return __builtin_amdgcn_raw_buffer_load_b32(tail, v4, 0, 0); }
-    __device__ __forceinline__ void st_a(pk_u32x4 w) const { __builtin_amdgcn_raw_buffer_store_b128(w, a, v16, 0, PZ_STATE_AUX); }
-    __device__ __forceinline__ void st_b(pk_u32x4 w) const { __builtin_amdgcn_raw_buffer_store_b128(w, b, v16, 0, PZ_STATE_AUX); }
-    __device__ __forceinline__ void st_tail(uint32_t w) const { __builtin_amdgcn_raw_buffer_store_b32(w, tail, v4, 0, PZ_STATE_AUX); }
+    __device__ __forceinline__ void st_a(pk_u32x4 w) const { __builtin_amdgcn_raw_buffer_store_b128(w, a, v16, 0, kStateAux); }
+    __device__ __forceinline__ void st_b(pk_u32x4 w) const { __builtin_amdgcn_raw_buffer_store_b128(w, b, v16, 0, kStateAux); }
+    __device__ __forceinline__ void st_tail(uint32_t w) const { __builtin_amdgcn_raw_buffer_store_b32(w, tail, v4, 0, kStateAux); }
     __device__ __forceinline__ void st_ex(int ex) const
     {
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ex, tail, v4, 0, PZ_STATE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ex, tail, v4, 0, kStateAux);
     }
     __device__ __forceinline__ void st_bold(int player, int bold) const  // player 0 / 1
     {
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bold, tail, v4 + 2u + (uint32_t)player, 0, PZ_STATE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bold, tail, v4 + 2u + (uint32_t)player, 0, kStateAux);
     }
 };
 
@@ -98,24 +98,26 @@ __device__ __forceinline__ PackedIO make_packed_io(const void* packed, int64_t s
                     (uint32_t)lane_index * 16u, (uint32_t)lane_index * 4u};
 }
 
-// What the first loads of a wave depend on.  The step kernels take these five as leading scalar kernel
-// arguments (and everything, again, in StepArgs): the build preloads the first 10 argument dwords into
-// SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=10), so the state loads do not have to wait
-// for a scalar load from the kernarg segment first (pair kernel: 7.51 -> 7.33 us per launch).
+// What the first loads of a wave depend on.  The step kernels take these six as leading scalar kernel
+// arguments (and everything, again, in StepArgs): the build preloads the first 11 argument dwords into
+// SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=11), so the state loads do not have to wait
+// for a scalar load from the kernarg segment first (pair kernel: 7.51 -> 7.33 us per launch).  The action
+// vectors' element type is one of them: the wave branches on it in front of its very first loads.
 struct HotArgs {
     int32_t* state;
     int64_t n, stride;
-    const int32_t* act_p1;
-    const int32_t* act_p2;
+    const void* act_p1;  // elements of act_format
+    const void* act_p2;
+    int32_t act_format;  // = cfg.action_format (enum pz_action_format)
 };
-#define PZ_HOT_PARAMS int32_t *state, int64_t n, int64_t stride, const int32_t *act_p1, const int32_t *act_p2
-#define PZ_HOT_ARGS(a) (a).state, (a).n, (a).stride, (a).act_p1, (a).act_p2
+#define PZ_HOT_PARAMS int32_t *state, int64_t n, int64_t stride, const void *act_p1, const void *act_p2, int32_t act_format
+#define PZ_HOT_ARGS(a) (a).state, (a).n, (a).stride, (a).act_p1, (a).act_p2, (a).cfg.action_format
 
 struct StepArgs {
     int32_t* state;
     int64_t n, stride;
-    const int32_t* act_p1;  // nullptr => on-device random policy
-    const int32_t* act_p2;
+    const void* act_p1;  // nullptr => on-device random policy; pz_step_many: the int32 tape
+    const void* act_p2;
     uint64_t action_seed, t0;
     int32_t k;  // frames per launch (random policy only)
     int32_t* act_out;  // trajectory mode only: int32[k][2][n] actions taken (may be nullptr)
@@ -303,6 +305,57 @@ __device__ __forceinline__ void store_game_packed(const Game& g, const PackedIO&
 // tape is parked as bytes), so the damage is that game's input for the frame.
 __device__ __forceinline__ uint32_t action_count(const pz_config& cfg) { return cfg.simplify_action ? 13u : 18u; }
 
+// Both agents' actions of game i, loaded as the caller holds them (pz_config.action_format: torch's default integer dtype
+// is int64 -- argmax, multinomial, Categorical.sample, randint -- and a cast kernel per agent in front of a 7 us launch
+// costs more than the launch's own loads; it also WRAPS, 2**32 + 3 -> 3, before any range check sees the value).  One
+// wave-uniform branch on the format, both loads inside it: nothing waits where the branch closes, the loads are in
+// flight under the state loads like the int32 ones.  `high`: the OR of what the 32-bit action words do not hold -- an
+// int64 element's upper dword; 0 in the other formats, whose widening (zero-extended uint8, sign-extended int16) keeps
+// an out-of-range value out of range.  Valid iff high == 0 and (uint32) action < n_actions.  Rows past n read as 0.
+typedef unsigned int act_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void load_actions(const void* p1, const void* p2, uint32_t n32, uint32_t i, int format, int& a1,
+                                             int& a2, uint32_t& high)
+{
+    high = 0u;
+    if (format == PZ_ACT_I64) {
+        const act_u32x2 w1 = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(p1, n32 * 8u), i * 8u, 0, 0);
+        const act_u32x2 w2 = __builtin_amdgcn_raw_buffer_load_b64(make_rsrc(p2, n32 * 8u), i * 8u, 0, 0);
+        a1 = (int)w1.x;
+        a2 = (int)w2.x;
+        high = w1.y | w2.y;
+    } else if (format == PZ_ACT_U8) {
+        a1 = (int)__builtin_amdgcn_raw_buffer_load_b8(make_rsrc(p1, n32), i, 0, 0);
+        a2 = (int)__builtin_amdgcn_raw_buffer_load_b8(make_rsrc(p2, n32), i, 0, 0);
+    } else if (format == PZ_ACT_I16) {
+        a1 = (int)(short)__builtin_amdgcn_raw_buffer_load_b16(make_rsrc(p1, n32 * 2u), i * 2u, 0, 0);
+        a2 = (int)(short)__builtin_amdgcn_raw_buffer_load_b16(make_rsrc(p2, n32 * 2u), i * 2u, 0, 0);
+    } else {
+        a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(p1, n32 * 4u), i * 4u, 0, 0);
+        a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(p2, n32 * 4u), i * 4u, 0, 0);
+    }
+}
+__device__ __forceinline__ bool actions_out_of_range(const pz_config& cfg, int a1, int a2, uint32_t high)
+{
+    return (high != 0u) | ((uint32_t)a1 >= action_count(cfg)) | ((uint32_t)a2 >= action_count(cfg));
+}
+
+// pz_config.landing_fresh: one byte per game, "the stored expected_landing_point_x is the landing point of the stored
+// ball" (pz_physics.hpp: a ball keeps its landing point along a free flight).  NULL: an empty descriptor -- the byte
+// reads as 0 (every frame predicts), the store is dropped; games past n likewise.
+struct FreshIO {
+    Rsrc rsrc;
+    uint32_t at;
+    __device__ __forceinline__ bool ld() const { return __builtin_amdgcn_raw_buffer_load_b8(rsrc, at, 0, 0) != 0; }
+    __device__ __forceinline__ void st(bool fresh) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)fresh, rsrc, at, 0, 0);
+    }
+};
+__device__ __forceinline__ FreshIO make_fresh_io(const pz_config& cfg, int64_t n, int64_t i)
+{
+    return FreshIO{make_rsrc(cfg.landing_fresh, cfg.landing_fresh != nullptr ? (uint32_t)n : 0u), (uint32_t)i};
+}
+
 __device__ __forceinline__ void count_action_faults(const pz_config& cfg, bool bad)
 {
     if (cfg.action_faults == nullptr) return;                  // wave-uniform (a kernel argument)
@@ -435,7 +488,7 @@ __device__ __forceinline__ void flush_rows16(const int32_t* __restrict__ lds, co
             const u32x4 lo = src4[2 * v], hi = src4[2 * v + 1];
             const u32x4 out = {(lo.x & 0xFFFFu) | (lo.y << 16), (lo.z & 0xFFFFu) | (lo.w << 16),
                                (hi.x & 0xFFFFu) | (hi.y << 16), (hi.z & 0xFFFFu) | (hi.w << 16)};
-            __builtin_amdgcn_raw_buffer_store_b128(out, span, (uint32_t)v * 16u, 0, PZ_OBS_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(out, span, (uint32_t)v * 16u, 0, kObsAux);
         }
     }
 }
@@ -452,44 +505,6 @@ __device__ __forceinline__ void flush_obs(const int32_t* __restrict__ lds, void*
         flush_rows(lds, static_cast<char*>(tensor) + t * n * kRowBytes, (uint32_t)n * kRowBytes, lane);
     }
 }
-
-#ifdef PZ_STAMPS
-// Diagnostic build only (tools/stamps.py): per-wave timeline of one launch in 100 MHz ticks.
-__device__ unsigned long long g_pz_stamps[8192 * 8];
-#define PZ_STAMP(k)                                                                        \
-    do {                                                                                   \
-        if (blockIdx.x < 8192 && threadIdx.x == 0) {                                        \
-            unsigned long long t_;                                                         \
-            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
-            g_pz_stamps[blockIdx.x * 8 + (k)] = t_;                                         \
-        }                                                                                  \
-    } while (0)
-#define PZ_DRAIN_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-// the pair kernel: lane 0 of BOTH waves, slot 2 * workgroup + role
-#define PZ_PAIR_STAMP(role, k)                                                             \
-    do {                                                                                   \
-        if (blockIdx.x < 4096 && lane == 0) {                                              \
-            unsigned long long t_;                                                         \
-            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
-            g_pz_stamps[(blockIdx.x * 2 + (role)) * 8 + (k)] = t_;                          \
-        }                                                                                  \
-    } while (0)
-// where the wave runs: HW_ID (wave / SIMD / CU / SE) and XCC_ID in slot 7
-#define PZ_PAIR_WHERE(role)                                                                                   \
-    do {                                                                                                      \
-        if (blockIdx.x < 4096 && lane == 0) {                                                                 \
-            unsigned int hw_, xcc_;                                                                           \
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)"      \
-                         : "=s"(hw_), "=s"(xcc_));                                                            \
-            g_pz_stamps[(blockIdx.x * 2 + (role)) * 8 + 7] = ((unsigned long long)xcc_ << 32) | hw_;          \
-        }                                                                                                     \
-    } while (0)
-#else
-#define PZ_STAMP(k)
-#define PZ_DRAIN_VMEM()
-#define PZ_PAIR_STAMP(role, k)
-#define PZ_PAIR_WHERE(role)
-#endif
 
 // PLAIN launches (k-frame kernels): no fused wrapper, no episode statistics, raw integer rows.  The configuration words
 // of those features then read as compile-time constants, and their branches -- with the scalars and lane masks the
@@ -522,19 +537,11 @@ __device__ __forceinline__ StepArgs effective_args(const StepArgs& in)
 //                    (pz_step_many), parked in LDS one byte per action, 64 frames per fetch.
 // SPARSE: changed-only write-back of the rarely changing columns (large batches).
 enum StepMode { kActions = 0, kRandom = 1, kRollout = 2, kTape = 3 };
-#ifndef PZ_TAPE_WAVES
-#define PZ_TAPE_WAVES 8
-#endif
-#ifndef PZ_TAPE_CHUNK
-#define PZ_TAPE_CHUNK 64
-#endif
-// pz_step_many parks its action tape in LDS, ONE BYTE per action (an action is < 18; out-of-range actions are undefined
-// behaviour in the C ABI, include/pikazoo_hip.h): kTapeChunk frames of both players for a wave's 64 games are 8 KB.
-constexpr int kTapeChunk = PZ_TAPE_CHUNK;            // frames of the action tape fetched at once by pz_step_many
+// pz_step_many parks its action tape in LDS, ONE BYTE per action (an action is < 18; an out-of-range one was counted
+// while it was parked, include/pikazoo_hip.h): kTapeChunk frames of both players for a wave's 64 games are 8 KB.
+constexpr int kTapeChunk = 64;                       // frames of the action tape fetched at once by pz_step_many (16: 3.88 vs 3.27 us per frame)
 constexpr int kTapeWords = kTapeChunk * 2 * kLanes / 4;  // the parked chunk in int32 words of LDS
-#ifndef PZ_TAPE_AUX
-#define PZ_TAPE_AUX 18  // sc1 nt: a cold tape streamed with the default policy pushes the flight tables' hot lines out of the caches
-#endif
+constexpr int kTapeAux = 18;  // sc1 nt: a cold tape streamed with the default policy pushes the flight tables' hot lines out of the caches
 constexpr int kTapeBatch = 16;                        // tape rows requested together by a refill inside the frame loop (= kTapeGroup)
 
 // Rows [s0 + f0, s0 + f0 + B) of the tape for the players asked for: ALL the loads are in flight before the first one is
@@ -560,8 +567,8 @@ __device__ __forceinline__ bool park_tape_rows(const int32_t* tape0, int64_t n, 
         uint32_t o1 = voff, o2 = voff + n32 * 4u;
 #pragma unroll
         for (int j = 0; j < kTapeGroup; ++j) {
-            v1[h + j] = P1 ? (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rows, o1, 0, PZ_TAPE_AUX) : 0;
-            v2[h + j] = P2 ? (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rows, o2, 0, PZ_TAPE_AUX) : 0;
+            v1[h + j] = P1 ? (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rows, o1, 0, kTapeAux) : 0;
+            v2[h + j] = P2 ? (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rows, o2, 0, kTapeAux) : 0;
             o1 += n32 * 8u;
             o2 += n32 * 8u;
         }
@@ -838,10 +845,10 @@ struct TrajOut {
             // (the two tensors' pieces alternating, or every other workgroup writing player 2's tensor first: the same)
 #pragma unroll
             for (int pass = 0; pass < 9; ++pass)
-                __builtin_amdgcn_raw_buffer_store_b128(p1[pass], s1, piece_off[pass], 0, PZ_TRAJ_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(p1[pass], s1, piece_off[pass], 0, kTrajAux);
 #pragma unroll
             for (int pass = 0; pass < 9; ++pass)
-                __builtin_amdgcn_raw_buffer_store_b128(p2[pass], s2, piece_off[pass], 0, PZ_TRAJ_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(p2[pass], s2, piece_off[pass], 0, kTrajAux);
         }
     }
     // one tensor's pieces requested from LDS at once (36 VGPRs), `between()`, their stores back to back
@@ -862,7 +869,7 @@ struct TrajOut {
             for (int pass = 0; pass < 5; ++pass) {
                 const u32x4 w = {(lo[pass].x & 0xFFFFu) | (lo[pass].y << 16), (lo[pass].z & 0xFFFFu) | (lo[pass].w << 16),
                                  (hi[pass].x & 0xFFFFu) | (hi[pass].y << 16), (hi[pass].z & 0xFFFFu) | (hi[pass].w << 16)};
-                __builtin_amdgcn_raw_buffer_store_b128(w, span, piece_off[pass], 0, PZ_TRAJ_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(w, span, piece_off[pass], 0, kTrajAux);
             }
         } else {
             u32x4 piece[9];
@@ -872,7 +879,7 @@ struct TrajOut {
             const Rsrc span = make_rsrc(slab, obs_span_bytes);
 #pragma unroll
             for (int pass = 0; pass < 9; ++pass)
-                __builtin_amdgcn_raw_buffer_store_b128(piece[pass], span, piece_off[pass], 0, PZ_TRAJ_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(piece[pass], span, piece_off[pass], 0, kTrajAux);
         }
     }
     static constexpr int kStores = OBS16 ? 10 : 18;  // row stores per frame
@@ -956,7 +963,7 @@ __device__ __forceinline__ void scout_candidates_posted(const int32_t* __restric
     }
 }
 
-// SCOUT (launches with a computer player, below PZ_TWO_WAVE_MAX_LANES games): the workgroup has a
+// SCOUT (launches with a computer player, below kTwoWaveMaxLanes games): the workgroup has a
 // second wave for the flight predictions that can run beside the frame -- kScoutLoads for the single
 // frame of pz_step (scout_candidates, scout_landing_after_hits), kScoutPosted for the k-frame modes
 // (scout_candidates_posted).  The scout executes exactly the workgroup barriers of the main wave.
@@ -966,18 +973,16 @@ __device__ __forceinline__ void scout_candidates_posted(const int32_t* __restric
 // tools/ab.py, us per frame at k = 32): the rollout of the on-device policy is at its best told that one wave per
 // SIMD is all there will be (4.23 vs 4.27 with a computer player), the tape kernel -- same register count either way
 // -- left alone (3.63 vs 3.96); with a scout wave two waves per SIMD must fit.
-#ifndef PZ_TRAJ_WAVES
-#define PZ_TRAJ_WAVES 1
-#endif
+constexpr int kTrajWaves = 1, kTapeWaves = 8;
 template <bool AI1, bool AI2, int MODE, bool SPARSE, int SCOUT = kNoScout, bool PACKED = false, bool OBS16 = false,
           bool PLAIN = false>
 __global__ __launch_bounds__(SCOUT != kNoScout ? 2 * kLanes : kLanes)
 __attribute__((amdgpu_waves_per_eu((MODE == kRollout || MODE == kTape) && SCOUT != kNoScout ? 2 : 1,
-                                   MODE == kRollout ? (SCOUT != kNoScout ? 2 : PZ_TRAJ_WAVES) : (MODE == kTape && SCOUT != kNoScout ? 2 : (MODE == kTape ? PZ_TAPE_WAVES : 8)))))
+                                   MODE == kRollout ? (SCOUT != kNoScout ? 2 : kTrajWaves) : (MODE == kTape && SCOUT != kNoScout ? 2 : (MODE == kTape ? kTapeWaves : 8)))))
 void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
 {
     const StepArgs a = effective_args<PLAIN, OBS16>(args);
-    const HotArgs hot{state, n, stride, act_p1, act_p2};
+    const HotArgs hot{state, n, stride, act_p1, act_p2, act_format};
     static_assert(!PACKED || (SCOUT == kNoScout && !SPARSE), "the packed format has no scout and no changed-only variant");
     static_assert(!OBS16 || MODE == kRollout || MODE == kTape, "the single-frame launches take the row format at run time");
     static_assert(SCOUT == kNoScout || ((AI1 || AI2) && (MODE == kActions) == (SCOUT == kScoutLoads)),
@@ -1037,19 +1042,22 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
     unsigned int finished = 0;
     PZ_STAMP(0);
     int a1 = 0, a2 = 0;
-    if (MODE == kActions) {  // rows past n read as 0 through the range check
-        a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.voff, 0, 0);
-        a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.voff, 0, 0);
-    }
+    uint32_t act_high = 0u;
+    if (MODE == kActions) load_actions(hot.act_p1, hot.act_p2, n32, (uint32_t)i, hot.act_format, a1, a2, act_high);
     EpisodeStats st{0.0, 0.0, 0};
     PackedWords was{};
+    // a computer player's landing point: does the stored one belong to the stored ball? (pz_config.landing_fresh)
+    const bool reuse = (AI1 || AI2) && a.cfg.landing_fresh != nullptr;  // wave-uniform
+    bool ex_fresh = false;
     if (live) {
         if constexpr (PACKED)
             was = load_game_packed(g, pio, true);
         else
             load_game(g, io);
         if (with_stats) sio.load(st);
+        if (AI1 || AI2) ex_fresh = make_fresh_io(a.cfg, hot.n, i).ld();
     }
+    const bool fresh_loaded = MODE == kActions && ex_fresh;
     // pz_step_many: the tape is fetched kTapeChunk frames at a time and parked in LDS -- a per-frame global load would
     // put a full memory latency on every frame of a lone wave, and its wait (vmcnt is in-order) would also drain that
     // frame's stores; LDS reads only touch lgkmcnt.  The FIRST chunk is requested here, behind the state loads: its
@@ -1058,8 +1066,8 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
     unsigned char* const parked = reinterpret_cast<unsigned char*>(tape_lds);
     bool bad_action = false;
     auto fetch_tape_chunk = [&](int32_t s0, auto first) {
-        bad_action |= park_tape_chunk<decltype(first)::value, true, true>(a.act_p1, a.n, n32, a.k, s0, io.voff, parked, lane,
-                                                                          action_count(a.cfg));
+        bad_action |= park_tape_chunk<decltype(first)::value, true, true>(static_cast<const int32_t*>(a.act_p1), a.n, n32, a.k, s0,
+                                                                          io.voff, parked, lane, action_count(a.cfg));
         wave_lds_handover<SCOUT == kNoScout>();  // every lane reads back its own bytes only
     };
     if (MODE == kTape) fetch_tape_chunk(0, std::true_type{});
@@ -1093,7 +1101,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
         // first frame reads them -- inside the loop body, counting down to vmcnt(0) -- where on every later frame
         // those waits drain the previous frame's 18 row stores instead (and the gathers queued behind them).
         if (kTraj) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
-        FrameHead head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold);
+        FrameHead head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold, reuse, ex_fresh);
         // The compiler sizes the tail's wait for the head's gathers for the worst path into the loop: from here
         // nothing would follow them (vmcnt(0): every frame drains its predecessor's row stores after all), around the
         // back edge a frame's 18 row stores do.  Eighteen dropped stores make the two paths look alike: vmcnt(18).
@@ -1108,7 +1116,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
             const bool last_frame = s == a.k - 1;
             frozen = head.frozen;
             reward = frame_tail<AI1, AI2, SCOUT, false>(g, a.cfg, id, a1, a2, live, head, lds_obs[0], lane, lut, link,
-                                                        nullptr, last_frame);
+                                                        nullptr, last_frame, &ex_fresh);
             finished += (unsigned int)(live && g.e.game_ended && !frozen);
             rw = shape_rewards(a.cfg, g, reward, frozen, parked_zones);
             if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
@@ -1121,7 +1129,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
             auto next_head = [&]() {  // this frame's outputs are staged: the game may move on
                 if (s + 1 < a.k) {
                     resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
-                    head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold);
+                    head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold, reuse, ex_fresh);
                 }
             };
             if (kTraj) {
@@ -1141,7 +1149,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
     } else {
         const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
         reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane, lut,
-                                             ScoutLink{cand, hits, posts}, &ex_pending);
+                                             ScoutLink{cand, hits, posts}, &ex_pending, true, reuse, &ex_fresh);
         finished = (unsigned int)(live && g.e.game_ended && !frozen);
         rw = shape_rewards(a.cfg, g, reward, frozen);
         if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
@@ -1161,6 +1169,9 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
             store_game(g, back, ex_pending);
         }
         if (with_stats) sio.store(st);
+        // (a single frame changes it when a round ends / starts: rarely; behind a frame loop it is stored as it is, through
+        // a descriptor built here: nothing more is carried around the loop)
+        if ((AI1 || AI2) && (MODE != kActions || ex_fresh != fresh_loaded)) make_fresh_io(a.cfg, hot.n, i).st(ex_fresh);
     }
     if (MODE != kRollout && MODE != kTape) emit_outputs(a, g, rw, as_float, live, i, lane, 0, lds_obs);
     PZ_STAMP(5);
@@ -1168,7 +1179,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
     PZ_STAMP(6);
 
     // the launches that read actions: pz_step (a1 / a2 as loaded) and pz_step_many (noted while the tape was parked)
-    if (MODE == kActions) bad_action = (uint32_t)a1 >= action_count(a.cfg) || (uint32_t)a2 >= action_count(a.cfg);
+    if (MODE == kActions) bad_action = actions_out_of_range(a.cfg, a1, a2, act_high);
     if (MODE == kActions || MODE == kTape) count_action_faults(a.cfg, live && bad_action);
     if (a.episodes_done != nullptr) {
         // one atomic per wave: reduce the per-lane counts across the wavefront first
@@ -1179,7 +1190,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
 }
 
 // ---- the pair kernel: two waves per 64 games, split by player (see step_games_pair) ---------------
-// Used for single-frame launches below PZ_TWO_WAVE_MAX_LANES games: human-vs-human (the bench headline)
+// Used for single-frame launches below kTwoWaveMaxLanes games: human-vs-human (the bench headline)
 // and, when flight tables are passed, every computer-player configuration.  Wave ROLE loads/stores its own
 // player's 13 columns, its half of the ball columns (both waves load all 12), player 1's wave also the 6
 // env columns, the episode statistics and `terminated`; each wave writes its own agent's reward and
@@ -1234,10 +1245,10 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     // ~2 % the early stores gain, never different.  Interleaved A/B, config 3, us per launch (cold | hot tape): no early
     // stores 8.62 | 8.32, round 4's unordered early stores 8.43 | 8.15, with the hand-shake 8.46 | 8.19
     // (profiles/r05_experiments/ab_early_store_edge_*.log).  The edge itself, deterministically:
-    // -DPZ_DEV_DELAY_PARTNER_LOADS=2 holds the computer's wave back for ~16 000 cycles in front of its first load -- the
+    // a diagnostic build (pz_diagnostic.hpp, bits 8-15 = 2) holds the computer's wave back for ~16 000 cycles in front of its first load -- the
     // trajectory stays bit-exact with the hand-shake and breaks without it (early_store_edge_partner_held_back.log);
     // tests/test_cabi_and_host.py scans the shipped code object for the hand-shake's shape.
-    constexpr bool kOneComputer = PZ_EARLY_OWN_STORES != 0 && !PACKED && (AI1 != AI2);
+    constexpr bool kOneComputer = kEarlyOwnStores != 0 && !PACKED && (AI1 != AI2);
     constexpr int kHumanRole = AI1 ? 1 : 0;
     constexpr int kLoadsDoneAt = 2048;  // word of the human wave's exchange region (rows 0..1151 carry the exchange)
     constexpr int32_t kLoadsDone = 0x10ADD0E5;
@@ -1247,15 +1258,17 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     int32_t* const partner_loaded = xchg + kHumanRole * (kLanes * PZ_OBS_DIM) + kLoadsDoneAt;
     if (kOneComputer && !kOwnAI && lane == 0)
         __hip_atomic_store(partner_loaded, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef PZ_DEV_DELAY_PARTNER_LOADS  // (diagnostic builds only: see above)
-    if (kOneComputer && kOwnAI)
-        for (int nap = 0; nap < (PZ_DEV_DELAY_PARTNER_LOADS); ++nap) __builtin_amdgcn_s_sleep(127);
-#endif
-    int a1 = 0, a2 = 0;
-    if (!RANDOM) {
-        a1 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p1, n32 * 4u), io.voff, 0, 0);
-        a2 = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(hot.act_p2, n32 * 4u), io.voff, 0, 0);
+    if constexpr (diag::kDelayPartnerLoads != 0) {  // (diagnostic builds only: see above)
+        if (kOneComputer && kOwnAI)
+            for (int nap = 0; nap < diag::kDelayPartnerLoads; ++nap) __builtin_amdgcn_s_sleep(127);
     }
+    int a1 = 0, a2 = 0;
+    uint32_t act_high = 0u;
+    if (!RANDOM) load_actions(hot.act_p1, hot.act_p2, n32, (uint32_t)i, hot.act_format, a1, a2, act_high);
+    // a computer player's wave: does the stored landing point belong to the stored ball? (pz_config.landing_fresh)
+    const bool reuse = kOwnAI && a.cfg.landing_fresh != nullptr;  // wave-uniform
+    const FreshIO fio = make_fresh_io(a.cfg, kOwnAI ? hot.n : 0, i);
+    bool ex_fresh = false;
     EpisodeStats st{0.0, 0.0, 0};
     uint32_t sticky = 0;  // PACKED: the own group's overflow flag, kept
     if (PACKED && live) {
@@ -1266,6 +1279,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         unpack_tail(g, tail);
         sticky = (ROLE == 0 ? ga.y : gb.y) & kPackedOverflowBit;
         if (with_stats) sio.load(st);
+        if (kOwnAI) ex_fresh = fio.ld();
     }
     if (!PACKED && live) {
         g.e.round_ended = io.ld(PZ_E_ROUND_ENDED);
@@ -1284,7 +1298,10 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         g.b.ppx = io.ld(PZ_B_PREVIOUS_PREVIOUS_X);
         g.b.ppy = io.ld(PZ_B_PREVIOUS_PREVIOUS_Y);
         g.b.rot = io.ld(PZ_B_FINE_ROTATION);
-        if (kKeepsEx) g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);
+        if (kOwnAI) {  // (every computer's wave decides on it; the one of the last computer player keeps it: kKeepsEx)
+            g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);
+            ex_fresh = fio.ld();
+        }
         g.b.punch = io.ld(PZ_B_PUNCH_EFFECT_X);
         load_player(ROLE == 0 ? g.p1 : g.p2, io, kOwn);
         Player& other = ROLE == 0 ? g.p2 : g.p1;
@@ -1305,6 +1322,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     if (RANDOM)  // (issued behind the loads: the block runs while they are in flight)
         policy_actions(id.id_lo, id.id_hi, make_rolling_key(a.action_seed), a.t0, a.cfg.simplify_action ? 13u : 18u, a1, a2);
     const Game loaded = g;  // what the columns held before the frame
+    const bool fresh_loaded = ex_fresh;
     const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     bool frozen = false;
     PZ_DRAIN_VMEM();
@@ -1322,8 +1340,8 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     // computer's wave none of them (8.44 -> 8.40; hot tape 8.30 -> 8.17 -> 8.15: profiles/r04_experiments/).  (Letting the
     // human player's wave SLEEP 256 - 1 536 cycles before its frame, so that the computer's wave has the SIMD to itself
     // up to its gathers, changes nothing: 8.38 -> 8.40 - 8.42, and 8.57 when it sleeps past its slack.)
-    constexpr bool kEarlyBall = kEarlyOwn && PZ_EARLY_OWN_STORES >= 2;
-    constexpr bool kPartnerStoresBall = PZ_EARLY_OWN_STORES >= 2 && kOneComputer && kOwnAI;
+    constexpr bool kEarlyBall = kEarlyOwn && kEarlyOwnStores >= 2;
+    constexpr bool kPartnerStoresBall = kEarlyOwnStores >= 2 && kOneComputer && kOwnAI;
     bool stored_early = false;  // wave-uniform: the partner's loads were known to be back in front of the barrier
     auto store_ball_trail = [&]() {  // the human wave's seven ball columns (kEarlyBall): early, or behind the barrier
         io.st(PZ_B_X, g.b.x);
@@ -1336,13 +1354,13 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     };
     auto before_barrier = [&]() {
         if constexpr (kEarlyOwn) {
-#ifdef PZ_DEV_UNORDERED_EARLY_STORES  // (diagnostic builds only: round 4's form, no hand-shake)
-            stored_early = true;
-#else
-            asm volatile("" ::: "memory");  // (read here, in front of the barrier: as late as the stores allow)
-            stored_early = __builtin_amdgcn_readfirstlane(__hip_atomic_load(partner_loaded, __ATOMIC_RELAXED,
-                                                                           __HIP_MEMORY_SCOPE_WORKGROUP)) == kLoadsDone;
-#endif
+            if constexpr (diag::kUnorderedEarlyStores) {  // (diagnostic builds only: round 4's form, no hand-shake)
+                stored_early = true;
+            } else {
+                asm volatile("" ::: "memory");  // (read here, in front of the barrier: as late as the stores allow)
+                stored_early = __builtin_amdgcn_readfirstlane(__hip_atomic_load(partner_loaded, __ATOMIC_RELAXED,
+                                                                               __HIP_MEMORY_SCOPE_WORKGROUP)) == kLoadsDone;
+            }
             if (stored_early && live) {
                 Player& mine = ROLE == 0 ? g.p1 : g.p2;
                 const Player& was = ROLE == 0 ? loaded.p1 : loaded.p2;
@@ -1355,7 +1373,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         }
     };
     const int reward = step_games_pair<ROLE, AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, xchg, kLanes * PZ_OBS_DIM,
-                                                        lane, lut, after_hit, bold_pending, before_barrier);
+                                                        lane, lut, after_hit, bold_pending, before_barrier, reuse, ex_fresh);
     const Rewards rw = shape_rewards(a.cfg, g, reward, frozen);
     if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
     PZ_PAIR_STAMP(ROLE, 2);
@@ -1471,10 +1489,11 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
             else
                 io.st(PZ_B_EXPECTED_LANDING_POINT_X, ex);
         }
+        // (changes when a round ends / starts and on the first frame after the caller cleared it: rarely)
+        if (live && ex_fresh != fresh_loaded) fio.st(ex_fresh);
     }
     // (player 1's wave checks both action words: both waves load both)
-    if (!RANDOM && ROLE == 0)
-        count_action_faults(a.cfg, live && ((uint32_t)a1 >= action_count(a.cfg) || (uint32_t)a2 >= action_count(a.cfg)));
+    if (!RANDOM && ROLE == 0) count_action_faults(a.cfg, live && actions_out_of_range(a.cfg, a1, a2, act_high));
     if (RANDOM && ROLE == 0 && a.episodes_done != nullptr) {  // pz_step_random's counter: one atomic per workgroup
         unsigned int total = (unsigned int)(live && g.e.game_ended && !frozen);
         for (int off = kLanes / 2; off > 0; off >>= 1) total += __shfl_down(total, off, kLanes);
@@ -1488,7 +1507,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
 template <bool AI1, bool AI2, bool PACKED = false, bool RANDOM = false>
 __global__ __launch_bounds__(2 * kLanes) void step_pair_kernel(PZ_HOT_PARAMS, const StepArgs a)
 {
-    const HotArgs hot{state, n, stride, act_p1, act_p2};
+    const HotArgs hot{state, n, stride, act_p1, act_p2, act_format};
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     // the player exchange of step_games_pair lives in the staging rows (each wave's incoming data in its own
     // rows, overwritten by nobody else): 17.5 KB of LDS per workgroup, 8 workgroups per CU
@@ -1572,7 +1591,7 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         g.b.ppx = io.ld(PZ_B_PREVIOUS_PREVIOUS_X);
         g.b.ppy = io.ld(PZ_B_PREVIOUS_PREVIOUS_Y);
         g.b.rot = io.ld(PZ_B_FINE_ROTATION);
-        if (kKeepsEx) g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);
+        if (kOwnAI) g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);  // (kKeepsEx: the wave that stores it back)
         g.b.punch = io.ld(PZ_B_PUNCH_EFFECT_X);
         load_player(own, io, kOwn);
         // of the partner: what an exchange hands over (its state before its next move) and the collision flag
@@ -1588,6 +1607,15 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         other.coll = io.ld(kOther + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED);
     }
     if (with_stats && live) sio.load(st);
+    // a computer's wave: g.b.ex is the landing point of the ball as it stands (pz_physics.hpp) -- carried in a register
+    // from frame to frame, across launches in the caller's pz_config.landing_fresh bytes (NULL: the first frame predicts)
+    // (stored back unconditionally, through a descriptor built there: nothing more is carried around the frame loop)
+    // (kept as a per-lane word: a lane mask would be two more scalars around the frame loop, which has none to spare)
+    int ex_fresh = kOwnAI && live && make_fresh_io(a.cfg, kOwnAI ? hot.n : 0, i).ld();
+    auto fresh_now = [&]() {
+        asm volatile("" : "+v"(ex_fresh));
+        return ex_fresh != 0;
+    };
 
     const uint32_t n_actions = a.cfg.simplify_action ? 13u : 18u;
     BoldDefer bold{false, false, 0u, 0u};
@@ -1605,16 +1633,15 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
     unsigned char* const parked = reinterpret_cast<unsigned char*>(tape_lds);
     bool bad_action = false;  // (every wave checks the row it parks: its own player's)
     auto fetch_tape_chunk = [&](int32_t s0, auto first) {
-        bad_action |= park_tape_chunk<decltype(first)::value, ROLE == 0, ROLE == 1>(a.act_p1, a.n, n32, a.k, s0, io.voff, parked,
-                                                                                     lane, action_count(a.cfg));
+        bad_action |= park_tape_chunk<decltype(first)::value, ROLE == 0, ROLE == 1>(static_cast<const int32_t*>(a.act_p1), a.n, n32,
+                                                                                     a.k, s0, io.voff, parked, lane, action_count(a.cfg));
         __syncthreads();
     };
     if (MODE == kTape) fetch_tape_chunk(0, std::true_type{});
     __builtin_amdgcn_s_waitcnt(0x0F70);  // every state load lands before the frame loop (see step_kernel)
     bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
-    bool ex_fresh = false;  // a computer's wave: g.b.ex is the landing point of the ball as it stands (pz_physics.hpp)
-    PairHead head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold, ex_fresh);
+    PairHead head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold, fresh_now());
     // (the gathers' wait, see step_kernel's frame loop -- for a computer's wave that stores rows: with two computer players)
     if (kOwnAI && !kWritesNone) issue_dropped_stores<TrajOut<OBS16>::kStores / 2>();
     for (int32_t s = 0; s < a.k; ++s) {
@@ -1627,9 +1654,11 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         }
         const bool last_frame = s == a.k - 1;
         const bool frozen = head.frozen;
+        bool fresh = fresh_now();
         const int reward = pair_frame_tail<ROLE, AI1, AI2>(g, a.cfg, id, a1, a2, live, head,
                                                            xchg + (s & 1) * (2 * kLoopXchgRegion), lane, lut, last_frame,
-                                                           &ex_fresh);
+                                                           &fresh);
+        ex_fresh = fresh;
         finished += (unsigned int)(live && g.e.game_ended && !frozen);
         const Rewards rw = shape_rewards(a.cfg, g, reward, frozen, &zones);
         if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
@@ -1665,7 +1694,7 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         if (s + 1 < a.k) {  // this frame's outputs are staged: the game may move on
             resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
             any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
-            head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold, ex_fresh);
+            head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold, fresh_now());
         }
         auto next_policy = [&]() {
             if (MODE == kRollout) policy_actions(id.id_lo, id.id_hi, policy, a.t0 + (uint64_t)s + 1u, n_actions, a1, a2);
@@ -1679,16 +1708,25 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         out.advance();
     }
     if (!kOwnAI && bold.pending1) own.bold = rng_integers(id, bold.counter1, 5u);  // the launch's last recorded draw
+    // (out.ioff: the game's index, ~0u past the end of the batch -- dropped by the range check like a NULL buffer's byte)
+    if (kKeepsEx)
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(ex_fresh != 0),
+                                             make_rsrc(a.cfg.landing_fresh, a.cfg.landing_fresh != nullptr ? n32 : 0u), out.ioff, 0, 0);
 
     // ---- the state back: every wave its player, its half of the ball; player 1's wave the env words
     if (live) {
         if constexpr (PACKED) {
+            // (the three descriptors built afresh behind the frame loop -- the opaque copy of the stride is a new value to
+            // the compiler: twelve scalars less to carry around the loop, as with the column offsets below)
+            int64_t stride_again = hot.stride;
+            asm volatile("" : "+s"(stride_again));
+            const PackedIO back = make_packed_io(hot.state, stride_again, i);
             if (ROLE == 0)
-                pio.st_a(pack_group_a(g, sticky));
+                back.st_a(pack_group_a(g, sticky));
             else
-                pio.st_b(pack_group_b(g, sticky));
-            if (kOwnAI ? any_round_started : bold.pending1) pio.st_bold(ROLE, own.bold);
-            if (kKeepsEx) pio.st_ex(g.b.ex);
+                back.st_b(pack_group_b(g, sticky));
+            if (kOwnAI ? any_round_started : bold.pending1) back.st_bold(ROLE, own.bold);
+            if (kKeepsEx) back.st_ex(g.b.ex);
         } else {
             // (column offsets computed afresh behind the frame loop: see step_kernel)
             StateIO back = io;
@@ -1731,7 +1769,7 @@ __global__ __launch_bounds__(2 * kLanes) __attribute__((amdgpu_waves_per_eu(2, 2
 void rollout_pair_kernel(PZ_HOT_PARAMS, const StepArgs args)
 {
     const StepArgs a = effective_args<PLAIN, OBS16>(args);
-    const HotArgs hot{state, n, stride, act_p1, act_p2};
+    const HotArgs hot{state, n, stride, act_p1, act_p2, act_format};
     __shared__ __attribute__((aligned(16))) int32_t lds_obs[2][kLanes * PZ_OBS_DIM];
     __shared__ int32_t xchg[kLoopXchgWords];  // the players' exchange: LDS of its own, double-buffered by frame parity
     __shared__ int32_t tape_lds[MODE == kTape ? kTapeWords : 1];  // parked action tape (kTape only)
@@ -1782,6 +1820,7 @@ __global__ __launch_bounds__(kLanes) void init_kernel(int32_t* state, int64_t n,
     const RngId id = make_rng_id(cfg, i);
     construct_game(g, id);
     io.store(g, PackedWords{});
+    make_fresh_io(cfg, n, i).st(false);  // (dropped without the bytes)
 }
 
 template <bool PACKED>
@@ -1800,6 +1839,7 @@ __global__ __launch_bounds__(kLanes) void reset_kernel(int32_t* state, int64_t n
             const RngId id = make_rng_id(cfg, i);
             reset_game(g, cfg, id);
             io.store(g, was);
+            make_fresh_io(cfg, n, i).st(false);  // the ball was put back, the stored landing point was not (carry-over)
             if (episode_stats != nullptr)  // RecordEpisodeStatistics.reset (:23-25)
                 make_stats_io(episode_stats, true, stride, i).store(EpisodeStats{0.0, 0.0, 0});
         }
@@ -1863,8 +1903,8 @@ __global__ __launch_bounds__(64) void probe_write_kernel(char* a, char* b, int32
             for (int pass = 0; pass < 9; ++pass) {
                 const uint32_t v = (uint32_t)(pass * 64 + lane);
                 const u32x4 w = {(uint32_t)f, v, (uint32_t)side, 0u};
-                // (nt, the policy placement.py's thresholds were measured with -- not the k-frame launches' PZ_TRAJ_AUX)
-                __builtin_amdgcn_raw_buffer_store_b128(w, span, v * 16u, 0, PZ_OBS_AUX);  // beyond the span: dropped
+                // (nt, the policy placement.py's thresholds were measured with -- not the k-frame launches' kTrajAux)
+                __builtin_amdgcn_raw_buffer_store_b128(w, span, v * 16u, 0, kObsAux);  // beyond the span: dropped
             }
         }
     }
@@ -2192,9 +2232,7 @@ constexpr int64_t kMaxLanesPerLaunch = (int64_t)0xFFFFFFFFu / (PZ_STATE_WORDS * 
 //       65 536: 7.58 | 8.01    131 072: 11.1 | 11.5    262 144: 22.4 | 23.8    294 912: 25.3 | 26.5
 //      524 288: 47.2 | 46.5    1 048 576: 93.9 | 90.6      (single-wave without changed-only at 65 536: 8.52)
 //   player 2 = computer, scout kernel | single-wave changed-only:   262 144: 36.5 | 38.2    524 288: 70.3 | 66.4
-#ifndef PZ_TWO_WAVE_MAX_LANES
-#define PZ_TWO_WAVE_MAX_LANES 393216  // below: two waves per workgroup (pair kernel / scout)
-#endif
+constexpr int64_t kTwoWaveMaxLanes = 393216;  // below: two waves per workgroup (pair kernel / scout)
 //   the changed-only write-back also pays in the scout kernel (65 536: 14.3 | 14.65 without, 262 144: 35.6 | 36.6)
 //   and is used by every launch that writes the state back after ONE frame; a trajectory launch writes it once
 //   per k frames, where the plain write-back is always right.
@@ -2217,6 +2255,7 @@ static int check_common(const void* state, int64_t n, int64_t stride, const pz_c
         cfg->normalize_obs < 0 || cfg->normalize_obs > 2)
         return PZ_E_CONFIG;
     if (cfg->packed_state != 0 && cfg->packed_state != 1) return PZ_E_CONFIG;
+    if (cfg->action_format < PZ_ACT_I32 || cfg->action_format > PZ_ACT_I16) return PZ_E_CONFIG;
     if (is_packed(*cfg)) {
         if (cfg->winning_score > 65535) return PZ_E_CONFIG;  // the scores are 16-bit fields
         if (misaligned16(state)) return PZ_E_ALIGN;
@@ -2226,26 +2265,23 @@ static int check_common(const void* state, int64_t n, int64_t stride, const pz_c
 
 static inline unsigned int blocks_for(int64_t n, int per) { return (unsigned int)((n + per - 1) / per); }
 
-// Diagnostic builds only (tools/ab.py, tools/kernel_notes.py; the product never defines it): -DPZ_DEV_SUBSET=bits keeps
-// a subset of the step kernels' instantiations -- a variant that is only ever timed on one configuration builds in a
-// fraction of the 100 s the full library takes.  bits 0-3: launch modes kActions / kRandom / kRollout / kTape; 4: the packed
-// state format; 5: int16 rows; 6: human vs human; 7: player 2 = computer; 8: the other computer-player combinations;
-// 9: step_pair_kernel; 10: rollout_pair_kernel; 11: step_kernel; 12: the PLAIN forms of the k-frame kernels; 13: their
-// generic forms.  A launch that was left out returns PZ_E_CONFIG.
+// Diagnostic builds only (pz_diagnostic.hpp: diag::kSubset, bits 16-29 of PZ_DIAGNOSTIC_BUILD; 0 in the product = keep
+// everything): a subset of the step kernels' instantiations -- a variant that is only ever timed on one configuration
+// builds in a fraction of the 100 s the full library takes.  bits 0-3: launch modes kActions / kRandom / kRollout / kTape;
+// 4: the packed state format; 5: int16 rows; 6: human vs human; 7: player 2 = computer; 8: the other computer-player
+// combinations; 9: step_pair_kernel; 10: rollout_pair_kernel; 11: step_kernel; 12: the PLAIN forms of the k-frame
+// kernels; 13: their generic forms.  A launch that was left out returns PZ_E_CONFIG.
 enum DevFamily { kDevPair = 9, kDevRolloutPair = 10, kDevSingle = 11 };
-#ifdef PZ_DEV_SUBSET
 constexpr bool dev_keep(int family, int mode, bool ai1, bool ai2, bool packed, bool obs16, bool plain = false)
 {
-    constexpr unsigned m = PZ_DEV_SUBSET;
+    constexpr unsigned m = diag::kSubset;
+    if (m == 0u) return true;
     const bool players = (!ai1 && !ai2) ? (m >> 6) & 1u : ((!ai1 && ai2) ? (m >> 7) & 1u : (m >> 8) & 1u);
     const bool form = (mode != kRollout && mode != kTape) || ((m >> (plain ? 12 : 13)) & 1u);
     return ((m >> family) & 1u) && ((m >> mode) & 1u) && players && (!packed || ((m >> 4) & 1u)) &&
            (!obs16 || ((m >> 5) & 1u)) && form;
 }
 #define PZ_KEEP(...) pz::dev_keep(__VA_ARGS__)
-#else
-#define PZ_KEEP(...) true
-#endif
 
 // one step_kernel instantiation per player configuration; the trajectory modes also per observation row format
 // (OBS16, compile-time there: see TrajOut::flush)
@@ -2262,7 +2298,7 @@ static int launch_step_players(const StepArgs& a, hipStream_t stream)
     // kernel and every computer-player launch gain 1-2 % from theirs
     constexpr bool kHasPlain = (MODE == kRollout || MODE == kTape) && SCOUT == kNoScout && !PACKED;
     const bool plain = kHasPlain && is_plain(a);
-#define PZ_PLAIN_HERE(A1, A2) (kHasPlain && !(PZ_HH_ROLLOUT_GENERIC && MODE == kRollout && !(A1) && !(A2)))
+#define PZ_PLAIN_HERE(A1, A2) (kHasPlain && !(kHhRolloutGeneric && MODE == kRollout && !(A1) && !(A2)))
 #define PZ_LAUNCH_SINGLE_AS(A1, A2, PLAIN)                                                                                \
     do {                                                                                                                  \
         if constexpr (PZ_KEEP(kDevSingle, MODE, A1, A2, PACKED, OBS16, PLAIN))                                             \
@@ -2327,36 +2363,35 @@ template <int MODE>
 static int launch_step(const StepArgs& a, hipStream_t stream)
 {
     const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
-    // with both tables every flight is one gather: no scout wave is needed, and the single frame splits by player
-    const bool tables = a.tables.landing != nullptr && a.tables.power_hit != nullptr;
-#ifndef PZ_NO_PAIR_KERNEL
-    // (the packed format: at every size -- 524 288 games, us per launch, pair | single wave: human 30.25 | 30.13,
-    // player 2 = computer 38.6 | 40.6; 1 048 576 human 56.2 | 56.4)
-    if (MODE == kActions && (a.n < PZ_TWO_WAVE_MAX_LANES || is_packed(a.cfg)) && (tables || !(ai1 || ai2))) {
-        if (ai1 && ai2) return launch_pair<true, true>(a, stream);
-        if (ai1) return launch_pair<true, false>(a, stream);
-        if (ai2) return launch_pair<false, true>(a, stream);
-        return launch_pair<false, false>(a, stream);
+    // with the power-hit table the six candidate flights of a deciding player are one gather: no scout wave is needed, and
+    // the single frame splits by player.  The landing table is optional on top of it (pz_flight_tables in the header):
+    // without it the lanes that need a landing point predict it in the kernel -- with cfg.landing_fresh only on the frames
+    // that interrupt a flight
+    const bool tables = a.tables.power_hit != nullptr;
+    if constexpr (!diag::kNoPairKernel) {
+        // (the packed format: at every size -- 524 288 games, us per launch, pair | single wave: human 30.25 | 30.13,
+        // player 2 = computer 38.6 | 40.6; 1 048 576 human 56.2 | 56.4)
+        if (MODE == kActions && (a.n < kTwoWaveMaxLanes || is_packed(a.cfg)) && (tables || !(ai1 || ai2))) {
+            if (ai1 && ai2) return launch_pair<true, true>(a, stream);
+            if (ai1) return launch_pair<true, false>(a, stream);
+            if (ai2) return launch_pair<false, true>(a, stream);
+            return launch_pair<false, false>(a, stream);
+        }
+        // one frame of the on-device random policy is the same launch with the policy's Philox block in place of the two
+        // action loads (65 536 games: 8.2 -> 7.0 us against the single-wave kernel)
+        if (MODE == kRandom && a.k == 1 && (a.n < kTwoWaveMaxLanes || is_packed(a.cfg)) && (tables || !(ai1 || ai2))) {
+            if (ai1 && ai2) return launch_pair<true, true, true>(a, stream);
+            if (ai1) return launch_pair<true, false, true>(a, stream);
+            if (ai2) return launch_pair<false, true, true>(a, stream);
+            return launch_pair<false, false, true>(a, stream);
+        }
     }
-    // one frame of the on-device random policy is the same launch with the policy's Philox block in place of the two
-    // action loads (65 536 games: 8.2 -> 7.0 us against the single-wave kernel)
-    if (MODE == kRandom && a.k == 1 && (a.n < PZ_TWO_WAVE_MAX_LANES || is_packed(a.cfg)) && (tables || !(ai1 || ai2))) {
-        if (ai1 && ai2) return launch_pair<true, true, true>(a, stream);
-        if (ai1) return launch_pair<true, false, true>(a, stream);
-        if (ai2) return launch_pair<false, true, true>(a, stream);
-        return launch_pair<false, false, true>(a, stream);
-    }
-#endif
-#if !defined(PZ_NO_ROLLOUT_PAIR) && !defined(PZ_STAMPS)
     // pz_rollout_random / pz_step_many with a computer player on the flight tables: two waves per 64 games below the size switch
     // (interleaved A/B, us per frame at k = 32: 3.49 vs 4.34 on one wave; human vs human the single wave is at the
     // write ceiling already: 3.62 on two waves -- player 1's writing all outputs -- vs 3.63 on one, 3.76 with the
     // outputs split between the waves)
-#ifndef PZ_HH_PAIR_ROLLOUT
-#define PZ_HH_PAIR_ROLLOUT 1  // 1: human vs human on int16 rows, 2: every human-vs-human k-frame launch
-#endif
-    const bool hh_pair = !(ai1 || ai2) && (PZ_HH_PAIR_ROLLOUT == 2 || (PZ_HH_PAIR_ROLLOUT == 1 && a.cfg.normalize_obs == 2));
-    if constexpr (MODE == kRollout || MODE == kTape) if (a.n < PZ_TWO_WAVE_MAX_LANES && ((tables && (ai1 || ai2)) || hh_pair)) {
+    const bool hh_pair = !(ai1 || ai2) && (kHhPairRollout == 2 || (kHhPairRollout == 1 && a.cfg.normalize_obs == 2));
+    if constexpr ((MODE == kRollout || MODE == kTape) && !diag::kNoRolloutPair) if (a.n < kTwoWaveMaxLanes && ((tables && (ai1 || ai2)) || hh_pair)) {
         const dim3 grid(blocks_for(a.n, kLanes)), block(2 * kLanes);
         const bool packed = is_packed(a.cfg), obs16 = a.cfg.normalize_obs == 2, plain = is_plain(a);
 #define PZ_LAUNCH_ROLLOUT_PAIR_AS(A1, A2, PK, O16, PLAIN)                                                                 \
@@ -2388,25 +2423,22 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
             PZ_LAUNCH_ROLLOUT_PAIR(true, false);
         else if (ai2)
             PZ_LAUNCH_ROLLOUT_PAIR(false, true);
-#if PZ_HH_PAIR_ROLLOUT
         else
             PZ_LAUNCH_ROLLOUT_PAIR(false, false);
-#endif
 #undef PZ_LAUNCH_ROLLOUT_PAIR
 #undef PZ_LAUNCH_ROLLOUT_PAIR_AS
         return (int)hipGetLastError();
     }
-#endif
     // the packed format: pair kernel above, else one wave per workgroup (a computer player without tables computes its
     // flights in that wave: no scout)
     if (is_packed(a.cfg)) return launch_step_ai<MODE, false, true>(a, stream);
-#if !defined(PZ_NO_SCOUT_WAVE) && !defined(PZ_STAMPS)
-    if (a.n < PZ_TWO_WAVE_MAX_LANES && !tables) {  // a computer player is present (else: pair kernel above)
-        constexpr int kScout = MODE == kActions ? kScoutLoads : kScoutPosted;
-        constexpr bool kSparse = MODE == kActions || MODE == kRandom;
-        if (ai1 || ai2) return launch_step_ai<MODE, kSparse, false, kScout>(a, stream);
+    if constexpr (!diag::kNoScoutWave) {
+        if (a.n < kTwoWaveMaxLanes && !tables) {  // a computer player is present (else: pair kernel above)
+            constexpr int kScout = MODE == kActions ? kScoutLoads : kScoutPosted;
+            constexpr bool kSparse = MODE == kActions || MODE == kRandom;
+            if (ai1 || ai2) return launch_step_ai<MODE, kSparse, false, kScout>(a, stream);
+        }
     }
-#endif
     return launch_step_ai<MODE, MODE == kActions || MODE == kRandom>(a, stream);
 }
 
@@ -2435,9 +2467,10 @@ int pz_config_bytes(void) { return (int)sizeof(pz_config); }
 #ifndef PZ_BUILD_ID
 #define PZ_BUILD_ID "unstamped"
 #endif
-// stored behind a marker so that build.py can read the id from the file without mapping the library
+// stored behind a marker so that build.py can read the id from the file without mapping the library; a diagnostic
+// build (pz_diagnostic.hpp) never carries a product id, whatever it was compiled with: _native.load() refuses it
 static const char kBuildIdRecord[] = "pz_build_id:" PZ_BUILD_ID;
-const char* pz_build_id(void) { return kBuildIdRecord + 12; }
+const char* pz_build_id(void) { return diag::kDiagnosticBuild ? "diagnostic" : kBuildIdRecord + 12; }
 
 int64_t pz_flight_table_bytes(int32_t which)
 {
@@ -2567,8 +2600,8 @@ int pz_unpack_state(const void* packed, int64_t n, int64_t packed_stride, int32_
     return (int)hipGetLastError();
 }
 
-int pz_step(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, const int32_t* act_p1,
-            const int32_t* act_p2, int32_t* obs_p1, int32_t* obs_p2, void* rew_p1, void* rew_p2, uint8_t* terminated,
+int pz_step(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, const void* act_p1,
+            const void* act_p2, int32_t* obs_p1, int32_t* obs_p2, void* rew_p1, void* rew_p2, uint8_t* terminated,
             void* episode_stats, const pz_flight_tables* tables, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
@@ -2605,7 +2638,7 @@ int pz_step_bind(void* bound, int32_t* state, int64_t n, int64_t stride, const p
     return PZ_OK;
 }
 
-int pz_step_bound(const void* bound, const int32_t* act_p1, const int32_t* act_p2, void* stream)
+int pz_step_bound(const void* bound, const void* act_p1, const void* act_p2, void* stream)
 {
     const BoundStep* b = static_cast<const BoundStep*>(bound);
     if (b == nullptr || !act_p1 || !act_p2) return PZ_E_NULL;
@@ -2652,13 +2685,15 @@ int pz_rollout_random(int32_t* state, int64_t n, int64_t stride, const pz_config
     return launch_step<kRollout>(a, (hipStream_t)stream);
 }
 
-int pz_step_many(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, const int32_t* actions, int32_t k,
+int pz_step_many(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, const void* actions, int32_t k,
                  int32_t* obs_p1, int32_t* obs_p2, void* rew_p1, void* rew_p2, uint8_t* terminated,
                  void* episode_stats, int64_t* episodes_done, const pz_flight_tables* tables, void* stream)
 {
     if (int e = check_common(state, n, stride, cfg)) return e;
     if (!actions || !obs_p1 || !obs_p2 || !rew_p1 || !rew_p2 || !terminated) return PZ_E_NULL;
     if (k < 1) return PZ_E_SIZE;
+    // the tape is parked from int32 rows (the header says how a caller brings another element type)
+    if (cfg->action_format != PZ_ACT_I32) return PZ_E_CONFIG;
     if (misaligned16(obs_p1) || misaligned16(obs_p2) || (k > 1 && (n & (cfg->normalize_obs == 2 ? 7 : 3)) != 0))
         return PZ_E_ALIGN;
     if (tables_misaligned(tables)) return PZ_E_ALIGN;
@@ -2719,14 +2754,14 @@ int pz_render(int32_t* state, int64_t n, int64_t stride, const pz_config* cfg, c
 }
 
 
-#ifdef PZ_STAMPS
+#ifdef PZ_DIAGNOSTIC_BUILD  // (tools/stamps.py; the product exports exactly the header's functions)
 int pz_debug_read_stamps(unsigned long long* dst_host, int64_t count)
 {
-    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_pz_stamps), count * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(pz::diag::g_pz_stamps), count * sizeof(unsigned long long));
 }
 int pz_debug_read_frame_stamps(unsigned long long* dst_host, int64_t count)
 {
-    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_pz_frame_stamps), count * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(pz::diag::g_pz_frame_stamps), count * sizeof(unsigned long long));
 }
 #endif
 

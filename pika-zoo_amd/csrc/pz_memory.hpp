@@ -10,18 +10,14 @@
 
 namespace pz {
 
-constexpr int kLanes = PZ_WAVE_GAMES;  // lanes (games) per workgroup = one wavefront
+constexpr int kLanes = kWaveGames;  // lanes (games) per workgroup = one wavefront
 constexpr uint32_t kRowBytes = PZ_OBS_DIM * 4;            // 140
 constexpr uint32_t kWaveObsBytes = kLanes * kRowBytes;    // 8 960: a wave's rows are contiguous
 constexpr int kWaveObsVecs = (int)(kWaveObsBytes / 16);   // 560 16-byte pieces
 
-// cache-policy bits of the stores (aux operand: 1 = sc0, 2 = nt, 16 = sc1); tools/ab.py variants
-#ifndef PZ_STATE_AUX
-#define PZ_STATE_AUX 0
-#endif
-#ifndef PZ_OBS_AUX
-#define PZ_OBS_AUX 2  // observations are written once and not re-read by the step chain: nt, -2.4 % per launch
-#endif
+// cache-policy bits of the single-frame launches' stores (aux operand: 1 = sc0, 2 = nt, 16 = sc1), as measured:
+constexpr int kStateAux = 0;  // the state is re-read by the next launch: default policy
+constexpr int kObsAux = 2;    // observations are written once and not re-read by the step chain: nt, -2.4 % per launch
 
 using Rsrc = __amdgpu_buffer_rsrc_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -49,7 +45,7 @@ __device__ __forceinline__ void flush_rows(const int32_t* __restrict__ lds, cons
 #pragma unroll
     for (int pass = 0; pass < (kWaveObsVecs + kLanes - 1) / kLanes; ++pass) {
         const int v = pass * kLanes + lane;
-        if (v < kWaveObsVecs) __builtin_amdgcn_raw_buffer_store_b128(src4[v], span, (uint32_t)v * 16u, 0, PZ_OBS_AUX);
+        if (v < kWaveObsVecs) __builtin_amdgcn_raw_buffer_store_b128(src4[v], span, (uint32_t)v * 16u, 0, kObsAux);
     }
 }
 

@@ -14,28 +14,13 @@
 #include <stdint.h>
 
 #include "pikazoo_hip.h"
-
-// games (active lanes) per workgroup; 64 = a full wavefront (tools/ab.py builds a 32 variant)
-#ifndef PZ_WAVE_GAMES
-#define PZ_WAVE_GAMES 64
-#endif
+#include "pz_diagnostic.hpp"
 
 namespace pz {
 
-// per-wave sub-phase stamps of the frame (tools/stamps.py builds with -DPZ_STAMPS; never in the product)
-#ifdef PZ_STAMPS
-__device__ unsigned long long g_pz_frame_stamps[8192 * 8];
-#define PZ_FRAME_STAMP(k)                                                                   \
-    do {                                                                                    \
-        if (blockIdx.x < 8192 && threadIdx.x == 0) {                                         \
-            unsigned long long t_;                                                          \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
-            g_pz_frame_stamps[blockIdx.x * 8 + (k)] = t_;                                    \
-        }                                                                                   \
-    } while (0)
-#else
-#define PZ_FRAME_STAMP(k)
-#endif
+// games (active lanes) per workgroup: a full wavefront (32 -- half-filled waves, twice as many of them -- lost on every
+// kernel it was tried on: human vs human 6.97 -> 7.49 us per launch, profiles/r04_experiments/ab_g32_and_early_stores.log)
+constexpr int kWaveGames = 64;
 
 // pikazoo/env/physics.py:9-33
 constexpr int kGroundWidth = 432;
@@ -728,7 +713,7 @@ __device__ __forceinline__ void wave_power_hit_candidates(bool need, const Ball&
     }
     wave_lds_handover<LONE_WAVE>();
     const int items = deciders * 6;
-    for (int first = 0; first < items; first += PZ_WAVE_GAMES) {
+    for (int first = 0; first < items; first += kWaveGames) {
         const int item = first + lane;
         if (item < items) {
             const int r = item / 6, c = item - 6 * r;
@@ -994,6 +979,44 @@ struct ScoutLink {
     int32_t* posts;       // LDS [64][kPostPitch]  (kScoutPosted)
 };
 
+// ---- a ball keeps its landing point along a free flight --------------------------------------------------------------
+// calculate_expected_landing_point_x_for (physics.py:643-686) iterates a copy of the ball with the statements of
+// process_collision_between_ball_and_world_and_set_ball_position (:359-431) until it would touch the ground.  So for a
+// ball B that the world step moves to W(B) without touching the ground, P(W(B)) = P(B) -- the predictor's first iteration
+// on B IS that world step -- with two exceptions: (1) over the net at y == 192 exactly the world step bounces the ball off
+// the net's top (`y <= NET_PILLAR_TOP_BOTTOM_Y_COORD`, :408) where the predictor pushes it sideways (`<`, :667); (2) P(B)
+// counts its iterations against INFINITE_LOOP_LIMIT (:33), which only a ball without x velocity bouncing on the net top
+// for ever reaches.  tests/flight_rule.c checks the statement on every one of the landing table's 4.6e8 balls against the
+// predictor's CPU restatement (416 234 714 balls covered, no violation; 2 387 182 excluded, 155 343 of them rightly).
+// So a frame whose stored expected_landing_point_x is known to belong to the stored ball (`fresh`) needs a prediction only
+// where the flight was interrupted: a collision, a ball outside the table's domain -- a round that starts serves a ball
+// without x velocity at x = 56 / 376, which comes down where it is.  The k-frame kernels carry `fresh` in a register from
+// frame to frame; across launches it lives in the caller's pz_config.landing_fresh bytes (include/pikazoo_hip.h), which
+// every step launch with a computer player maintains and pz_init / pz_reset clear -- without them (NULL) the first frame
+// of every launch predicts.
+__device__ __forceinline__ bool ball_in_landing_domain(int x, int y, int xv, int yv)
+{
+    return (ft_xv_index(xv) >= 0) & ((unsigned)(x - kBallRadius) < (unsigned)kFtXCount) & ((unsigned)y < (unsigned)kFtYCount) &
+           (abs(yv) <= PZ_FT_YV_MAX);
+}
+// B = (x, y, xv) BEFORE the world step
+__device__ __forceinline__ bool flight_keeps_landing_point(int x, int y, int xv)
+{
+    const bool over_net = abs(x - kGroundHalfWidth) < kNetPillarHalfWidth;
+    return !(over_net & ((y == kNetTopBottomY) | (xv == 0)));
+}
+
+// `known`, part 1 (B = the ball BEFORE the world step): the stored landing point is B's and the step will not change it
+__device__ __forceinline__ bool landing_known_before_step(bool round_began, bool fresh, const Ball& b)
+{
+    return round_began | (fresh & ball_in_landing_domain(b.x, b.y, b.xv, b.yv) & flight_keeps_landing_point(b.x, b.y, b.xv));
+}
+// part 2 (the ball AFTER the world step): it did not touch the ground and is still inside the domain the rule was checked on
+__device__ __forceinline__ bool landing_known_after_step(bool known, bool round_began, bool ground, const Ball& b)
+{
+    return known & !ground & (round_began | ball_in_landing_domain(b.x, b.y, b.xv, b.yv));
+}
+
 // Deferred boldness draws (k-frame launches): computer_boldness is drawn for every player at every round start
 // (physics.py:218) but read by the computer player's decision only.  For a HUMAN player a round start therefore just
 // records the draw's counter; the caller makes the launch's last recorded draw once, behind its frame loop, instead of
@@ -1019,15 +1042,19 @@ struct BoldDefer {
 // profiles/r03_experiments/ab_rollout_p2_computer_head_orderings.log.)
 struct FrameHead {
     bool frozen, ground;
+    bool known;               // g.b.ex already is this frame's landing point (no look-up, no prediction)
     uint32_t landing_word;    // LandingProbe::value
     lut_u32x4 candidate_row;  // CandidateProbe::value
     PreDrawn pre;
 };
 
 // DEFER1 / DEFER2: player 1's / 2's boldness draw is recorded in *bold instead of made (human players, k-frame launches)
+// reuse (wave-uniform: the caller passed pz_config.landing_fresh) / ex_fresh: g.b.ex is the landing point of the ball as
+// it stands -- the flight rule above then replaces the prediction; without `reuse` every frame predicts
 template <bool AI1, bool AI2, int SCOUT = kNoScout, bool DEFER1 = false, bool DEFER2 = false>
 __device__ __forceinline__ FrameHead frame_head(Game& g, const pz_config& cfg, const RngId& id, bool live, int lane,
-                                                const FlightLut& lut, const ScoutLink link, BoldDefer* bold)
+                                                const FlightLut& lut, const ScoutLink link, BoldDefer* bold,
+                                                const bool reuse = false, const bool ex_fresh = false)
 {
     static_assert(!(DEFER1 && AI1) && !(DEFER2 && AI2), "a computer player reads its boldness");
     // The reference empties `agents` on termination (:237-238) and expects reset() before the
@@ -1039,7 +1066,9 @@ __device__ __forceinline__ FrameHead frame_head(Game& g, const pz_config& cfg, c
     const bool active = live && !h.frozen;
     PZ_FRAME_STAMP(0);
     if (active) {
+        bool round_began = false;
         if (g.e.round_ended) {  // game_ended implies round_ended
+            round_began = true;
             if (g.e.game_ended) {
                 g.e.game_ended = 0;
                 g.e.p2serve = 0;
@@ -1067,8 +1096,13 @@ __device__ __forceinline__ FrameHead frame_head(Game& g, const pz_config& cfg, c
             ball_new_round(g.b, get_server(cfg, g.e, id));
         }
         PZ_FRAME_STAMP(1);
+        if (AI1 || AI2) {
+            h.known = reuse & landing_known_before_step(round_began, ex_fresh, g.b);
+            g.b.ex = (reuse & round_began) ? g.b.x : g.b.ex;  // (a serve has no x velocity and is not over the net)
+        }
         // physics_engine
         h.ground = ball_world_step(g.b);
+        if (AI1 || AI2) h.known = landing_known_after_step(h.known, round_began, h.ground, g.b);
         PZ_FRAME_STAMP(3);
     }
     if (SCOUT == kScoutPosted) {
@@ -1082,13 +1116,15 @@ __device__ __forceinline__ FrameHead frame_head(Game& g, const pz_config& cfg, c
         }
         __syncthreads();  // the scout starts on this frame's candidates
     }
-    // With both flight tables every prediction is one gather and nothing needs the wave's cooperation: the decision
-    // runs as in the pair kernel (step_games_pair) -- both gathers issued, the first decision's three possible draws
-    // computed under them, branch-free decisions.  One candidate gather serves both players (same ball).
-    const bool by_tables = (AI1 || AI2) && SCOUT == kNoScout && lut.has_landing && lut.has_power_hit;  // wave-uniform
+    // With the power-hit table the six candidates are one gather and nothing needs the wave's cooperation: the decision
+    // runs as in the pair kernel (step_games_pair) -- both gathers issued (without the landing table that one reads
+    // nothing and the lanes that need a landing point predict it), the first decision's three possible draws computed
+    // under them, branch-free decisions.  One candidate gather serves both players (same ball).
+    const bool by_tables = (AI1 || AI2) && SCOUT == kNoScout && lut.has_power_hit;  // wave-uniform
     if (by_tables && active) {
         const bool scan = (AI1 && power_hit_scan_needed(g.p1, g.b)) || (AI2 && power_hit_scan_needed(g.p2, g.b));
-        h.landing_word = lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv).value;
+        // (a lane that knows its landing point reads entry 0 like a lane outside the domain: a line the whole wave shares)
+        h.landing_word = lut.landing_issue(!h.known, g.b.x, g.b.y, g.b.xv, g.b.yv).value;
         h.candidate_row = lut.candidates_issue(scan, g.b.x, g.b.y, abs(g.b.yv)).value;
         h.pre = predraw3(id, g.e.rng);
     }
@@ -1096,10 +1132,13 @@ __device__ __forceinline__ FrameHead frame_head(Game& g, const pz_config& cfg, c
 }
 
 // PIN: the caller runs head and tail back to back (single frame): keep the head's Philox blocks under its gathers
+// ex_fresh (may be NULL): set to whether g.b.ex -- as stored by the caller, or by the scout wave -- is the landing point
+// of the ball this frame leaves behind; left alone for a game the frame did not step
 template <bool AI1, bool AI2, int SCOUT = kNoScout, bool PIN = true>
 __device__ __forceinline__ int frame_tail(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
                                           FrameHead& h, int32_t* __restrict__ scratch, int lane, const FlightLut& lut,
-                                          const ScoutLink link, bool* ex_pending, const bool last_frame)
+                                          const ScoutLink link, bool* ex_pending, const bool last_frame,
+                                          bool* ex_fresh = nullptr)
 {
     const bool active = live && !h.frozen, ground = h.ground;
     Input in1{0, 0, 0}, in2{0, 0, 0};
@@ -1114,7 +1153,7 @@ __device__ __forceinline__ int frame_tail(Game& g, const pz_config& cfg, const R
         }
         PZ_FRAME_STAMP(2);
     }
-    const bool by_tables = (AI1 || AI2) && SCOUT == kNoScout && lut.has_landing && lut.has_power_hit;  // wave-uniform
+    const bool by_tables = (AI1 || AI2) && SCOUT == kNoScout && lut.has_power_hit;  // wave-uniform
     if (by_tables) {
         if (active) {
             int ex[6] = {0, 0, 0, 0, 0, 0};
@@ -1126,11 +1165,11 @@ __device__ __forceinline__ int frame_tail(Game& g, const pz_config& cfg, const R
             const bool scan2 = AI2 && power_hit_scan_needed(g.p2, g.b);
             const int ayv = abs(g.b.yv);
             uint32_t unused;
-            LandingProbe lp = lut.landing_locate(true, g.b.x, g.b.y, g.b.xv, g.b.yv, unused);
+            LandingProbe lp = lut.landing_locate(!h.known, g.b.x, g.b.y, g.b.xv, g.b.yv, unused);
             lp.value = h.landing_word;
             CandidateProbe cp = lut.candidates_locate(scan1 | scan2, g.b.x, g.b.y, ayv, unused);
             cp.value = h.candidate_row;
-            g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, 0);  // :314-315, one evaluation serves both
+            g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, g.b.ex);  // :314-315, one evaluation serves both (known: it stands)
             lut.candidates_finish(cp, g.b.x, g.b.y, ayv, ex);
             PreDrawn pre = h.pre;
             if (AI1) g.e.rng += computer_decide_predrawn<false>(g.p1, g.b, g.p2.x, pre, scan1, ex, in1);
@@ -1141,9 +1180,10 @@ __device__ __forceinline__ int frame_tail(Game& g, const pz_config& cfg, const R
             }
         }
     } else {
-        if ((AI1 || AI2) && active) {
+        if ((AI1 || AI2) && active && !h.known) {
             // :314-315 recomputes the landing point before each player; the ball does not move
-            // between the two calls, so one evaluation serves both.
+            // between the two calls, so one evaluation serves both.  (known: the stored one stands -- the lanes of a
+            // wave that still predict are the ones whose flight was interrupted)
             g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
         }
 
@@ -1222,6 +1262,9 @@ __device__ __forceinline__ int frame_tail(Game& g, const pz_config& cfg, const R
             else
                 g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
         }
+        // what the frame leaves: the landing point of its moved ball (:314-315), or of the ball a player hit (:331-332);
+        // a ball on the ground ends the round, and a collision whose prediction was skipped leaves a stale value
+        if ((AI1 || AI2) && ex_fresh != nullptr) *ex_fresh = !ground & (!hit_processed | ex_observable);
     }
     if (SCOUT == kScoutLoads) {
         int32_t* slot = link.hits + lane * kHitPitch;
@@ -1244,11 +1287,13 @@ template <bool AI1, bool AI2, int SCOUT = kNoScout>
 __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
                                           bool& frozen, int32_t* __restrict__ scratch, int lane,
                                           const FlightLut& lut, const ScoutLink link = ScoutLink{nullptr, nullptr, nullptr},
-                                          bool* ex_pending = nullptr, const bool last_frame = true)
+                                          bool* ex_pending = nullptr, const bool last_frame = true, const bool reuse = false,
+                                          bool* ex_fresh = nullptr)
 {
-    FrameHead h = frame_head<AI1, AI2, SCOUT>(g, cfg, id, live, lane, lut, link, nullptr);
+    FrameHead h = frame_head<AI1, AI2, SCOUT>(g, cfg, id, live, lane, lut, link, nullptr, reuse, ex_fresh != nullptr && *ex_fresh);
     frozen = h.frozen;
-    return frame_tail<AI1, AI2, SCOUT, true>(g, cfg, id, a1, a2, live, h, scratch, lane, lut, link, ex_pending, last_frame);
+    return frame_tail<AI1, AI2, SCOUT, true>(g, cfg, id, a1, a2, live, h, scratch, lane, lut, link, ex_pending, last_frame,
+                                             ex_fresh);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1288,11 +1333,13 @@ constexpr int kEarlyPostAt = 1024;  // word offset of the early post {x, draws} 
 
 // before_barrier(): called once the own player has moved and been posted, in front of the exchange barrier -- what the
 // caller can do with its finished player while the partner wave is still deciding
+// reuse (wave-uniform) / ex_fresh (a computer's wave; in: the caller's pz_config.landing_fresh byte, out: what to store
+// there): g.b.ex is the landing point of the ball as it stands -- see "a ball keeps its landing point" above
 template <int ROLE, bool AI1, bool AI2, class BeforeBarrier>
 __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2,
                                                bool live, bool& frozen, int32_t* __restrict__ xchg, int xchg_region,
                                                int lane, const FlightLut& lut, LandingProbe& after_hit, bool& bold_pending,
-                                               BeforeBarrier&& before_barrier)
+                                               BeforeBarrier&& before_barrier, const bool reuse, bool& ex_fresh)
 {
     constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
     constexpr bool kOtherAI = ROLE == 0 ? AI2 : AI1;
@@ -1305,6 +1352,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     bool ground = false;
     bool bold_late = false;       // the computer's round-start boldness, drawn behind the gathers' issue
     uint32_t bold_counter = 0u;
+    bool known = false;           // own computer player: g.b.ex already is this frame's landing point
     PZ_FRAME_STAMP(0);
     // (Moving the ball first and issuing the computer's two gathers in front of the players' round start and the action
     // decode -- the gathers depend on the ball columns, the round flags and the serve only -- was built twice in round 4
@@ -1312,7 +1360,9 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     // branch it was issued in closes), issue and consumption in one block 8.33 -> 8.36, packed 7.25 -> 7.71:
     // profiles/r04_experiments/ab_early_gather_*.log.  A hundred instructions earlier buys nothing.)
     if (active) {
+        bool round_began = false;
         if (g.e.round_ended) {  // reset (:149-164) or new round (:176-180); game_ended implies round_ended
+            round_began = true;
             if (g.e.game_ended) {
                 g.e.game_ended = 0;
                 g.e.p2serve = 0;
@@ -1374,7 +1424,12 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
         }
         PZ_FRAME_STAMP(2);
 
+        if (kOwnAI) {
+            known = reuse & landing_known_before_step(round_began, ex_fresh, g.b);
+            g.b.ex = (reuse & round_began) ? g.b.x : g.b.ex;  // (a serve has no x velocity and is not over the net)
+        }
         ground = ball_world_step(g.b);
+        if (kOwnAI) known = landing_known_after_step(known, round_began, ground, g.b);
         PZ_FRAME_STAMP(3);
     }
     const uint32_t rng_base = g.e.rng;  // the env stream before this frame's decisions
@@ -1397,7 +1452,8 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             const bool scan = power_hit_scan_needed(own, g.b);
             const int ayv = abs(g.b.yv);
             int ex[6] = {0, 0, 0, 0, 0, 0};
-            LandingProbe lp = lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv);
+            // (a lane that knows its landing point reads entry 0 like a lane outside the domain: a line the whole wave shares)
+            LandingProbe lp = lut.landing_issue(!known, g.b.x, g.b.y, g.b.xv, g.b.yv);
             CandidateProbe cp = lut.candidates_issue(scan, g.b.x, g.b.y, ayv);
             PreDrawn pre = predraw3(id, rng_base + draws_other);
             if (__builtin_amdgcn_ballot_w64(bold_late) != 0ull) {  // (wave-uniform: a lane of the wave starts a round)
@@ -1416,7 +1472,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
                 const int nx = min(max(other.x + vx, kPlayerHalfLength), kGroundHalfWidth - kPlayerHalfLength);
                 other.x = (other.state == 4) ? other.x : nx;
             }
-            g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, 0);
+            g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, g.b.ex);  // (known: it stands)
             lut.candidates_finish(cp, g.b.x, g.b.y, ayv, ex);
             draws_own = computer_decide_predrawn<ROLE == 1>(own, g.b, other.x, pre, scan, ex, in_own);
         }
@@ -1499,6 +1555,9 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     // the second of two would).  Nothing in the frame reads it any more: the gather is issued here and taken
     // by the caller behind its other stores (`after_hit`).
     if (kKeepsEx) after_hit = lut.landing_issue(hit_processed, g.b.x, g.b.y, g.b.xv, g.b.yv);
+    // what the frame leaves (the caller finishes `after_hit` before it stores): the landing point of the ball as it stands,
+    // unless the ball is on the ground -- the round ends, and the next one starts from the serve
+    if (kOwnAI && active) ex_fresh = !ground;
     PZ_FRAME_STAMP(7);
     return reward;
 }
@@ -1518,30 +1577,6 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
 constexpr int kLoopXchgEarlyAt = 10 * kXchgPitch;            // the early post {x, draws} behind the ten exchange words
 constexpr int kLoopXchgRegion = kLoopXchgEarlyAt + 2 * 64;   // words per region (one per wave)
 constexpr int kLoopXchgWords = 2 * 2 * kLoopXchgRegion;      // two regions, two frame parities
-
-// ---- a ball keeps its landing point along a free flight --------------------------------------------------------------
-// calculate_expected_landing_point_x_for (physics.py:643-686) iterates a copy of the ball with the statements of
-// process_collision_between_ball_and_world_and_set_ball_position (:359-431) until it would touch the ground.  So for a
-// ball B that the world step moves to W(B) without touching the ground, P(W(B)) = P(B) -- the predictor's first iteration
-// on B IS that world step -- with two exceptions: (1) over the net at y == 192 exactly the world step bounces the ball off
-// the net's top (`y <= NET_PILLAR_TOP_BOTTOM_Y_COORD`, :408) where the predictor pushes it sideways (`<`, :667); (2) P(B)
-// counts its iterations against INFINITE_LOOP_LIMIT (:33), which only a ball without x velocity bouncing on the net top
-// for ever reaches.  tests/flight_rule.c checks the statement on every one of the landing table's 4.6e8 balls against the
-// predictor's CPU restatement (416 234 714 balls covered, no violation; 2 387 182 excluded, 155 343 of them rightly).
-// The k-frame pair kernel, which holds the ball and its last prediction in registers, looks a landing point up only for
-// the games whose flight was interrupted: a collision, a ball outside the table's domain, the launch's first frame --
-// a round that starts serves a ball without x velocity at x = 56 / 376, which comes down where it is.
-__device__ __forceinline__ bool ball_in_landing_domain(int x, int y, int xv, int yv)
-{
-    return (ft_xv_index(xv) >= 0) & ((unsigned)(x - kBallRadius) < (unsigned)kFtXCount) & ((unsigned)y < (unsigned)kFtYCount) &
-           (abs(yv) <= PZ_FT_YV_MAX);
-}
-// B = (x, y, xv) BEFORE the world step
-__device__ __forceinline__ bool flight_keeps_landing_point(int x, int y, int xv)
-{
-    const bool over_net = abs(x - kGroundHalfWidth) < kNetPillarHalfWidth;
-    return !(over_net & ((y == kNetTopBottomY) | (xv == 0)));
-}
 
 struct PairHead {
     bool frozen, ground;
@@ -1598,12 +1633,11 @@ __device__ __forceinline__ PairHead pair_frame_head(Game& g, const pz_config& cf
         if (kOwnAI) {
             // ex_fresh: g.b.ex is the landing point of the ball as it stands (the last frame predicted it for its moved
             // ball and no collision has changed the flight since)
-            h.known = round_began | (ex_fresh & ball_in_landing_domain(g.b.x, g.b.y, g.b.xv, g.b.yv) &
-                                     flight_keeps_landing_point(g.b.x, g.b.y, g.b.xv));
+            h.known = landing_known_before_step(round_began, ex_fresh, g.b);
             g.b.ex = round_began ? g.b.x : g.b.ex;  // (a serve has no x velocity and is not over the net)
         }
         h.ground = ball_world_step(g.b);
-        if (kOwnAI) h.known &= !h.ground & (round_began | ball_in_landing_domain(g.b.x, g.b.y, g.b.xv, g.b.yv));
+        if (kOwnAI) h.known = landing_known_after_step(h.known, round_began, h.ground, g.b);
     }
     h.rng_base = g.e.rng;
     if (kOwnAI && active) {
@@ -1740,10 +1774,9 @@ __device__ __forceinline__ int pair_frame_tail(Game& g, const pz_config& cfg, co
         // next frame's prediction before anything reads it: evaluated on the last frame and for a game that freezes
         const bool ex_observable = last_frame | (g.e.game_ended != 0 && cfg.auto_reset == 0);
         if (kKeepsEx && (hit1 | hit2) && ex_observable) g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
-        // a processed collision has changed the flight: g.b.ex no longer belongs to the ball (pair_frame_head)
-        if (kOwnAI && ex_fresh != nullptr) *ex_fresh = !(hit1 | hit2);
-    } else if (kOwnAI && ex_fresh != nullptr) {
-        *ex_fresh = false;
+        // a processed collision has changed the flight: g.b.ex no longer belongs to the ball (pair_frame_head) unless it
+        // was predicted again just now; a ball on the ground ends the round.  (A game the frame did not step keeps its flag.)
+        if (kOwnAI && ex_fresh != nullptr) *ex_fresh = !ground & (!(hit1 | hit2) | (kKeepsEx & ex_observable));
     }
     return reward;
 }

@@ -11,12 +11,14 @@ from pathlib import Path
 PKG_ROOT = Path(__file__).resolve().parent.parent  # .../pika-zoo_amd
 LIB_PATH = PKG_ROOT / "lib" / "libpikazoo_hip.so"
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PACKED_BYTES_PER_GAME = 36
 SCENERY_WORDS = 75
 STATE_WORDS = 44
 OBS_DIM = 35
 SERVE_MODES = {"winner": 0, "alternate": 1, "random": 2}
+# pz_action_format: the element type of the action vectors a step launch reads as they are
+ACTION_FORMATS = {"int32": 0, "int64": 1, "uint8": 2, "int16": 3}
 
 
 class PzConfig(C.Structure):
@@ -42,13 +44,16 @@ class PzConfig(C.Structure):
         ("seed", C.c_uint64),
         ("env_id_base", C.c_int64),
         ("action_faults", C.c_void_p),  # NULL or a device uint64 counter of out-of-range actions (pikazoo_env.py:182)
+        ("landing_fresh", C.c_void_p),  # NULL or `stride` device bytes: the stored landing point belongs to the stored ball
+        ("action_format", C.c_int32),   # ACTION_FORMATS: element type of the action vectors
+        ("reserved0", C.c_int32),
     ]
 
 
 class PzFlightTables(C.Structure):
     """`pz_flight_tables` (include/pikazoo_hip.h): device pointers of the computer player's flight tables."""
 
-    _fields_ = [("landing", C.c_void_p), ("power_hit", C.c_void_p)]
+    _fields_ = [("landing", C.c_void_p), ("power_hit", C.c_void_p)]  # either may be NULL
 
 
 class PikazooNativeError(RuntimeError):

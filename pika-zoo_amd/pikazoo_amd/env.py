@@ -23,7 +23,23 @@ import torch
 from . import _native
 from .spaces import Box, Discrete
 
+# The reference is `class raw_env(ParallelEnv)` (pikazoo_env.py:72) and downstream libraries test `isinstance(env,
+# ParallelEnv)`: when PettingZoo is importable its class is the base (like spaces.py does with gymnasium's spaces); the
+# build image has neither, so the stand-in only carries the name.
+try:  # pragma: no cover - pettingzoo is not installed in the build image
+    from pettingzoo import ParallelEnv  # type: ignore
+except Exception:  # noqa: BLE001
+
+    class ParallelEnv:  # type: ignore[no-redef]
+        """Stand-in base when PettingZoo is not installed (``raw_env`` defines the whole parallel API itself)."""
+
 AGENTS = ["player_1", "player_2"]
+
+# action vectors a step launch reads as they are (pz_action_format); any other integer dtype is widened on the host
+_ACTION_FORMAT = {torch.int32: 0, torch.int64: 1, torch.uint8: 2, torch.int16: 3}
+# flight_tables= of the env -> (landing table, power-hit table)
+_TABLE_MODES = {True: (True, True), "both": (True, True), "power_hit": (False, True),
+                False: (False, False), None: (False, False), "none": (False, False)}
 
 # observation bounds: pikazoo/env/pikazoo_env.py:485-562 (player, opponent, ball)
 _PLAYER_LOW = [32, 108, -15, -1, -2, 0, 0, 0, 0, 0, 0, 0, 0]
@@ -61,40 +77,54 @@ def _raw_stream(device_index: int) -> int:
 _FLIGHT_TABLES = {}
 
 
-def flight_tables(device: torch.device):
-    """``(PzFlightTables, landing, power_hit)`` of `device`, built on first use."""
+def flight_tables(device: torch.device, landing: bool = True, power_hit: bool = True):
+    """``(PzFlightTables, landing, power_hit)`` of `device`; each table is built on first use and kept per device
+    (``landing``: 927 MB, ``power_hit``: 82 MB; a table that was not asked for is NULL in the struct)."""
     key = device.index
-    hit = _FLIGHT_TABLES.get(key)
-    if hit is None:
-        lib = _native.load()
+    have = _FLIGHT_TABLES.setdefault(key, {})
+    lib = _native.load()
+    want = [w for w, on in (("landing", landing), ("power_hit", power_hit)) if on and w not in have]
+    if want:
         with torch.cuda.device(device):
-            landing = torch.empty(lib.pz_flight_table_bytes(0), dtype=torch.uint8, device=device)
-            power_hit = torch.empty(lib.pz_flight_table_bytes(1), dtype=torch.uint8, device=device)
-            _native.check(lib.pz_build_flight_tables(landing.data_ptr(), power_hit.data_ptr(), _raw_stream(key)),
-                          "pz_build_flight_tables")
+            for which in want:
+                have[which] = torch.empty(lib.pz_flight_table_bytes(0 if which == "landing" else 1), dtype=torch.uint8,
+                                          device=device)
+            _native.check(lib.pz_build_flight_tables(have["landing"].data_ptr() if "landing" in want else None,
+                                                     have["power_hit"].data_ptr() if "power_hit" in want else None,
+                                                     _raw_stream(key)), "pz_build_flight_tables")
             torch.cuda.current_stream(device).synchronize()  # envs on other streams may use them right away
-        hit = _FLIGHT_TABLES[key] = (_native.PzFlightTables(landing.data_ptr(), power_hit.data_ptr()), landing,
-                                     power_hit)
-    return hit
+    t_landing = have["landing"] if landing else None
+    t_hit = have["power_hit"] if power_hit else None
+    return _native.PzFlightTables(_ptr(t_landing), _ptr(t_hit)), t_landing, t_hit
+
+
+def flight_table_bytes(mode=True) -> int:
+    """Device memory the flight tables of ``flight_tables=mode`` take (per process and device)."""
+    landing, power_hit = _TABLE_MODES[mode]
+    lib = _native.load()
+    return int(landing) * int(lib.pz_flight_table_bytes(0)) + int(power_hit) * int(lib.pz_flight_table_bytes(1))
 
 
 class _OutputSet:
     """One set of the buffers a step writes (observations, rewards, terminations) with what is cached per set: the raw
     pointers, the `pz_step_bind` block and the result tuple ``step()`` returns (its dicts hold views of these buffers)."""
 
-    __slots__ = ("obs", "rew", "term_u8", "term", "ptrs", "bound", "bound_key", "result")
+    __slots__ = ("obs", "rew", "term_u8", "term", "ptrs", "bound", "bound_key", "result", "result_key")
 
     def __init__(self, obs, rew, term_u8, state_ptr):
         self.obs, self.rew, self.term_u8 = obs, rew, term_u8
         self.term = term_u8.view(torch.bool)
         self.ptrs = (state_ptr, obs[0].data_ptr(), obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(),
                      term_u8.data_ptr())
-        self.bound = None       # ctypes block filled by pz_step_bind
-        self.bound_key = None   # the configuration it was bound for (_result_key)
+        # per action format (pz_action_format 0..3): the ctypes block filled by pz_step_bind and the configuration it was
+        # bound for (_result_key) -- the block of a format is bound when a tensor of that dtype first comes in
+        self.bound = [None] * 4
+        self.bound_key = [None] * 4
         self.result = None
+        self.result_key = None
 
 
-class raw_env:
+class raw_env(ParallelEnv):
     """``pikazoo_v0.raw_env`` for ``num_envs`` games at once.
 
     Reference kwargs (pikazoo_env.py:79-86): ``winning_score``, ``serve`` in {"winner",
@@ -121,8 +151,17 @@ class raw_env:
     has not.  The offending game's input for that frame is undefined; no other game and no memory is affected); ``scalar_api`` (``num_envs == 1`` only: return numpy rows / Python
     scalars and empty ``agents`` on termination, i.e. the reference's exact return types;
     ``auto_reset`` then defaults to False, so that ``while env.agents:`` loops end like they do around
-    the reference); ``flight_tables`` (computer players only: look the flight predictions up in the
-    per-device HBM tables instead of iterating them in the kernel; results are identical);
+    the reference); ``flight_tables`` (computer players only: ``True`` / ``"both"``: look both flight predictions up in
+    per-device HBM tables -- 927 MB for the landing point + 82 MB for the six power-hit candidates, per process and device;
+    ``"power_hit"``: only the 82 MB table -- the candidates are what diverges, the landing point is one closed-form flight
+    and, with ``landing_reuse``, only predicted on the frames that interrupt a flight; ``False``: everything computed in
+    the kernel; results are identical in all three); ``landing_reuse`` (computer players only, default on: the kernels
+    note per game -- one byte -- that the stored ``expected_landing_point_x`` belongs to the stored ball and skip the
+    landing prediction along a free flight, where the reference recomputes the same value on every frame
+    (physics.py:314-315); the 44 state words stay the reference's bit for bit.  The notes are dropped whenever anything
+    but a step launch writes the state: :meth:`set_state`, ``reset``, and any torch operation on :attr:`state` or a view
+    of it -- the env watches the tensor's version counter before every launch; somebody who writes the state through its
+    raw pointer, or between replays of a captured hipGraph, calls :meth:`invalidate_landing`);
     ``state_format`` ("int32": the state lives in HBM as the ``int32[44, num_envs]`` tensor :attr:`state`,
     live and writable; "packed": as 36 bytes per game instead of 176 -- the bit-packed format of
     ``include/pikazoo_hip.h`` -- which makes large batches about a third faster; every result is identical,
@@ -154,10 +193,10 @@ class raw_env:
     def __init__(self, winning_score: int = 15, serve: str = "winner", is_player1_computer: bool = False,
                  is_player2_computer: bool = False, render_mode=None, *, num_envs: int = 1,
                  device="cuda", seed: int = 0, env_id_base: int = 0, auto_reset: Optional[bool] = None,
-                 validate_actions: bool = True, scalar_api: bool = False, flight_tables: bool = True,
+                 validate_actions: bool = True, scalar_api: bool = False, flight_tables=True,
                  sprite_dir=None, sprites=None, state_format: str = "int32", scenery: bool = False,
                  observation_dtype=torch.int32, output_ring: int = 1, place_trajectories: bool = True,
-                 validate_every: int = 64):
+                 validate_every: int = 64, landing_reuse: Optional[bool] = None):
         assert serve in ("winner", "alternate", "random")  # pikazoo_env.py:104
         if render_mode not in (None, "rgb_array"):
             raise NotImplementedError('render_mode must be None or "rgb_array" (no "human" window on a GPU batch)')
@@ -177,6 +216,8 @@ class raw_env:
             raise ValueError("the packed state format holds scores up to 32767")
         if int(output_ring) < 1:
             raise ValueError("output_ring must be >= 1")
+        if not isinstance(flight_tables, (bool, str, type(None))) or flight_tables not in _TABLE_MODES:
+            raise ValueError('flight_tables must be True / "both", "power_hit" or False / "none"')
         self._lib = _native.load()  # raises when the HIP library has not been built
         self._step_bound = self._lib.pz_step_bound
         self.device = torch.device(device)
@@ -236,18 +277,29 @@ class raw_env:
         self._cfg_version = 0  # bumped by every _fuse_* method
         self._unfused = []           # wrapper classes of this stack that apply themselves outside the kernel (_fuse_*)
         self._unfused_reward = False
-        # the action tensors step() saw last: (weak reference, data pointer) of a tensor that passed the format checks
-        self._a1_seen = self._a2_seen = (lambda: None, 0)
+        # the action tensors step() saw last: (weak reference, data pointer, dtype, pz_action_format) of a tensor that
+        # passed the format checks
+        self._a1_seen = self._a2_seen = (lambda: None, 0, None, 0)
         self._tables = None
         self._tables_ref = None  # `const pz_flight_tables*` of every step call (None: compute in the kernel)
-        if flight_tables and (cfg.p1_computer or cfg.p2_computer):
-            self._tables = globals()["flight_tables"](self.device)
+        computer = bool(cfg.p1_computer or cfg.p2_computer)
+        self.flight_tables = "none"
+        if computer and any(_TABLE_MODES[flight_tables]):
+            self.flight_tables = "both" if all(_TABLE_MODES[flight_tables]) else "power_hit"
+            self._tables = globals()["flight_tables"](self.device, *_TABLE_MODES[flight_tables])
             self._tables_ref = C.byref(self._tables[0])
 
         n, dev = self.num_envs, self.device
         # columns are padded to a multiple of 64 games so that every workgroup's 256-byte segment of a column is
         # aligned whatever num_envs is (a ragged pitch costs ~10 % per launch); `state` is the [44, n] view
         self._stride = (n + 63) // 64 * 64
+        # landing_reuse: pz_config.landing_fresh, one byte per game the step kernels maintain (see the class docstring)
+        self.landing_reuse = computer and (True if landing_reuse is None else bool(landing_reuse))
+        self._fresh = None
+        self._state_version = 0  # torch's version counter of the state tensor when the notes were last known to hold
+        if self.landing_reuse:
+            self._fresh = torch.zeros(self._stride, dtype=torch.uint8, device=self.device)
+            cfg.landing_fresh = self._fresh.data_ptr()
         if cfg.packed_state:
             # group A [stride][4] dwords, group B [stride][4] dwords, tail [stride] dwords (include/pikazoo_hip.h)
             self._state_buf = torch.zeros(_native.PACKED_BYTES_PER_GAME * self._stride, dtype=torch.uint8, device=dev)
@@ -259,6 +311,7 @@ class raw_env:
             self._state_view = self._state_buf[:, :n]
             self._scores = self._state_view[_E_SCORE_P1:_E_SCORE_P1 + 2].t()  # live [n, 2] view of the state
         self._state_ptr = self._state_buf.data_ptr()
+        self._state_version = self._state_buf._version
         # the output buffers: `output_ring` sets, used in rotation (one set: every step overwrites the last results)
         self._ring = []
         for _ in range(int(output_ring)):
@@ -302,18 +355,23 @@ class raw_env:
             self._ring_pos = (self._ring_pos + 1) % len(self._ring)
             self._use_outputs(self._ring[self._ring_pos])
 
-    def _bound_step(self):
-        """The current output set's `pz_step_bind` block for the current configuration (bound on first use; a wrapper
-        fused later, or statistics switched on, re-binds)."""
+    def _bound_step(self, fmt: int = 0):
+        """The current output set's `pz_step_bind` block for the current configuration and the action format `fmt`
+        (bound on first use; a wrapper fused later, or statistics switched on, re-binds)."""
         out, key = self._out, self._result_key()
-        if out.bound is None or out.bound_key != key:
-            if out.bound is None:
-                out.bound = C.create_string_buffer(int(self._lib.pz_step_bound_bytes()))
+        if out.bound[fmt] is None or out.bound_key[fmt] != key:
+            if out.bound[fmt] is None:
+                out.bound[fmt] = C.create_string_buffer(int(self._lib.pz_step_bound_bytes()))
             p = out.ptrs
-            _native.check(self._lib.pz_step_bind(out.bound, p[0], self.num_envs, self._stride, self._cfg_ref, p[1], p[2],
-                                                 p[3], p[4], p[5], self._stats_ptr(), self._tables_ref), "pz_step_bind")
-            out.bound_key = key
-        return out.bound
+            self._cfg.action_format = fmt  # (the block copies the configuration; every other call takes int32)
+            try:
+                _native.check(self._lib.pz_step_bind(out.bound[fmt], p[0], self.num_envs, self._stride, self._cfg_ref, p[1],
+                                                     p[2], p[3], p[4], p[5], self._stats_ptr(), self._tables_ref),
+                              "pz_step_bind")
+            finally:
+                self._cfg.action_format = 0
+            out.bound_key[fmt] = key
+        return out.bound[fmt]
 
     def _stream(self):
         """Raw handle of the caller's current stream on this env's device (every launch goes there)."""
@@ -345,6 +403,23 @@ class raw_env:
         if self._state_view is not None:
             return self._state_view
         return self._unpacked()[0][:, :self.num_envs]
+
+    def read_state(self) -> torch.Tensor:
+        """A copy of the game state as ``int32[44, num_envs]`` (either format)."""
+        if self._state_view is not None:
+            return self._state_view.clone()
+        return self._unpacked()[0][:, :self.num_envs]
+
+    def invalidate_landing(self):
+        """Somebody other than the step kernels wrote the state: every game's stored landing point is taken as stale
+        (``pz_config.landing_fresh`` is cleared; the next frame predicts again -- see ``landing_reuse``).  The env calls
+        this itself for :meth:`set_state` and for torch operations on :attr:`state` (it watches the tensor's version
+        counter); a writer it cannot see -- a raw-pointer kernel, a write between replays of a captured graph -- calls
+        it.  A no-op without a computer player."""
+        if self._fresh is not None:
+            self._fresh.zero_()
+            self._state_version = self._state_buf._version
+
 
     def _unpacked(self):
         """(int32[44, stride] copy of the packed state, its stride)"""
@@ -385,6 +460,7 @@ class raw_env:
             raise ValueError(f"state must be int32[{_native.STATE_WORDS}, {self.num_envs}]")
         if self._state_view is not None:
             self._state_view.copy_(state)
+            self.invalidate_landing()
             return
         src = state.contiguous()
         misfits = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -395,6 +471,7 @@ class raw_env:
         if int(misfits.item()):
             raise ValueError(f"{int(misfits.item())} games hold values outside the packed format's fields")
         self._state_buf.copy_(staged)
+        self.invalidate_landing()
 
     @property
     def packed_misfits(self) -> int:
@@ -640,10 +717,12 @@ class raw_env:
         elif a.device != self.device:
             a = a.to(self.device)
         a = a.reshape(-1)
-        if a.dtype != torch.int32:
-            if a.dtype.is_floating_point or a.dtype == torch.bool:
+        if a.dtype not in _ACTION_FORMAT:
+            # int32 / int64 / uint8 / int16 go into the launch as they are (pz_action_format: no cast kernel, and the
+            # range check sees the full value); the remaining integer dtypes are widened, which cannot wrap
+            if a.dtype.is_floating_point or a.dtype == torch.bool or a.dtype.is_complex:
                 raise TypeError(f"actions must be integer tensors, got {a.dtype}")
-            a = a.to(torch.int32)
+            a = a.to(torch.int64 if a.dtype in (getattr(torch, "uint32", None), getattr(torch, "uint64", None)) else torch.int32)
         a = a.contiguous()
         if a.numel() != self.num_envs:
             raise ValueError(f"expected {self.num_envs} actions per agent, got {a.numel()}")
@@ -658,36 +737,46 @@ class raw_env:
         a1 = actions["player_1"]  # KeyError on a missing agent
         a2 = actions["player_2"]
         n = self.num_envs
-        # fast path: an int32 device tensor of the right size needs no conversion.  A tensor OBJECT that passed once (a
-        # policy writing its actions into the same buffer every step) is recognised by identity + data pointer and only
-        # re-checked for what an in-place operation can change without moving it (dtype, size, strides: `set_`,
-        # `as_strided_`, `.data = ...`) -- the host side of a step has to stay below the duration of the launch it
-        # issues.  The env keeps a weak reference only.
-        seen, seen_ptr = self._a1_seen
+        # fast path: an int32 / int64 / uint8 / int16 device tensor of the right size needs no conversion: the launch
+        # reads the caller's element type (pz_action_format; torch's default integer dtype is int64).  A tensor OBJECT
+        # that passed once (a policy writing its actions into the same buffer every step) is recognised by identity + data
+        # pointer and only re-checked for what an in-place operation can change without moving it (dtype, size, strides:
+        # `set_`, `as_strided_`, `.data = ...`) -- the host side of a step has to stay below the duration of the launch
+        # it issues.  The env keeps a weak reference only.
+        seen, seen_ptr, seen_dtype, f1 = self._a1_seen
         p1 = a1.data_ptr() if type(a1) is torch.Tensor else 0
-        if not (seen() is a1 and p1 == seen_ptr and a1.dtype is torch.int32 and a1.numel() == n and a1.is_contiguous()):
-            if not (type(a1) is torch.Tensor and a1.dtype is torch.int32 and a1.get_device() == self._dev_index
+        if not (seen() is a1 and p1 == seen_ptr and a1.dtype is seen_dtype and a1.numel() == n and a1.is_contiguous()):
+            if not (type(a1) is torch.Tensor and a1.dtype in _ACTION_FORMAT and a1.get_device() == self._dev_index
                     and a1.numel() == n and a1.is_contiguous()):
                 a1 = self._action_tensor(a1)
                 p1 = a1.data_ptr()
+                f1 = _ACTION_FORMAT[a1.dtype]
             else:
-                self._a1_seen = (weakref.ref(a1), p1)
-        seen, seen_ptr = self._a2_seen
+                f1 = _ACTION_FORMAT[a1.dtype]
+                self._a1_seen = (weakref.ref(a1), p1, a1.dtype, f1)
+        seen, seen_ptr, seen_dtype, f2 = self._a2_seen
         p2 = a2.data_ptr() if type(a2) is torch.Tensor else 0
-        if not (seen() is a2 and p2 == seen_ptr and a2.dtype is torch.int32 and a2.numel() == n and a2.is_contiguous()):
-            if not (type(a2) is torch.Tensor and a2.dtype is torch.int32 and a2.get_device() == self._dev_index
+        if not (seen() is a2 and p2 == seen_ptr and a2.dtype is seen_dtype and a2.numel() == n and a2.is_contiguous()):
+            if not (type(a2) is torch.Tensor and a2.dtype in _ACTION_FORMAT and a2.get_device() == self._dev_index
                     and a2.numel() == n and a2.is_contiguous()):
                 a2 = self._action_tensor(a2)
                 p2 = a2.data_ptr()
+                f2 = _ACTION_FORMAT[a2.dtype]
             else:
-                self._a2_seen = (weakref.ref(a2), p2)
+                f2 = _ACTION_FORMAT[a2.dtype]
+                self._a2_seen = (weakref.ref(a2), p2, a2.dtype, f2)
+        if f1 != f2:  # one launch reads one element type: two dtypes meet in int64, which holds all four
+            a1, a2 = self._action_tensor(a1).to(torch.int64), self._action_tensor(a2).to(torch.int64)
+            p1, p2, f1 = a1.data_ptr(), a2.data_ptr(), 1
+        if self._fresh is not None and self._state_buf._version != self._state_version:
+            self.invalidate_landing()  # (a torch operation wrote the state tensor since the last launch: landing_reuse)
         if len(self._ring) > 1:
             self._next_outputs()
         self._last_traj = None  # (this launch overwrites the single-frame buffers)
         out = self._out
         # pz_step through its prepared-argument form: one FFI call with four scalars (the twelve buffers and the
         # configuration were bound once) -- the host side of a step stays below the duration of the launch it issues
-        bound = out.bound if out.bound_key == self._cfg_version else self._bound_step()
+        bound = out.bound[f1] if out.bound_key[f1] == self._cfg_version else self._bound_step(f1)
         if _get_device() == self._dev_index:
             rc = self._step_bound(bound, p1, p2, _raw_stream(self._dev_index))
         else:
@@ -707,10 +796,9 @@ class raw_env:
         if self.scalar_api:
             self.check_actions()  # (this API synchronises on every step anyway: the reference's error on the step itself)
             return self._pack_step()
-        res = out.result
-        if res is None or res[0] != out.bound_key:
-            res = out.result = (out.bound_key, self._pack_step())
-        return res[1]
+        if out.result is None or out.result_key != self._cfg_version:
+            out.result, out.result_key = self._pack_step(), self._cfg_version
+        return out.result
 
     # ---- out-of-range actions (validate_actions) -------------------------------------------------------------------
     def _raise_action_fault(self):
@@ -748,6 +836,8 @@ class raw_env:
         ``action_seed``, step indices ``t0 .. t0+k-1``; ``t0`` defaults to ``steps_done``) in ONE
         launch.  Returns the last frame's step tuple."""
         self._no_unfused_wrappers("step_random")
+        if self._fresh is not None and self._state_buf._version != self._state_version:
+            self.invalidate_landing()
         if t0 is None:
             t0 = self.steps_done
         self._next_outputs()
@@ -773,6 +863,8 @@ class raw_env:
         ``bool[k, N]``.  Bit-identical to ``k`` calls of ``step(random_actions(...))``; the state
         tensor is read and written once.  Pass the previous result as ``out`` to reuse its buffers."""
         self._no_unfused_wrappers("rollout_random")
+        if self._fresh is not None and self._state_buf._version != self._state_version:
+            self.invalidate_landing()
         if t0 is None:
             t0 = self.steps_done
         k, n, dev = int(k), self.num_envs, self.device
@@ -805,11 +897,20 @@ class raw_env:
         call this is asks with :meth:`check_actions` before it trusts the trajectory; with ``validate_every=1`` (strict)
         this call synchronises and raises itself."""
         self._no_unfused_wrappers("step_many")
+        if self._fresh is not None and self._state_buf._version != self._state_version:
+            self.invalidate_landing()
         n, dev = self.num_envs, self.device
         if actions.dim() != 3 or actions.shape[1] != 2 or actions.shape[2] != n:
             raise ValueError(f"actions must have shape [k, 2, {n}]")
+        if actions.dtype.is_floating_point or actions.dtype == torch.bool or actions.dtype.is_complex:
+            raise TypeError(f"actions must be an integer tensor, got {actions.dtype}")
+        if actions.dtype == torch.int64:
+            # the launch parks the tape from int32 rows; a plain cast would WRAP (2**32 + 3 -> 3) in front of its range
+            # check, so the narrowing saturates first: every out-of-range value stays out of range (-1 or 127), and the
+            # launch counts it like any other (two small torch launches per k frames, no synchronisation)
+            actions = actions.to(dev).clamp(-1, 127).to(torch.int32)
         if actions.dtype != torch.int32 or actions.device != dev or not actions.is_contiguous():
-            actions = actions.to(device=dev, dtype=torch.int32).contiguous()
+            actions = actions.to(device=dev, dtype=torch.int32).contiguous()  # (the smaller integer types: widened, exact)
         k = int(actions.shape[0])
         if k > 1 and n % self._traj_multiple() != 0:
             raise ValueError(f"step_many needs num_envs to be a multiple of {self._traj_multiple()}")

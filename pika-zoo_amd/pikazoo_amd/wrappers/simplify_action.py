@@ -45,18 +45,20 @@ class SimplifyAction(BaseParallelWrapper):
         for a in raw.possible_agents:
             v = actions[a]  # KeyError on a missing agent
             if isinstance(v, torch.Tensor) and v.device == raw.device:
-                # the reference indexes a 13-tuple the Python way: -13 .. -1 count from its end, anything else raises.
-                # Here: the same wrap-around, and an index outside [-13, 13) becomes the out-of-range action 255, which
-                # the env's validate_actions reports as that IndexError (without it nothing reports it: an un-fused
-                # SimplifyAction on device tensors relies on validate_actions, the constructor's default)
+                # An index outside [0, 13) becomes the out-of-range action 255, which the env's validate_actions reports
+                # as the reference's IndexError (without it nothing reports it: an un-fused SimplifyAction on device
+                # tensors relies on validate_actions, the constructor's default).  Negative indices too: the reference's
+                # tuple indexing would count -13 .. -1 from the end -- a Python accident, not an interface, and the fused
+                # form of this wrapper (and the env's own 18 actions) reject them; one meaning for both forms.
                 idx = v.to(torch.int64)
-                idx = torch.where(idx < 0, idx + 13, idx)
                 idx = torch.where((idx < 0) | (idx > 12), 13, idx)
                 mapped[a] = self._maps[a][idx]
-            else:  # host values: the reference's own indexing -- negative indices and IndexError included
+            else:  # host values: checked before anything is launched, like the env checks its own
                 import numpy as np
 
                 flat = np.asarray(v.cpu() if isinstance(v, torch.Tensor) else v).reshape(-1)
+                if flat.size and (int(flat.min()) < 0 or int(flat.max()) > 12):
+                    raise IndexError("action out of range [0, 13)")
                 out = np.array([ACTION_MAP[a][int(x)] for x in flat], dtype=np.int64)
                 mapped[a] = int(out[0]) if np.ndim(v) == 0 else out
         return self.env.step(mapped)

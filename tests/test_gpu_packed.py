@@ -332,7 +332,8 @@ def test_planted_fast_balls_follow_the_reference(name, fmt, tables):
     _replay_planted_through_hip(name, fmt, tables)
 
 
-@pytest.mark.parametrize("fmt,tables", [("int32", True), ("int32", False), ("packed", True), ("packed", False)])
+@pytest.mark.parametrize("fmt,tables", [("int32", True), ("int32", False), ("packed", True), ("packed", False),
+                                        ("int32", "power_hit"), ("packed", "power_hit")])
 @pytest.mark.parametrize("name", ["planted_random_states_human", "planted_random_states_both_computer",
                                   "planted_random_states_p2_computer_random_serve"])
 def test_random_planted_states_follow_the_reference(name, fmt, tables):

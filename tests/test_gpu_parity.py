@@ -49,9 +49,11 @@ AI_FIXTURES = ["cfg3_p2_computer", "p1_computer", "both_computer", "full_wrapper
 
 @pytest.mark.parametrize("name,tables,fmt", [(n, True, "int32") for n in FULL_FIXTURES] +
                          [(n, False, "int32") for n in AI_FIXTURES] + [(n, True, "packed") for n in FULL_FIXTURES] +
-                         [(n, False, "packed") for n in AI_FIXTURES])
+                         [(n, False, "packed") for n in AI_FIXTURES] +
+                         [(n, "power_hit", f) for n in AI_FIXTURES for f in ("int32", "packed")])
 def test_hip_matches_reference_trajectory(name, tables, fmt):
-    """`tables`: the computer player's flight predictions come from the HBM look-up tables (default) or are
+    """`tables`: the computer player's flight predictions come from the HBM look-up tables (default), from the 82 MB
+    power-hit table alone ("power_hit": the landing point predicted in the kernel), or are all
     iterated in the kernel (the scout-wave launch); fixtures without a computer player never use them.
     `fmt`: the state lives in HBM as int32 columns or in the packed format (36 bytes per game); `raw.state` is the
     same int32[44, lanes] either way."""
@@ -212,13 +214,14 @@ def _has_computer(kw):
 @pytest.mark.parametrize("case,tables,fmt", [(c, True, "int32") for c in CASES] +
                          [(c, False, "int32") for c in CASES if _has_computer(CASES[c]["kw"])] +
                          [(c, True, "packed") for c in CASES] +
-                         [(c, False, "packed") for c in ("cfg3_p2_computer", "both_computer_random_serve_ws2")])
+                         [(c, False, "packed") for c in ("cfg3_p2_computer", "both_computer_random_serve_ws2")] +
+                         [(c, "power_hit", f) for c in CASES if _has_computer(CASES[c]["kw"]) for f in ("int32", "packed")])
 def test_hip_matches_oracle_random_batches(case, tables, fmt, oracle):
     c = CASES[case]
     n, steps, kw, wr = c["n"], c["steps"], dict(c["kw"]), c.get("wr", {})
     seed, base, aseed = 99, 12345, 4242
     env = make_env(num_envs=n, seed=seed, env_id_base=base, wrappers=wr, flight_tables=tables, state_format=fmt, **kw)
-    assert (env.unwrapped._tables_ref is not None) == (tables and _has_computer(kw))
+    assert (env.unwrapped._tables_ref is not None) == (bool(tables) and _has_computer(kw))
     raw = env.unwrapped
     from oracle.ref_capture import fused_options
     ocfg = oracle.make_config(
@@ -344,7 +347,7 @@ def test_full_size_properties(n, kw, oracle):
 # ------------------------------------------------------------------------------------------------
 # 4. C ABI edge cases
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tables", [True, False])
+@pytest.mark.parametrize("tables", [True, "power_hit", False])
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 129])
 def test_small_and_ragged_sizes(n, tables, oracle):
     env = make_env(num_envs=n, seed=1, env_id_base=5, is_player1_computer=True, is_player2_computer=True,
@@ -868,7 +871,7 @@ def test_randomized_config_sweep_vs_oracle(oracle):
     (dict(winning_score=1, is_player2_computer=True), 60, 393216),
     (dict(winning_score=1, is_player1_computer=True, is_player2_computer=True, serve="random"), 60, 393216),
 ])
-@pytest.mark.parametrize("tables", [True, False])
+@pytest.mark.parametrize("tables", [True, "power_hit", False])
 def test_two_wave_and_single_wave_kernels_agree_across_the_size_switch(kw, steps, switch, tables, oracle):
     """Below 393 216 games pz_step runs two waves per 64 games (split by player; with a computer player and no
     flight tables: frame wave + scout wave for the flight predictions), from there on one: both sides of the
@@ -967,6 +970,8 @@ def test_human_vs_human_k_frame_launches_on_int16_rows_vs_oracle(fmt, oracle):
     ("random_random_pair_kernel", dict(), {}),
     ("cfg3_p2_computer_tables", dict(is_player2_computer=True), {}),
     ("cfg3_p2_computer_scout", dict(is_player2_computer=True, flight_tables=False), {}),
+    ("cfg3_p2_computer_power_hit_table", dict(is_player2_computer=True, flight_tables="power_hit"), {}),
+    ("cfg3_p2_computer_every_frame", dict(is_player2_computer=True, landing_reuse=False), {}),
     ("cfg5_fused_wrappers", dict(), dict(simplify_action=True,
                                          additional_reward=(0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01))),
 ])
@@ -976,7 +981,7 @@ def test_headline_size_every_lane_vs_oracle(name, kw, wr, oracle):
     from oracle.ref_capture import fused_options
 
     n, steps, seed, base, aseed = 65536, 320, 11, 1 << 33, 99
-    okw = {k: v for k, v in kw.items() if k != "flight_tables"}
+    okw = {k: v for k, v in kw.items() if k not in ("flight_tables", "landing_reuse")}
     env = make_env(num_envs=n, seed=seed, env_id_base=base, winning_score=2, wrappers=wr, **kw)
     raw = env.unwrapped
     ref = oracle.OracleEnv(n, oracle.make_config(winning_score=2, seed=seed, env_id_base=base, **okw,

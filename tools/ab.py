@@ -2,14 +2,20 @@
 """A/B timing of kernel build variants (diagnostic; cdna_hip_programming.md rule 24: interleaved
 rounds in ONE process, median and min reported).
 
-    python tools/ab.py --build [--common "-DPZ_DEV_SUBSET=705"] name1=-DFLAG1 name2="-DFLAG2 -DFLAG3" ...   # here: cross-compile variants
+    python tools/ab.py --build [--subset 705] name1=BITS name2=BITS ...    # here: cross-compile variants
     python tools/ab.py [--ai] [--n 65536] [--rollout K] name1 name2 ...    # on the GPU box: time them
                                                                            # (--rollout: pz_rollout_random, K frames/launch)
-    a name with the suffix "+t" runs that library WITH the flight look-up tables (pz_flight_tables), "+p" on the
-    packed state format, "+h" with int16 observations, combined at will, e.g. `python tools/ab.py --ai base base+t base+tph`
+    a name with the suffix "+t" runs that library WITH both flight look-up tables (pz_flight_tables), "+q" with the
+    power-hit table alone, "+f" with the landing-freshness bytes (pz_config.landing_fresh: the landing point predicted
+    only where a flight is interrupted), "+p" on the packed state format, "+h" with int16 observations, combined at will,
+    e.g. `python tools/ab.py --ai base+t base+tf base+qf base+f`: run-time variants of ONE library.
 
-A variant named "base" is always built with no extra flags.  Libraries go to
-pika-zoo_amd/lib/ab_<name>.so (git-ignored, shipped by gpurun).
+Compile-time variants are DIAGNOSTIC builds (pika-zoo_amd/csrc/pz_diagnostic.hpp: the one switch of the kernel
+sources): BITS are the low 16 bits of -DPZ_DIAGNOSTIC_BUILD (1 stamps, 2 no pair kernel, 4 no rollout pair kernel,
+8 no scout wave, 16 early stores without the hand-shake, 32 no early stores, N << 8 hold the computer's wave back),
+--subset the kernel families to instantiate (bits 16-29: a variant then builds in seconds).  A variant named "base"
+is always built with BITS = 0.  Libraries go to tools/bin/ab_<name>.so (git-ignored, shipped by gpurun); the product
+path pika-zoo_amd/lib/ never holds one.
 """
 import ctypes as C
 import statistics
@@ -20,33 +26,40 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO / "pika-zoo_amd"))
 from build import FLAGS as PRODUCT_FLAGS  # noqa: E402  (same compiler flags as the product library)
-LIBDIR = REPO / "pika-zoo_amd" / "lib"
+LIBDIR = REPO / "tools" / "bin"
+LIB_ALIASES = {}
 
 
-def build(name, flags):
+def diag_bits(bits=0, subset=0):
+    """The value of -DPZ_DIAGNOSTIC_BUILD (pz_diagnostic.hpp): switches in the low 16 bits, kernel subset in bits 16-29."""
+    return (int(subset) << 16) | (int(bits) & 0xFFFF)
+
+
+def build(name, bits, subset):
     out = LIBDIR / f"ab_{name}.so"
-    cmd = ["hipcc", *PRODUCT_FLAGS, "-shared", "-fPIC", *flags.split(),
+    cmd = ["hipcc", *PRODUCT_FLAGS, "-shared", "-fPIC", f"-DPZ_DIAGNOSTIC_BUILD={diag_bits(bits, subset)}u",
            f"-I{REPO / 'include'}", f"-I{REPO / 'pika-zoo_amd' / 'csrc'}", "-o", str(out),
            str(REPO / "pika-zoo_amd" / "csrc" / "pz_kernels.hip")]
     subprocess.check_call(cmd)
-    print("built", out.name, flags)
+    print("built", out.name, f"bits={bits} subset={subset}")
 
 
 def main():
     args = sys.argv[1:]
     if args and args[0] == "--build":
-        # --common "-DPZ_DEV_SUBSET=bits": flags for every variant incl. base (pz_kernels.hip: keep only the kernel
-        # families the run will launch -- seconds instead of 100 s per variant); the variants compile in parallel
+        # --subset bits: for every variant incl. base (pz_kernels.hip dev_keep: only the kernel families the run will
+        # launch -- seconds instead of 100 s per variant); the variants compile in parallel
         from concurrent.futures import ThreadPoolExecutor
 
         LIBDIR.mkdir(exist_ok=True)
         specs = args[1:]
-        common = ""
-        if "--common" in specs:
-            at = specs.index("--common")
-            common = specs[at + 1]
+        subset = 0
+        if "--subset" in specs:
+            at = specs.index("--subset")
+            subset = int(specs[at + 1], 0)
             del specs[at:at + 2]
-        jobs = [("base", common)] + [(name, f"{common} {flags}") for name, _, flags in (s.partition("=") for s in specs)]
+        jobs = [("base", 0, subset)] + [(name, int(bits, 0), subset) for name, _, bits in (s.partition("=") for s in specs)
+                                        if name != "base"]
         with ThreadPoolExecutor(max_workers=6) as pool:
             list(pool.map(lambda j: build(*j), jobs))
         return
@@ -61,6 +74,11 @@ def main():
     rollout = int(args[args.index("--rollout") + 1]) if "--rollout" in args else 0
     tape = "--tape" in args  # with --rollout K: pz_step_many on an action tape instead of pz_rollout_random
     names = [a for a in args if not a.startswith("--") and not a.isdigit()]
+    if "--lib" in args:  # e.g. --lib product=pika-zoo_amd/lib/libpikazoo_hip.so: a library by path under a variant name
+        at = args.index("--lib")
+        alias, _, path = args[at + 1].partition("=")
+        LIB_ALIASES[alias] = Path(path)
+        names = [a for a in names if a != args[at + 1]]
     no_check = "--no-check" in args  # variants that change the stored state legitimately
     # the variant every other one is compared with: "base", or the first "base+..." given (e.g. base+t: with the tables)
     ref = "base" if "base" in names else next((nm for nm in names if nm.startswith("base+")), None)
@@ -76,7 +94,7 @@ def main():
         if file in loaded:
             libs[nm] = loaded[file]
             continue
-        lib = loaded[file] = C.CDLL(str(LIBDIR / f"ab_{file}.so"))
+        lib = loaded[file] = C.CDLL(str(LIB_ALIASES.get(file, LIBDIR / f"ab_{file}.so")))
         lib.pz_init.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P]
         lib.pz_reset.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P]
         lib.pz_step.argtypes = [P, C.c_int64, C.c_int64, C.POINTER(_native.PzConfig), P, P, P, P, P, P, P, P, P, P]
@@ -117,12 +135,17 @@ def main():
     acts = torch.randint(0, 13 if wrappers else 18, (slices, 2, n), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     base = libs[ref]
-    tables = None
-    if any("t" in mods(nm) for nm in names):
+    tables = tables_hit = None
+    if any("t" in mods(nm) or "q" in mods(nm) for nm in names):
         t_land = torch.empty(base.pz_flight_table_bytes(0), dtype=torch.uint8, device=dev)
         t_hit = torch.empty(base.pz_flight_table_bytes(1), dtype=torch.uint8, device=dev)
         assert base.pz_build_flight_tables(t_land.data_ptr(), t_hit.data_ptr(), stream) == 0
         tables = _native.PzFlightTables(t_land.data_ptr(), t_hit.data_ptr())
+        tables_hit = _native.PzFlightTables(None, t_hit.data_ptr())  # "+q": the power-hit table alone
+    # "+f": the landing-freshness bytes of that variant's state (pz_config.landing_fresh)
+    fresh = {nm: torch.zeros(n, dtype=torch.uint8, device=dev) for nm in names if "f" in mods(nm)}
+    for nm, buf in fresh.items():
+        cfgs[nm].landing_fresh = buf.data_ptr()
     for nm in names:
         assert libs[nm].pz_init(states[nm].data_ptr(), n, n, C.byref(cfgs[nm]), stream) == 0
         obs = obs16 if "h" in mods(nm) else obs32
@@ -146,7 +169,7 @@ def main():
     def run(nm, steps):
         lib = libs[nm]
         state = states[nm]
-        tb = C.byref(tables) if "t" in mods(nm) else None
+        tb = C.byref(tables) if "t" in mods(nm) else (C.byref(tables_hit) if "q" in mods(nm) else None)
         cfg = cfgs[nm]
         obs = obs16 if "h" in mods(nm) else obs32
         if rollout:
@@ -170,16 +193,24 @@ def main():
             assert rc == 0, (nm, rc)  # (-3: a PZ_DEV_SUBSET build without this launch's kernel family)
         return steps
 
-    snapshots = {}
+    snapshots, fresh_snap = {}, {}
     for nm in names:
         run(nm, 700)
         snapshots[nm] = states[nm].clone()
+        if nm in fresh:
+            fresh_snap[nm] = fresh[nm].clone()
     torch.cuda.synchronize()
+
+    def restore(nm):
+        states[nm].copy_(snapshots[nm])
+        if nm in fresh:
+            fresh[nm].copy_(fresh_snap[nm])
+
     # every variant must produce the same trajectory as base (compared on the outputs; the state only between
     # variants of the same layout)
     finals = {}
     for nm in names:
-        states[nm].copy_(snapshots[nm])
+        restore(nm)
         run(nm, 128)
         torch.cuda.synchronize()
         o = obs16 if "h" in mods(nm) else obs32
@@ -200,7 +231,7 @@ def main():
     if not eager:
         stream_holder = [stream]
         for nm in names:
-            states[nm].copy_(snapshots[nm])
+            restore(nm)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.stream(side):
@@ -218,7 +249,7 @@ def main():
                 graphs[names[-1]].replay()
             torch.cuda.synchronize()
         for nm in names:
-            states[nm].copy_(snapshots[nm])
+            restore(nm)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             if eager:

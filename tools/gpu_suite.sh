@@ -4,6 +4,11 @@
 # that fails ends the script: no GPU step is started behind a failed one.
 #
 #   check   GPU test suite, __graft_entry__.smoke(), the default bench line (+ its --configs-out file)
+#   check_every_frame  the GPU test suite once more with the reference's own rule as the default of every env it builds:
+#           the computer player's landing point predicted on EVERY frame (PZ_TEST_LANDING_REUSE=0, tests/conftest.py)
+#   reuse   round 6's A/B: config 3 with and without the landing-freshness bytes (pz_config.landing_fresh), in the three
+#           flight-table modes, interleaved in one process on one library (cold and hot action tape), then the early stores
+#           of DESIGN 4.2 re-measured on top of it (kill criterion of the hand-shake: < 1 %)
 #   bench   the default bench line and the --extra line only
 #   driver  the bench line exactly as the driver runs it (--steps 20 --warmup 5)
 #   variants  the bench line's other workloads and launch modes, headline only (--no-configs): config 3, config 5, packed,
@@ -11,13 +16,10 @@
 #           a line with its in-run oracle parity true
 #   edge    config 3's early stores: A/B of the LDS hand-shake against round 4's unordered form and against no
 #           early stores, then the deterministic proof of the edge: the computer's wave held back ~16 000 cycles in front of
-#           its first load must stay bit-exact with the hand-shake and breaks without it.  Variants (build here first):
-#             python tools/ab.py --build --common "-DPZ_DEV_SUBSET=705" unordered=-DPZ_DEV_UNORDERED_EARLY_STORES \
-#                 early0=-DPZ_EARLY_OWN_STORES=0 delayedge=-DPZ_DEV_DELAY_PARTNER_LOADS=2 \
-#                 delayunordered="-DPZ_DEV_DELAY_PARTNER_LOADS=2 -DPZ_DEV_UNORDERED_EARLY_STORES"
+#           its first load must stay bit-exact with the hand-shake and breaks without it.  The variants are diagnostic
+#           builds (csrc/pz_diagnostic.hpp), compiled on the box by the case itself (subset 705: seconds each)
 #   edge_soak  the one-computer configurations (config 3, p1 computer) for 60 000 frames against the oracle on a build whose
-#           computer's wave is ALWAYS late (-DPZ_DEV_DELAY_PARTNER_LOADS=1, full library: python tools/ab.py --build
-#           delayfull=-DPZ_DEV_DELAY_PARTNER_LOADS=1): every launch takes the hand-shake's late-store path
+#           computer's wave is ALWAYS late (bits 8-15 = 1, full library): every launch takes the hand-shake's late-store path
 #   chains  one batch as two / four sub-batch chains in ONE hipGraph (fork / join at its ends) and as separate graphs on
 #           separate streams, human vs human and config 3, 65 536 and 131 072 games (tools/chains.py)
 #   soak    long parity runs against the CPU oracle on every lane (tests/soak.py), single-frame and k-frame, both formats
@@ -25,7 +27,7 @@
 #   profile tools/profile.sh TAG (all sections): the rocprofv3 evidence of the round
 set -u
 CASE=${1:?case}
-TAG=${2:-r05_$CASE}
+TAG=${2:-r06_$CASE}
 O=gpurun_out/$TAG
 mkdir -p "$O"
 step() {  # seconds, log, command...: run one step, stop the script when it fails
@@ -86,14 +88,32 @@ for path in sys.argv[1:]:
 sys.exit(1 if bad else 0)
 PY
     ;;
+check_every_frame)
+    export PZ_TEST_LANDING_REUSE=0
+    step 1100 gputest_every_frame.log python3 -m pytest tests -m gpu -x -q
+    tail -n 4 "$O/gputest_every_frame.log"
+    ;;
+reuse)
+    # (pz_diagnostic.hpp bits: 32 = no early stores, 16 = early stores without the hand-shake; subset 2753 = the single-frame
+    # kernels -- pair and single-wave / scout --, human vs human and player 2 = computer)
+    step 600 build_variants.log python3 tools/ab.py --build --subset 2753 early0=32 unordered=16
+    step 400 ab_landing_reuse_cold_tape.log python3 tools/ab.py --ai --slices 2048 --samples base+t base+tf base+q base+qf base base+f
+    step 400 ab_landing_reuse_hot_tape.log python3 tools/ab.py --ai --samples base+t base+tf base+q base+qf base base+f
+    step 400 ab_landing_reuse_packed_cold_tape.log python3 tools/ab.py --ai --slices 2048 base+tp base+tpf base+qp base+qpf
+    step 400 ab_early_stores_on_top_of_reuse_cold_tape.log python3 tools/ab.py --ai --slices 2048 --samples base+tf early0+tf unordered+tf base+qf early0+qf
+    step 400 ab_early_stores_on_top_of_reuse_hot_tape.log python3 tools/ab.py --ai --samples base+tf early0+tf unordered+tf
+    tail -n 9 "$O"/ab_*.log
+    ;;
 edge)
+    step 600 build_variants.log python3 tools/ab.py --build --subset 705 unordered=16 early0=32 delayedge=0x200 delayunordered=0x210
     step 300 ab_early_store_edge_cold_tape.log python3 tools/ab.py --ai --slices 2048 base+t unordered+t early0+t
     step 300 ab_early_store_edge_hot_tape.log python3 tools/ab.py --ai base+t unordered+t early0+t
     step 300 early_store_edge_partner_held_back.log python3 tools/ab.py --ai --slices 2048 base+t delayedge+t delayunordered+t
     tail -n 8 "$O"/*.log
     ;;
 edge_soak)
-    step 600 soak_one_computer_partner_always_late_65536x60000.log python3 tests/soak.py --frames 60000 --every 10000 --only "computer, flight tables" --lib pika-zoo_amd/lib/ab_delayfull.so
+    step 900 build_variants.log python3 tools/ab.py --build delayfull=0x100
+    step 600 soak_one_computer_partner_always_late_65536x60000.log python3 tests/soak.py --frames 60000 --every 10000 --only "computer, flight tables" --lib tools/bin/ab_delayfull.so
     tail -n 4 "$O"/soak_one_computer*.log
     ;;
 chains)

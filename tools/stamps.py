@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-wave timeline of one step launch (diagnostic build with -DPZ_STAMPS; not product).
+"""Per-wave timeline of one step launch (diagnostic build, pz_diagnostic.hpp bit 0 = stamps; not product).
 
     python tools/stamps.py --build ; python tools/stamps.py [--ai [--tables]] [--packed] [--n N]     (second on the GPU box)
 
@@ -18,13 +18,13 @@ import numpy as np
 REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO / "pika-zoo_amd"))
 from build import FLAGS as PRODUCT_FLAGS  # noqa: E402  (same compiler flags as the product library)
-LIB = REPO / "pika-zoo_amd" / "lib" / "stamps.so"
+LIB = REPO / "tools" / "bin" / "stamps.so"
 
 
 def main():
     args = sys.argv[1:]
     if "--build" in args:
-        subprocess.check_call(["hipcc", *PRODUCT_FLAGS, "-shared", "-fPIC", "-DPZ_STAMPS=1",
+        subprocess.check_call(["hipcc", *PRODUCT_FLAGS, "-shared", "-fPIC", "-DPZ_DIAGNOSTIC_BUILD=1u",
                                f"-I{REPO / 'include'}", f"-I{REPO / 'pika-zoo_amd' / 'csrc'}", "-o", str(LIB),
                                str(REPO / "pika-zoo_amd" / "csrc" / "pz_kernels.hip")])
         return
