@@ -259,7 +259,7 @@ def test_a_fresh_note_means_the_stored_point_is_the_stored_balls_prediction(kw, 
             for l in np.flatnonzero(fresh)[::7]:
                 assert st[36, l] == oracle.expected_landing_x(int(st[26, l]), int(st[27, l]), int(st[28, l]), int(st[29, l])), (t, l)
                 checked += 1
-    assert checked > 1000
+    assert checked > 500
 
 
 @pytest.mark.parametrize("fmt", ["int32", "packed"])
