@@ -99,9 +99,6 @@ def parse_args():
     ap.add_argument("--flight-tables", choices=["both", "power_hit", "none"], default=None,
                     help="computer players: which flight look-up tables the launches use (both: 927 + 82 MB per device, "
                          "power_hit: the 82 MB one, none: everything predicted in the kernel); default both")
-    ap.add_argument("--no-landing-reuse", action="store_true",
-                    help="computer players: predict the landing point on every frame like the reference (pz_config."
-                         "landing_fresh = NULL) instead of only on the frames that interrupt a flight")
     ap.add_argument("--action-dtype", choices=["int32", "int64", "uint8", "int16"], default="int32",
                     help="element type of the action tensors the launches read (pz_action_format)")
     ap.add_argument("--state-format", choices=["int32", "packed"], default="int32",
@@ -131,15 +128,14 @@ def parse_args():
 
 
 def make_env(shard, device, *, num_envs, p1_computer=False, p2_computer=False, wrappers=False, flight_tables=True,
-             state_format="int32", obs16=False, validate_actions=False, landing_reuse=None):
+             state_format="int32", obs16=False, validate_actions=False):
     from pikazoo_amd.wrappers import RewardByBallPosition, SimplifyAction
 
     env = pikazoo_v0.env(winning_score=15, serve="winner", is_player2_computer=p2_computer,
                          is_player1_computer=p1_computer,
                          num_envs=num_envs, device=device, seed=0, env_id_base=shard.env_id_base,
                          auto_reset=True, validate_actions=validate_actions, flight_tables=flight_tables,
-                         state_format=state_format, observation_dtype=torch.int16 if obs16 else torch.int32,
-                         landing_reuse=landing_reuse)
+                         state_format=state_format, observation_dtype=torch.int16 if obs16 else torch.int32)
     if wrappers:
         env = SimplifyAction(env)
         env = RewardByBallPosition(env, WRAPPER_TABLE, 216, 176)
@@ -355,7 +351,7 @@ def cpu_baseline(args, raw_gpu, p2_computer, wrappers):
 
 def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=False, launch=None, steps=None,
             warmup=None, burn=None, min_time=None, check_lanes=0, flight_tables=True, state_format="int32", obs16=False,
-            validate_actions=False, tape="cold", landing_reuse=None, action_dtype=torch.int32):
+            validate_actions=False, tape="cold", action_dtype=torch.int32):
     """One timed measurement of the single-frame launch.  tape = "cold": every launch of the timed unit reads its own
     action slice (K x graph_repeats(K) distinct slices behind the warm-up ones: >= 1 GB at 65 536 games, streamed from
     HBM); "hot": the K slices are re-used."""
@@ -367,7 +363,7 @@ def measure(args, shard, device, *, num_envs=None, p2_computer=False, wrappers=F
     launch = args.launch if launch is None else launch
     env = make_env(shard, device, num_envs=num_envs, p1_computer=args.p1_computer, p2_computer=p2_computer,
                    wrappers=wrappers, flight_tables=flight_tables, state_format=state_format, obs16=obs16,
-                   validate_actions=validate_actions, landing_reuse=landing_reuse)
+                   validate_actions=validate_actions)
     raw = env.unwrapped
     env.reset()
     burn_in(raw, burn)
@@ -796,13 +792,13 @@ def load_traffic(workload_key, num_envs):
 
 
 def traffic_key(num_envs, p2_computer=False, wrappers=False, flight_tables=True, state_format="int32", obs16=False,
-                p1_computer=False, landing_reuse=None):
+                p1_computer=False):
     """The profiles/traffic.json entry of a single-frame workload (none was profiled with a computer player 1: another
     kernel, so no counted bytes for it)."""
     if p1_computer:
         return "p1_computer_unprofiled"
     mode = {True: "cfg3", "both": "cfg3", "power_hit": "cfg3_power_hit", False: "cfg3_compute", None: "cfg3_compute",
-            "none": "cfg3_compute"}[flight_tables] + ("_every_frame" if landing_reuse is False else "")
+            "none": "cfg3_compute"}[flight_tables]
     wl = (mode if p2_computer else ("cfg5" if wrappers else "random_random"))
     if num_envs != 65536:
         wl += f"_{num_envs}"
@@ -923,7 +919,6 @@ def main():
     dist.barrier()  # rank 0 may have rebuilt the library: nobody loads it earlier
     shard = dist.weak_shard(args.num_envs, rank, world)
     tables = args.flight_tables if args.flight_tables is not None else ("none" if args.no_flight_tables else "both")
-    reuse = False if args.no_landing_reuse else None  # (None: the env's default = on with a computer player)
     action_dtype = getattr(torch, args.action_dtype)
     single = rank == 0 and world == 1
     cdev = dist.collective_device(device)
@@ -941,7 +936,7 @@ def main():
     check_lanes = args.check_lanes if single else (min(1024, args.check_lanes) if rank in (0, world - 1) else 0)
     main_res = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers,
                        check_lanes=check_lanes, flight_tables=tables, state_format=args.state_format, obs16=args.int16_obs,
-                       tape=args.action_tape, landing_reuse=reuse, action_dtype=action_dtype)
+                       tape=args.action_tape, action_dtype=action_dtype)
     raw_main = main_res.pop("raw")
     # every rank's own figures (a straggler GPU is invisible in the MAX-over-ranks wall clock alone)
     parity = main_res.get("parity_bit_exact")
@@ -981,7 +976,7 @@ def main():
         o_steps = min(args.steps, 20) if other == "hot" else args.steps
         r = measure(args, shard, device, p2_computer=args.p2_computer, wrappers=args.wrappers, flight_tables=tables,
                     state_format=args.state_format, obs16=args.int16_obs, steps=o_steps, warmup=5, burn=512,
-                    min_time=0.1, tape=other, landing_reuse=reuse, action_dtype=action_dtype)
+                    min_time=0.1, tape=other, action_dtype=action_dtype)
         r.pop("raw")
         other_tape = {"action_tape": other, "steps": o_steps, "action_tape_bytes": r["action_tape_bytes"],
                       "value": r["value"], "launch_us": r["launch_us"], "frac": r["frac"]}
@@ -995,20 +990,10 @@ def main():
             "cfg3": ("65 536 games, player 2 = rule-based computer (both flight look-up tables in HBM: 927 + 82 MB)",
                      dict(num_envs=65536, p2_computer=True)),
             "cfg3_power_hit": ("65 536 games, player 2 = rule-based computer, the 82 MB power-hit table only (the landing "
-                               "point predicted in the kernel on the frames that interrupt a flight)",
+                               "point predicted in the kernel)",
                                dict(num_envs=65536, p2_computer=True, flight_tables="power_hit")),
             "cfg3_compute": ("65 536 games, player 2 = rule-based computer, flight predictors computed in the kernel",
                              dict(num_envs=65536, p2_computer=True, flight_tables="none")),
-            # the same three with the reference's own rule -- predict the landing point on EVERY frame (physics.py:314-315:
-            # pz_config.landing_fresh = NULL) -- what the freshness bytes buy in each mode
-            "cfg3_every_frame": ("config 3, both tables, the landing point looked up on every frame",
-                                 dict(num_envs=65536, p2_computer=True, landing_reuse=False, check_lanes=0)),
-            "cfg3_power_hit_every_frame": ("config 3, power-hit table only, the landing point predicted on every frame",
-                                           dict(num_envs=65536, p2_computer=True, flight_tables="power_hit",
-                                                landing_reuse=False, check_lanes=0)),
-            "cfg3_compute_every_frame": ("config 3, no tables, the landing point predicted on every frame",
-                                         dict(num_envs=65536, p2_computer=True, flight_tables="none", landing_reuse=False,
-                                              check_lanes=0)),
             "cfg5": ("65 536 games, fused SimplifyAction + RewardByBallPosition",
                      dict(num_envs=65536, wrappers=True)),
             # the same workloads on the packed state format (36 instead of 176 bytes of state per game;
@@ -1045,7 +1030,7 @@ def main():
             r.pop("raw")
             tk = traffic_key(kw["num_envs"], kw.get("p2_computer", False), kw.get("wrappers", False),
                              kw.get("flight_tables", True), kw.get("state_format", "int32"), kw.get("obs16", False),
-                             args.p1_computer, kw.get("landing_reuse"))
+                             args.p1_computer)
             configs[key] = config_entry(r, wl, kw["num_envs"], tk)
         configs["cfg3"]["flight_tables"] = table_info
         # env.step() with the action tensors a policy hands over: torch's default integer dtype (int64: argmax, multinomial,
@@ -1127,7 +1112,7 @@ def main():
     if rank == 0:
         alg_bytes = main_res["algorithmic_bytes_per_launch"]
         wl = traffic_key(args.num_envs, args.p2_computer, args.wrappers, tables, args.state_format, args.int16_obs,
-                         args.p1_computer, reuse)
+                         args.p1_computer)
         fr = fractions(main_res, args.num_envs, wl)
         tstat = _TRAFFIC_STATUS.get(wl, {})
         checked = [p for p in per_rank if p["parity_bit_exact"] is not None]
@@ -1160,16 +1145,20 @@ def main():
                 "launch": args.launch,
                 "kernel": kernel_name(args.num_envs, args.p2_computer or args.p1_computer, tables != "none",
                                       args.state_format == "packed"),
-                "flight_tables": tables, "landing_reuse": not args.no_landing_reuse, "action_dtype": args.action_dtype,
+                "flight_tables": tables, "action_dtype": args.action_dtype,
                 "state_format": args.state_format, "observation_dtype": "int16" if args.int16_obs else "int32",
                 "build_id": _native.build_id(), "ranks": dist.world_size(), "rccl_ranks": dist.rccl_ranks(),
                 "dist_backend": dist.backend_name(), "dist_note": (dist.fallback_note() or "")[:120],
+                # an RCCL start that hung was given up on in some rank: its communicator kernel may still hold CUs on that
+                # GPU -- every figure of this line is then SUSPECT (pikazoo_amd/dist.py: left_behind_anywhere)
+                "rccl_left_behind": dist.left_behind_anywhere(),
                 "env_id_base_last_rank": per_rank[-1]["env_id_base"],
             },
             "roofline": {
                 # the bound is HBM-side in every regime; which part of the memory system a launch of this batch size
                 # actually runs against is the regime (the configs file says what each name means)
                 "bound": "hbm", "bound_regime": fr["regime"], "achieved": main_res["achieved_GBps"],
+                "rccl_left_behind": dist.left_behind_anywhere(),  # true: the figures below are suspect (see config)
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 # `frac` is a CONTRACT-bytes figure: the algorithmic 649 B/game-step over the HIP-event
                 # launch duration over 8 TB/s -- not achieved HBM bandwidth: the changed-only write-back moves fewer
@@ -1240,7 +1229,6 @@ def main():
                 # config 3 in the three table modes (flight_tables= of the env) and what each costs in device memory
                 for mode, key in (("both", "cfg3"), ("power_hit", "cfg3_power_hit"), ("none", "cfg3_compute")):
                     roof[f"cfg3_tables_{mode}_us"] = round(configs[key]["launch_us"], 4)
-                    roof[f"cfg3_tables_{mode}_every_frame_us"] = round(configs[key + "_every_frame"]["launch_us"], 4)
                 roof["flight_tables_bytes_both"] = configs["cfg3"]["flight_tables"]["bytes"]
                 roof["flight_tables_bytes_power_hit"] = configs["cfg3"]["flight_tables"]["bytes_power_hit_only"]
             for name in ("api_int32", "api_int64"):
@@ -1275,7 +1263,9 @@ def main():
         line = json.dumps(out)
         assert len(line) < 8000, f"the bench line grew to {len(line)} bytes: the driver's record keeps 8 KB"
         print(line, flush=True)
-    dist.shutdown()  # (destroys the process groups; leaves hard when an RCCL start was left behind in some rank)
+    # (destroys the process groups; leaves hard -- and non-zero: the line above is flagged, a retry belongs in a fresh
+    # process -- when an RCCL start was left behind in some rank)
+    dist.shutdown(exit_code=3 if dist.left_behind_anywhere() else 0)
 
 
 if __name__ == "__main__":

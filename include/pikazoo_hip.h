@@ -32,10 +32,9 @@
 extern "C" {
 #endif
 
-/* 10: pz_config grows to 128 bytes: landing_fresh (the per-game "the stored landing point belongs to the stored ball"
- *     bytes that let a launch skip the computer player's landing prediction along a free flight) and action_format
- *     (int64 / uint8 / int16 action vectors straight into the launch, range-checked on the full value); the landing
- *     table of pz_flight_tables is optional on its own (power_hit alone is a supported mode).
+/* 10: pz_config grows to 120 bytes: action_format (int64 / uint8 / int16 action vectors straight into the launch,
+ *     range-checked on the full value; pz_step / pz_step_bound take `const void *` action vectors); the landing table
+ *     of pz_flight_tables is optional on its own (power_hit alone is a supported mode).
  *  9: the diagnostics pz_probe_launch / pz_selftest_predictor left this library (include/pikazoo_diag.h,
  *     libpikazoo_diag.so) */
 #define PZ_ABI_VERSION 10
@@ -83,8 +82,8 @@ enum pz_error {
 /* Constructor kwargs of pikazoo_v0.env (pikazoo_env.py:79-86) + the fused wrappers
  * (wrappers/simplify_action.py, reward_by_ball_position.py, reward_in_normal_state.py,
  * normalize_observation.py, record_episode_statistics.py) + the batched-env additions
- * (auto_reset, seed, env_id_base, action_faults, landing_fresh, action_format). POD, 128 bytes, passed by pointer
- * from the host and by value to the kernels.
+ * (auto_reset, seed, env_id_base, action_faults, action_format). POD, 120 bytes, passed by pointer from the host and
+ * by value to the kernels.
  *
  * Reward pipeline of one frame, in the order the reference's wrapper stack would apply it:
  *   r = +1/-1/0 (pikazoo_env.py:217-228)
@@ -127,19 +126,6 @@ typedef struct pz_config {
                                      shifts bit tables): that game's input for the frame is undefined, no memory is
                                      touched out of bounds, every other game is unaffected.  With NULL nothing is
                                      checked (the range is then the caller's contract, as in ABI 7). */
-    uint8_t *landing_fresh;       /* NULL, or `stride` bytes of device memory owned by the caller, one per game: non-zero =
-                                     "ball.expected_landing_point_x of the stored state IS the landing prediction of the
-                                     stored ball".  The reference recomputes that prediction on every frame with a computer
-                                     player (physics.py:314-315) although a ball keeps its landing point along a free flight
-                                     (pz_physics.hpp: flight_keeps_landing_point; tests/flight_rule.c checks the statement on
-                                     every ball of the landing table's domain); a launch that finds the byte set takes the
-                                     stored value instead of a table look-up / a prediction loop -- the 44 state words it
-                                     leaves are the reference's bit for bit either way.  Maintained by the library: every
-                                     step launch with a computer player sets / clears the bytes of the games it stepped,
-                                     pz_init and pz_reset clear the games they touch.  The CALLER clears it (hipMemsetAsync)
-                                     after anything else wrote the state: its own writes, pz_unpack_state into it, a step
-                                     launch under a configuration WITHOUT a computer player (those launches neither read nor
-                                     write it).  NULL = every frame predicts, as in ABI 9. */
     int32_t action_format;        /* enum pz_action_format: element type of act_p1 / act_p2 (pz_step, pz_step_bound) and of
                                      the tape of pz_step_many (PZ_ACT_I32 or PZ_ACT_I64 there) */
     int32_t reserved0;            /* 0 */
@@ -215,7 +201,7 @@ int64_t pz_probe_frame_bytes(void);   /* = 1024 * 8960 */
 typedef struct pz_flight_tables {
     const uint16_t *landing;     /* pz_flight_table_bytes(0) bytes (the entries + 2 bytes of padding: 927 MB), 4-byte
                                     aligned, or NULL: the landing point is then predicted in the kernel (closed-form
-                                    fast-forward; with cfg->landing_fresh only on the frames that interrupt a flight) */
+                                    fast-forward) */
     const uint16_t *power_hit;   /* pz_flight_table_bytes(1) bytes (82 MB), 16-byte aligned, or NULL */
 } pz_flight_tables;
 int64_t pz_flight_table_bytes(int32_t which);   /* 0: landing, 1: power_hit */

@@ -71,9 +71,6 @@ typedef struct pzo_config {
     uint64_t *action_faults;     /* product-side diagnostic pointer (pz_config, ABI 8): kept for the identical byte
                                     layout, never read here -- the reference raises IndexError on such an action
                                     (pikazoo_env.py:182), the oracle's behaviour for one is undefined */
-    uint8_t *landing_fresh;      /* product-side (pz_config, ABI 10): where the kernels note that a stored landing point
-                                    belongs to the stored ball and skip the prediction; layout only -- the oracle
-                                    predicts on every frame like the reference (physics.py:314-315) */
     int32_t action_format;       /* product-side (ABI 10): element type of the action vectors; layout only -- the oracle
                                     takes int32 */
     int32_t reserved0;

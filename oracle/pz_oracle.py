@@ -70,7 +70,6 @@ class Config(C.Structure):
         ("seed", C.c_uint64),
         ("env_id_base", C.c_int64),
         ("action_faults", C.c_void_p),  # product-side diagnostic pointer (layout only; never read by the oracle)
-        ("landing_fresh", C.c_void_p),  # product-side (ABI 10; layout only: the oracle predicts on every frame)
         ("action_format", C.c_int32),   # product-side (ABI 10; layout only: the oracle takes int32 actions)
         ("reserved0", C.c_int32),
     ]

@@ -339,23 +339,6 @@ __device__ __forceinline__ bool actions_out_of_range(const pz_config& cfg, int a
     return (high != 0u) | ((uint32_t)a1 >= action_count(cfg)) | ((uint32_t)a2 >= action_count(cfg));
 }
 
-// pz_config.landing_fresh: one byte per game, "the stored expected_landing_point_x is the landing point of the stored
-// ball" (pz_physics.hpp: a ball keeps its landing point along a free flight).  NULL: an empty descriptor -- the byte
-// reads as 0 (every frame predicts), the store is dropped; games past n likewise.
-struct FreshIO {
-    Rsrc rsrc;
-    uint32_t at;
-    __device__ __forceinline__ bool ld() const { return __builtin_amdgcn_raw_buffer_load_b8(rsrc, at, 0, 0) != 0; }
-    __device__ __forceinline__ void st(bool fresh) const
-    {
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)fresh, rsrc, at, 0, 0);
-    }
-};
-__device__ __forceinline__ FreshIO make_fresh_io(const pz_config& cfg, int64_t n, int64_t i)
-{
-    return FreshIO{make_rsrc(cfg.landing_fresh, cfg.landing_fresh != nullptr ? (uint32_t)n : 0u), (uint32_t)i};
-}
-
 __device__ __forceinline__ void count_action_faults(const pz_config& cfg, bool bad)
 {
     if (cfg.action_faults == nullptr) return;                  // wave-uniform (a kernel argument)
@@ -1046,18 +1029,13 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
     if (MODE == kActions) load_actions(hot.act_p1, hot.act_p2, n32, (uint32_t)i, hot.act_format, a1, a2, act_high);
     EpisodeStats st{0.0, 0.0, 0};
     PackedWords was{};
-    // a computer player's landing point: does the stored one belong to the stored ball? (pz_config.landing_fresh)
-    const bool reuse = (AI1 || AI2) && a.cfg.landing_fresh != nullptr;  // wave-uniform
-    bool ex_fresh = false;
     if (live) {
         if constexpr (PACKED)
             was = load_game_packed(g, pio, true);
         else
             load_game(g, io);
         if (with_stats) sio.load(st);
-        if (AI1 || AI2) ex_fresh = make_fresh_io(a.cfg, hot.n, i).ld();
     }
-    const bool fresh_loaded = MODE == kActions && ex_fresh;
     // pz_step_many: the tape is fetched kTapeChunk frames at a time and parked in LDS -- a per-frame global load would
     // put a full memory latency on every frame of a lone wave, and its wait (vmcnt is in-order) would also drain that
     // frame's stores; LDS reads only touch lgkmcnt.  The FIRST chunk is requested here, behind the state loads: its
@@ -1101,7 +1079,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
         // first frame reads them -- inside the loop body, counting down to vmcnt(0) -- where on every later frame
         // those waits drain the previous frame's 18 row stores instead (and the gathers queued behind them).
         if (kTraj) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
-        FrameHead head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold, reuse, ex_fresh);
+        FrameHead head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold);
         // The compiler sizes the tail's wait for the head's gathers for the worst path into the loop: from here
         // nothing would follow them (vmcnt(0): every frame drains its predecessor's row stores after all), around the
         // back edge a frame's 18 row stores do.  Eighteen dropped stores make the two paths look alike: vmcnt(18).
@@ -1116,7 +1094,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
             const bool last_frame = s == a.k - 1;
             frozen = head.frozen;
             reward = frame_tail<AI1, AI2, SCOUT, false>(g, a.cfg, id, a1, a2, live, head, lds_obs[0], lane, lut, link,
-                                                        nullptr, last_frame, &ex_fresh);
+                                                        nullptr, last_frame);
             finished += (unsigned int)(live && g.e.game_ended && !frozen);
             rw = shape_rewards(a.cfg, g, reward, frozen, parked_zones);
             if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
@@ -1129,7 +1107,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
             auto next_head = [&]() {  // this frame's outputs are staged: the game may move on
                 if (s + 1 < a.k) {
                     resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
-                    head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold, reuse, ex_fresh);
+                    head = frame_head<AI1, AI2, SCOUT, kDefer1, kDefer2>(g, a.cfg, id, live, lane, lut, link, &bold);
                 }
             };
             if (kTraj) {
@@ -1149,7 +1127,7 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
     } else {
         const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
         reward = step_games<AI1, AI2, SCOUT>(g, a.cfg, id, a1, a2, live, frozen, lds_obs[0], lane, lut,
-                                             ScoutLink{cand, hits, posts}, &ex_pending, true, reuse, &ex_fresh);
+                                             ScoutLink{cand, hits, posts}, &ex_pending);
         finished = (unsigned int)(live && g.e.game_ended && !frozen);
         rw = shape_rewards(a.cfg, g, reward, frozen);
         if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
@@ -1169,9 +1147,6 @@ void step_kernel(PZ_HOT_PARAMS, const StepArgs args)
             store_game(g, back, ex_pending);
         }
         if (with_stats) sio.store(st);
-        // (a single frame changes it when a round ends / starts: rarely; behind a frame loop it is stored as it is, through
-        // a descriptor built here: nothing more is carried around the loop)
-        if ((AI1 || AI2) && (MODE != kActions || ex_fresh != fresh_loaded)) make_fresh_io(a.cfg, hot.n, i).st(ex_fresh);
     }
     if (MODE != kRollout && MODE != kTape) emit_outputs(a, g, rw, as_float, live, i, lane, 0, lds_obs);
     PZ_STAMP(5);
@@ -1265,10 +1240,6 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     int a1 = 0, a2 = 0;
     uint32_t act_high = 0u;
     if (!RANDOM) load_actions(hot.act_p1, hot.act_p2, n32, (uint32_t)i, hot.act_format, a1, a2, act_high);
-    // a computer player's wave: does the stored landing point belong to the stored ball? (pz_config.landing_fresh)
-    const bool reuse = kOwnAI && a.cfg.landing_fresh != nullptr;  // wave-uniform
-    const FreshIO fio = make_fresh_io(a.cfg, kOwnAI ? hot.n : 0, i);
-    bool ex_fresh = false;
     EpisodeStats st{0.0, 0.0, 0};
     uint32_t sticky = 0;  // PACKED: the own group's overflow flag, kept
     if (PACKED && live) {
@@ -1279,7 +1250,6 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         unpack_tail(g, tail);
         sticky = (ROLE == 0 ? ga.y : gb.y) & kPackedOverflowBit;
         if (with_stats) sio.load(st);
-        if (kOwnAI) ex_fresh = fio.ld();
     }
     if (!PACKED && live) {
         g.e.round_ended = io.ld(PZ_E_ROUND_ENDED);
@@ -1298,10 +1268,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         g.b.ppx = io.ld(PZ_B_PREVIOUS_PREVIOUS_X);
         g.b.ppy = io.ld(PZ_B_PREVIOUS_PREVIOUS_Y);
         g.b.rot = io.ld(PZ_B_FINE_ROTATION);
-        if (kOwnAI) {  // (every computer's wave decides on it; the one of the last computer player keeps it: kKeepsEx)
-            g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);
-            ex_fresh = fio.ld();
-        }
+        if (kKeepsEx) g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);
         g.b.punch = io.ld(PZ_B_PUNCH_EFFECT_X);
         load_player(ROLE == 0 ? g.p1 : g.p2, io, kOwn);
         Player& other = ROLE == 0 ? g.p2 : g.p1;
@@ -1322,7 +1289,6 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
     if (RANDOM)  // (issued behind the loads: the block runs while they are in flight)
         policy_actions(id.id_lo, id.id_hi, make_rolling_key(a.action_seed), a.t0, a.cfg.simplify_action ? 13u : 18u, a1, a2);
     const Game loaded = g;  // what the columns held before the frame
-    const bool fresh_loaded = ex_fresh;
     const bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     bool frozen = false;
     PZ_DRAIN_VMEM();
@@ -1373,7 +1339,7 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
         }
     };
     const int reward = step_games_pair<ROLE, AI1, AI2>(g, a.cfg, id, a1, a2, live, frozen, xchg, kLanes * PZ_OBS_DIM,
-                                                        lane, lut, after_hit, bold_pending, before_barrier, reuse, ex_fresh);
+                                                        lane, lut, after_hit, bold_pending, before_barrier);
     const Rewards rw = shape_rewards(a.cfg, g, reward, frozen);
     if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
     PZ_PAIR_STAMP(ROLE, 2);
@@ -1489,8 +1455,6 @@ __device__ __forceinline__ void pair_body(const StepArgs& a, const HotArgs hot, 
             else
                 io.st(PZ_B_EXPECTED_LANDING_POINT_X, ex);
         }
-        // (changes when a round ends / starts and on the first frame after the caller cleared it: rarely)
-        if (live && ex_fresh != fresh_loaded) fio.st(ex_fresh);
     }
     // (player 1's wave checks both action words: both waves load both)
     if (!RANDOM && ROLE == 0) count_action_faults(a.cfg, live && actions_out_of_range(a.cfg, a1, a2, act_high));
@@ -1591,7 +1555,7 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         g.b.ppx = io.ld(PZ_B_PREVIOUS_PREVIOUS_X);
         g.b.ppy = io.ld(PZ_B_PREVIOUS_PREVIOUS_Y);
         g.b.rot = io.ld(PZ_B_FINE_ROTATION);
-        if (kOwnAI) g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);  // (kKeepsEx: the wave that stores it back)
+        if (kKeepsEx) g.b.ex = io.ld(PZ_B_EXPECTED_LANDING_POINT_X);
         g.b.punch = io.ld(PZ_B_PUNCH_EFFECT_X);
         load_player(own, io, kOwn);
         // of the partner: what an exchange hands over (its state before its next move) and the collision flag
@@ -1607,16 +1571,6 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         other.coll = io.ld(kOther + PZ_P_IS_COLLISION_WITH_BALL_HAPPENED);
     }
     if (with_stats && live) sio.load(st);
-    // a computer's wave: g.b.ex is the landing point of the ball as it stands (pz_physics.hpp) -- carried in a register
-    // from frame to frame, across launches in the caller's pz_config.landing_fresh bytes (NULL: the first frame predicts)
-    // (stored back unconditionally, through a descriptor built there: nothing more is carried around the frame loop)
-    // (kept as a per-lane word: a lane mask would be two more scalars around the frame loop, which has none to spare)
-    int ex_fresh = kOwnAI && live && make_fresh_io(a.cfg, kOwnAI ? hot.n : 0, i).ld();
-    auto fresh_now = [&]() {
-        asm volatile("" : "+v"(ex_fresh));
-        return ex_fresh != 0;
-    };
-
     const uint32_t n_actions = a.cfg.simplify_action ? 13u : 18u;
     BoldDefer bold{false, false, 0u, 0u};
     const ZoneTable zones = park_zone_table(a.cfg);
@@ -1641,7 +1595,8 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
     __builtin_amdgcn_s_waitcnt(0x0F70);  // every state load lands before the frame loop (see step_kernel)
     bool resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
     any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
-    PairHead head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold, fresh_now());
+    bool ex_fresh = false;  // a computer's wave: g.b.ex is the landing point of the ball as it stands (pz_physics.hpp)
+    PairHead head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold, ex_fresh);
     // (the gathers' wait, see step_kernel's frame loop -- for a computer's wave that stores rows: with two computer players)
     if (kOwnAI && !kWritesNone) issue_dropped_stores<TrajOut<OBS16>::kStores / 2>();
     for (int32_t s = 0; s < a.k; ++s) {
@@ -1654,11 +1609,9 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         }
         const bool last_frame = s == a.k - 1;
         const bool frozen = head.frozen;
-        bool fresh = fresh_now();
         const int reward = pair_frame_tail<ROLE, AI1, AI2>(g, a.cfg, id, a1, a2, live, head,
                                                            xchg + (s & 1) * (2 * kLoopXchgRegion), lane, lut, last_frame,
-                                                           &fresh);
-        ex_fresh = fresh;
+                                                           &ex_fresh);
         finished += (unsigned int)(live && g.e.game_ended && !frozen);
         const Rewards rw = shape_rewards(a.cfg, g, reward, frozen, &zones);
         if (with_stats) stats_update(st, a.cfg, rw, resets, live && !frozen, as_float);
@@ -1694,7 +1647,7 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         if (s + 1 < a.k) {  // this frame's outputs are staged: the game may move on
             resets = live && g.e.game_ended != 0 && a.cfg.auto_reset != 0;
             any_round_started |= live && g.e.round_ended != 0 && !(g.e.game_ended != 0 && a.cfg.auto_reset == 0);
-            head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold, fresh_now());
+            head = pair_frame_head<ROLE, AI1, AI2, !kOwnAI>(g, a.cfg, id, live, lut, &bold, ex_fresh);
         }
         auto next_policy = [&]() {
             if (MODE == kRollout) policy_actions(id.id_lo, id.id_hi, policy, a.t0 + (uint64_t)s + 1u, n_actions, a1, a2);
@@ -1708,10 +1661,6 @@ __device__ __forceinline__ void rollout_pair_body(const StepArgs& a, const HotAr
         out.advance();
     }
     if (!kOwnAI && bold.pending1) own.bold = rng_integers(id, bold.counter1, 5u);  // the launch's last recorded draw
-    // (out.ioff: the game's index, ~0u past the end of the batch -- dropped by the range check like a NULL buffer's byte)
-    if (kKeepsEx)
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(ex_fresh != 0),
-                                             make_rsrc(a.cfg.landing_fresh, a.cfg.landing_fresh != nullptr ? n32 : 0u), out.ioff, 0, 0);
 
     // ---- the state back: every wave its player, its half of the ball; player 1's wave the env words
     if (live) {
@@ -1820,7 +1769,6 @@ __global__ __launch_bounds__(kLanes) void init_kernel(int32_t* state, int64_t n,
     const RngId id = make_rng_id(cfg, i);
     construct_game(g, id);
     io.store(g, PackedWords{});
-    make_fresh_io(cfg, n, i).st(false);  // (dropped without the bytes)
 }
 
 template <bool PACKED>
@@ -1839,7 +1787,6 @@ __global__ __launch_bounds__(kLanes) void reset_kernel(int32_t* state, int64_t n
             const RngId id = make_rng_id(cfg, i);
             reset_game(g, cfg, id);
             io.store(g, was);
-            make_fresh_io(cfg, n, i).st(false);  // the ball was put back, the stored landing point was not (carry-over)
             if (episode_stats != nullptr)  // RecordEpisodeStatistics.reset (:23-25)
                 make_stats_io(episode_stats, true, stride, i).store(EpisodeStats{0.0, 0.0, 0});
         }
@@ -2365,8 +2312,7 @@ static int launch_step(const StepArgs& a, hipStream_t stream)
     const bool ai1 = a.cfg.p1_computer != 0, ai2 = a.cfg.p2_computer != 0;
     // with the power-hit table the six candidate flights of a deciding player are one gather: no scout wave is needed, and
     // the single frame splits by player.  The landing table is optional on top of it (pz_flight_tables in the header):
-    // without it the lanes that need a landing point predict it in the kernel -- with cfg.landing_fresh only on the frames
-    // that interrupt a flight
+    // without it the landing point is predicted in the kernel (predict_landing_x<true>: the closed-form fast-forward)
     const bool tables = a.tables.power_hit != nullptr;
     if constexpr (!diag::kNoPairKernel) {
         // (the packed format: at every size -- 524 288 games, us per launch, pair | single wave: human 30.25 | 30.13,

@@ -988,12 +988,14 @@ struct ScoutLink {
 // counts its iterations against INFINITE_LOOP_LIMIT (:33), which only a ball without x velocity bouncing on the net top
 // for ever reaches.  tests/flight_rule.c checks the statement on every one of the landing table's 4.6e8 balls against the
 // predictor's CPU restatement (416 234 714 balls covered, no violation; 2 387 182 excluded, 155 343 of them rightly).
-// So a frame whose stored expected_landing_point_x is known to belong to the stored ball (`fresh`) needs a prediction only
-// where the flight was interrupted: a collision, a ball outside the table's domain -- a round that starts serves a ball
-// without x velocity at x = 56 / 376, which comes down where it is.  The k-frame kernels carry `fresh` in a register from
-// frame to frame; across launches it lives in the caller's pz_config.landing_fresh bytes (include/pikazoo_hip.h), which
-// every step launch with a computer player maintains and pz_init / pz_reset clear -- without them (NULL) the first frame
-// of every launch predicts.
+// The k-frame pair kernel, which holds the ball and its last prediction in registers, looks a landing point up only for
+// the games whose flight was interrupted: a collision, a ball outside the table's domain, the launch's first frame --
+// a round that starts serves a ball without x velocity at x = 56 / 376, which comes down where it is.
+// (Carrying the same note ACROSS launches -- one byte per game beside the state, every single-frame launch skipping the
+// prediction of a free-flying ball -- was built in full in round 6, bit-identical in every table mode, and measured:
+// config 3 8.71 -> 8.81 us per launch with both tables, 13.23 -> 12.86 with the power-hit table alone, 14.49 -> 14.30
+// with none: at 65 536 games every wave is in the same phase at once and a launch lasts as long as its slowest wave,
+// which still has a lane whose flight a player just interrupted.  profiles/r06_experiments/landing_fresh.patch.)
 __device__ __forceinline__ bool ball_in_landing_domain(int x, int y, int xv, int yv)
 {
     return (ft_xv_index(xv) >= 0) & ((unsigned)(x - kBallRadius) < (unsigned)kFtXCount) & ((unsigned)y < (unsigned)kFtYCount) &
@@ -1042,19 +1044,15 @@ struct BoldDefer {
 // profiles/r03_experiments/ab_rollout_p2_computer_head_orderings.log.)
 struct FrameHead {
     bool frozen, ground;
-    bool known;               // g.b.ex already is this frame's landing point (no look-up, no prediction)
     uint32_t landing_word;    // LandingProbe::value
     lut_u32x4 candidate_row;  // CandidateProbe::value
     PreDrawn pre;
 };
 
 // DEFER1 / DEFER2: player 1's / 2's boldness draw is recorded in *bold instead of made (human players, k-frame launches)
-// reuse (wave-uniform: the caller passed pz_config.landing_fresh) / ex_fresh: g.b.ex is the landing point of the ball as
-// it stands -- the flight rule above then replaces the prediction; without `reuse` every frame predicts
 template <bool AI1, bool AI2, int SCOUT = kNoScout, bool DEFER1 = false, bool DEFER2 = false>
 __device__ __forceinline__ FrameHead frame_head(Game& g, const pz_config& cfg, const RngId& id, bool live, int lane,
-                                                const FlightLut& lut, const ScoutLink link, BoldDefer* bold,
-                                                const bool reuse = false, const bool ex_fresh = false)
+                                                const FlightLut& lut, const ScoutLink link, BoldDefer* bold)
 {
     static_assert(!(DEFER1 && AI1) && !(DEFER2 && AI2), "a computer player reads its boldness");
     // The reference empties `agents` on termination (:237-238) and expects reset() before the
@@ -1066,9 +1064,7 @@ __device__ __forceinline__ FrameHead frame_head(Game& g, const pz_config& cfg, c
     const bool active = live && !h.frozen;
     PZ_FRAME_STAMP(0);
     if (active) {
-        bool round_began = false;
         if (g.e.round_ended) {  // game_ended implies round_ended
-            round_began = true;
             if (g.e.game_ended) {
                 g.e.game_ended = 0;
                 g.e.p2serve = 0;
@@ -1096,13 +1092,8 @@ __device__ __forceinline__ FrameHead frame_head(Game& g, const pz_config& cfg, c
             ball_new_round(g.b, get_server(cfg, g.e, id));
         }
         PZ_FRAME_STAMP(1);
-        if (AI1 || AI2) {
-            h.known = reuse & landing_known_before_step(round_began, ex_fresh, g.b);
-            g.b.ex = (reuse & round_began) ? g.b.x : g.b.ex;  // (a serve has no x velocity and is not over the net)
-        }
         // physics_engine
         h.ground = ball_world_step(g.b);
-        if (AI1 || AI2) h.known = landing_known_after_step(h.known, round_began, h.ground, g.b);
         PZ_FRAME_STAMP(3);
     }
     if (SCOUT == kScoutPosted) {
@@ -1123,8 +1114,7 @@ __device__ __forceinline__ FrameHead frame_head(Game& g, const pz_config& cfg, c
     const bool by_tables = (AI1 || AI2) && SCOUT == kNoScout && lut.has_power_hit;  // wave-uniform
     if (by_tables && active) {
         const bool scan = (AI1 && power_hit_scan_needed(g.p1, g.b)) || (AI2 && power_hit_scan_needed(g.p2, g.b));
-        // (a lane that knows its landing point reads entry 0 like a lane outside the domain: a line the whole wave shares)
-        h.landing_word = lut.landing_issue(!h.known, g.b.x, g.b.y, g.b.xv, g.b.yv).value;
+        h.landing_word = lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv).value;
         h.candidate_row = lut.candidates_issue(scan, g.b.x, g.b.y, abs(g.b.yv)).value;
         h.pre = predraw3(id, g.e.rng);
     }
@@ -1132,13 +1122,10 @@ __device__ __forceinline__ FrameHead frame_head(Game& g, const pz_config& cfg, c
 }
 
 // PIN: the caller runs head and tail back to back (single frame): keep the head's Philox blocks under its gathers
-// ex_fresh (may be NULL): set to whether g.b.ex -- as stored by the caller, or by the scout wave -- is the landing point
-// of the ball this frame leaves behind; left alone for a game the frame did not step
 template <bool AI1, bool AI2, int SCOUT = kNoScout, bool PIN = true>
 __device__ __forceinline__ int frame_tail(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
                                           FrameHead& h, int32_t* __restrict__ scratch, int lane, const FlightLut& lut,
-                                          const ScoutLink link, bool* ex_pending, const bool last_frame,
-                                          bool* ex_fresh = nullptr)
+                                          const ScoutLink link, bool* ex_pending, const bool last_frame)
 {
     const bool active = live && !h.frozen, ground = h.ground;
     Input in1{0, 0, 0}, in2{0, 0, 0};
@@ -1165,11 +1152,11 @@ __device__ __forceinline__ int frame_tail(Game& g, const pz_config& cfg, const R
             const bool scan2 = AI2 && power_hit_scan_needed(g.p2, g.b);
             const int ayv = abs(g.b.yv);
             uint32_t unused;
-            LandingProbe lp = lut.landing_locate(!h.known, g.b.x, g.b.y, g.b.xv, g.b.yv, unused);
+            LandingProbe lp = lut.landing_locate(true, g.b.x, g.b.y, g.b.xv, g.b.yv, unused);
             lp.value = h.landing_word;
             CandidateProbe cp = lut.candidates_locate(scan1 | scan2, g.b.x, g.b.y, ayv, unused);
             cp.value = h.candidate_row;
-            g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, g.b.ex);  // :314-315, one evaluation serves both (known: it stands)
+            g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, 0);  // :314-315, one evaluation serves both
             lut.candidates_finish(cp, g.b.x, g.b.y, ayv, ex);
             PreDrawn pre = h.pre;
             if (AI1) g.e.rng += computer_decide_predrawn<false>(g.p1, g.b, g.p2.x, pre, scan1, ex, in1);
@@ -1180,10 +1167,9 @@ __device__ __forceinline__ int frame_tail(Game& g, const pz_config& cfg, const R
             }
         }
     } else {
-        if ((AI1 || AI2) && active && !h.known) {
+        if ((AI1 || AI2) && active) {
             // :314-315 recomputes the landing point before each player; the ball does not move
-            // between the two calls, so one evaluation serves both.  (known: the stored one stands -- the lanes of a
-            // wave that still predict are the ones whose flight was interrupted)
+            // between the two calls, so one evaluation serves both.
             g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
         }
 
@@ -1262,9 +1248,6 @@ __device__ __forceinline__ int frame_tail(Game& g, const pz_config& cfg, const R
             else
                 g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
         }
-        // what the frame leaves: the landing point of its moved ball (:314-315), or of the ball a player hit (:331-332);
-        // a ball on the ground ends the round, and a collision whose prediction was skipped leaves a stale value
-        if ((AI1 || AI2) && ex_fresh != nullptr) *ex_fresh = !ground & (!hit_processed | ex_observable);
     }
     if (SCOUT == kScoutLoads) {
         int32_t* slot = link.hits + lane * kHitPitch;
@@ -1287,13 +1270,11 @@ template <bool AI1, bool AI2, int SCOUT = kNoScout>
 __device__ __forceinline__ int step_games(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2, bool live,
                                           bool& frozen, int32_t* __restrict__ scratch, int lane,
                                           const FlightLut& lut, const ScoutLink link = ScoutLink{nullptr, nullptr, nullptr},
-                                          bool* ex_pending = nullptr, const bool last_frame = true, const bool reuse = false,
-                                          bool* ex_fresh = nullptr)
+                                          bool* ex_pending = nullptr, const bool last_frame = true)
 {
-    FrameHead h = frame_head<AI1, AI2, SCOUT>(g, cfg, id, live, lane, lut, link, nullptr, reuse, ex_fresh != nullptr && *ex_fresh);
+    FrameHead h = frame_head<AI1, AI2, SCOUT>(g, cfg, id, live, lane, lut, link, nullptr);
     frozen = h.frozen;
-    return frame_tail<AI1, AI2, SCOUT, true>(g, cfg, id, a1, a2, live, h, scratch, lane, lut, link, ex_pending, last_frame,
-                                             ex_fresh);
+    return frame_tail<AI1, AI2, SCOUT, true>(g, cfg, id, a1, a2, live, h, scratch, lane, lut, link, ex_pending, last_frame);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1333,13 +1314,11 @@ constexpr int kEarlyPostAt = 1024;  // word offset of the early post {x, draws} 
 
 // before_barrier(): called once the own player has moved and been posted, in front of the exchange barrier -- what the
 // caller can do with its finished player while the partner wave is still deciding
-// reuse (wave-uniform) / ex_fresh (a computer's wave; in: the caller's pz_config.landing_fresh byte, out: what to store
-// there): g.b.ex is the landing point of the ball as it stands -- see "a ball keeps its landing point" above
 template <int ROLE, bool AI1, bool AI2, class BeforeBarrier>
 __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, const RngId& id, int a1, int a2,
                                                bool live, bool& frozen, int32_t* __restrict__ xchg, int xchg_region,
                                                int lane, const FlightLut& lut, LandingProbe& after_hit, bool& bold_pending,
-                                               BeforeBarrier&& before_barrier, const bool reuse, bool& ex_fresh)
+                                               BeforeBarrier&& before_barrier)
 {
     constexpr bool kOwnAI = ROLE == 0 ? AI1 : AI2;
     constexpr bool kOtherAI = ROLE == 0 ? AI2 : AI1;
@@ -1352,7 +1331,6 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     bool ground = false;
     bool bold_late = false;       // the computer's round-start boldness, drawn behind the gathers' issue
     uint32_t bold_counter = 0u;
-    bool known = false;           // own computer player: g.b.ex already is this frame's landing point
     PZ_FRAME_STAMP(0);
     // (Moving the ball first and issuing the computer's two gathers in front of the players' round start and the action
     // decode -- the gathers depend on the ball columns, the round flags and the serve only -- was built twice in round 4
@@ -1360,9 +1338,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     // branch it was issued in closes), issue and consumption in one block 8.33 -> 8.36, packed 7.25 -> 7.71:
     // profiles/r04_experiments/ab_early_gather_*.log.  A hundred instructions earlier buys nothing.)
     if (active) {
-        bool round_began = false;
         if (g.e.round_ended) {  // reset (:149-164) or new round (:176-180); game_ended implies round_ended
-            round_began = true;
             if (g.e.game_ended) {
                 g.e.game_ended = 0;
                 g.e.p2serve = 0;
@@ -1424,12 +1400,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
         }
         PZ_FRAME_STAMP(2);
 
-        if (kOwnAI) {
-            known = reuse & landing_known_before_step(round_began, ex_fresh, g.b);
-            g.b.ex = (reuse & round_began) ? g.b.x : g.b.ex;  // (a serve has no x velocity and is not over the net)
-        }
         ground = ball_world_step(g.b);
-        if (kOwnAI) known = landing_known_after_step(known, round_began, ground, g.b);
         PZ_FRAME_STAMP(3);
     }
     const uint32_t rng_base = g.e.rng;  // the env stream before this frame's decisions
@@ -1452,8 +1423,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
             const bool scan = power_hit_scan_needed(own, g.b);
             const int ayv = abs(g.b.yv);
             int ex[6] = {0, 0, 0, 0, 0, 0};
-            // (a lane that knows its landing point reads entry 0 like a lane outside the domain: a line the whole wave shares)
-            LandingProbe lp = lut.landing_issue(!known, g.b.x, g.b.y, g.b.xv, g.b.yv);
+            LandingProbe lp = lut.landing_issue(true, g.b.x, g.b.y, g.b.xv, g.b.yv);
             CandidateProbe cp = lut.candidates_issue(scan, g.b.x, g.b.y, ayv);
             PreDrawn pre = predraw3(id, rng_base + draws_other);
             if (__builtin_amdgcn_ballot_w64(bold_late) != 0ull) {  // (wave-uniform: a lane of the wave starts a round)
@@ -1472,7 +1442,7 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
                 const int nx = min(max(other.x + vx, kPlayerHalfLength), kGroundHalfWidth - kPlayerHalfLength);
                 other.x = (other.state == 4) ? other.x : nx;
             }
-            g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, g.b.ex);  // (known: it stands)
+            g.b.ex = lut.landing_finish(lp, g.b.x, g.b.y, g.b.xv, g.b.yv, 0);
             lut.candidates_finish(cp, g.b.x, g.b.y, ayv, ex);
             draws_own = computer_decide_predrawn<ROLE == 1>(own, g.b, other.x, pre, scan, ex, in_own);
         }
@@ -1555,9 +1525,6 @@ __device__ __forceinline__ int step_games_pair(Game& g, const pz_config& cfg, co
     // the second of two would).  Nothing in the frame reads it any more: the gather is issued here and taken
     // by the caller behind its other stores (`after_hit`).
     if (kKeepsEx) after_hit = lut.landing_issue(hit_processed, g.b.x, g.b.y, g.b.xv, g.b.yv);
-    // what the frame leaves (the caller finishes `after_hit` before it stores): the landing point of the ball as it stands,
-    // unless the ball is on the ground -- the round ends, and the next one starts from the serve
-    if (kOwnAI && active) ex_fresh = !ground;
     PZ_FRAME_STAMP(7);
     return reward;
 }
@@ -1774,9 +1741,10 @@ __device__ __forceinline__ int pair_frame_tail(Game& g, const pz_config& cfg, co
         // next frame's prediction before anything reads it: evaluated on the last frame and for a game that freezes
         const bool ex_observable = last_frame | (g.e.game_ended != 0 && cfg.auto_reset == 0);
         if (kKeepsEx && (hit1 | hit2) && ex_observable) g.b.ex = lut.landing_x(g.b.x, g.b.y, g.b.xv, g.b.yv);
-        // a processed collision has changed the flight: g.b.ex no longer belongs to the ball (pair_frame_head) unless it
-        // was predicted again just now; a ball on the ground ends the round.  (A game the frame did not step keeps its flag.)
-        if (kOwnAI && ex_fresh != nullptr) *ex_fresh = !ground & (!(hit1 | hit2) | (kKeepsEx & ex_observable));
+        // a processed collision has changed the flight: g.b.ex no longer belongs to the ball (pair_frame_head)
+        if (kOwnAI && ex_fresh != nullptr) *ex_fresh = !(hit1 | hit2);
+    } else if (kOwnAI && ex_fresh != nullptr) {
+        *ex_fresh = false;
     }
     return reward;
 }

@@ -44,7 +44,6 @@ class PzConfig(C.Structure):
         ("seed", C.c_uint64),
         ("env_id_base", C.c_int64),
         ("action_faults", C.c_void_p),  # NULL or a device uint64 counter of out-of-range actions (pikazoo_env.py:182)
-        ("landing_fresh", C.c_void_p),  # NULL or `stride` device bytes: the stored landing point belongs to the stored ball
         ("action_format", C.c_int32),   # ACTION_FORMATS: element type of the action vectors
         ("reserved0", C.c_int32),
     ]

@@ -44,6 +44,7 @@ def weak_shard(n_per_gpu: int, rank: int, world_size: int) -> Shard:
 _COUNTERS = None       # the RCCL group the counters travel over (None: the gloo control group / no group at all)
 _FALLBACK_NOTE = None
 _LEFT_BEHIND = False   # an RCCL start that did not return in time is still running in a daemon thread of this process
+_LEFT_BEHIND_ANYWHERE = False  # ... in some rank of the job (agreed on over gloo right after the start)
 RCCL_START_TIMEOUT_S = 90.0   # (PIKAZOO_RCCL_START_TIMEOUT_S) how long a rank waits for its communicator + probe all-reduce
 
 
@@ -80,9 +81,19 @@ def _device_ready(index: int):
 def _start_rccl(rank: int, world: int, index: int):
     """This rank's attempt at an RCCL group over all ranks: (group or None, why not).  `dist.new_group` is a collective:
     every rank calls this or none does (init_from_env agrees on that over gloo first).  A call that HANGS inside RCCL is
-    not caught here but by `_start_rccl_bounded`, which runs this in a thread it can give up on; the group's own
-    watchdog timeout is set far beyond that bound (ten minutes), so that it cannot abort a job that has moved on."""
+    not caught here but by `_start_rccl_bounded`, which runs this in a thread it can give up on.
+
+    A communicator that is given up on keeps its own threads: ProcessGroupNCCL's watchdog would throw (or SIGABRT the
+    whole process) when the stuck collective passes the group's timeout, and its heartbeat monitor kills a process whose
+    watchdog stopped answering after 8-10 minutes -- a job that went on over gloo would be killed mid-run by a group it
+    no longer uses.  Both are switched off for this process BEFORE the group is created (they are read at construction;
+    a value the user exported wins): TORCH_NCCL_ASYNC_ERROR_HANDLING=0 (a timed-out collective aborts nothing) and
+    TORCH_NCCL_ENABLE_MONITORING=0 (no heartbeat kill).  The group's timeout stays at ten minutes as the second line: with
+    either variable overridden, that is how long a job that left a start behind may still run (`left_behind_anywhere()`
+    tells it so; bench.py prints it and ends through `shutdown()`)."""
     try:
+        for var in ("TORCH_NCCL_ASYNC_ERROR_HANDLING", "NCCL_ASYNC_ERROR_HANDLING", "TORCH_NCCL_ENABLE_MONITORING"):
+            os.environ.setdefault(var, "0")
         dev = torch.device("cuda", index)
         torch.cuda.set_device(dev)  # (the current device is per thread)
         group = dist.new_group(backend="nccl", timeout=timedelta(seconds=600))
@@ -101,7 +112,10 @@ def _start_rccl_bounded(rank: int, world: int, index: int, seconds: float | None
     its own start) they HANG.  The attempt therefore runs in a daemon thread: when it has not returned after `seconds`,
     this rank reports failure like any other -- the ranks then agree over gloo to leave the counters there -- and the
     thread is left behind (`left_behind()`: the process must then end through `shutdown()`, which does not try to tear
-    the half-made communicator down).  Nothing on the step path ever touches RCCL, so the measurement is not affected."""
+    the half-made communicator down).  Nothing on the step path ever touches RCCL -- but a probe all-reduce that was
+    already enqueued when the rank gave up keeps an RCCL kernel spinning on the GPU, holding CUs and a queue slot beside
+    whatever is timed afterwards: figures taken in such a job are FLAGGED (`left_behind_anywhere()`; bench.py:
+    `rccl_left_behind`), not trusted."""
     global _LEFT_BEHIND
     import threading
 
@@ -124,6 +138,13 @@ def _start_rccl_bounded(rank: int, world: int, index: int, seconds: float | None
 def left_behind() -> bool:
     """True when an RCCL start of this process never returned (see `_start_rccl_bounded`)."""
     return _LEFT_BEHIND
+
+
+def left_behind_anywhere() -> bool:
+    """True when an RCCL start never returned in SOME rank of the job (agreed on over gloo by `init_from_env`): a
+    communicator kernel may still be spinning on that rank's GPU, so the job's timings are suspect and the job should end
+    soon (through `shutdown()`; a retry belongs in a fresh child process)."""
+    return _LEFT_BEHIND_ANYWHERE
 
 
 def shutdown(exit_code: int = 0):
@@ -161,7 +182,7 @@ def init_from_env(backend: str | None = None, device_index: int | None = None) -
     instead of failing is given up on after `RCCL_START_TIMEOUT_S` (`_start_rccl_bounded`) and reads as a failure of that
     rank -- the job goes on over gloo and ends through `shutdown()`.  (`_shares_a_gpu` compares
     host name, the *_VISIBLE_DEVICES strings and the device index: two hosts of the same name would read as one.)"""
-    global _COUNTERS, _FALLBACK_NOTE
+    global _COUNTERS, _FALLBACK_NOTE, _LEFT_BEHIND_ANYWHERE
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -186,9 +207,12 @@ def init_from_env(backend: str | None = None, device_index: int | None = None) -
                 group, why = None, "two ranks share one GPU (RCCL refuses duplicate GPUs)"
             else:
                 group, why = _start_rccl_bounded(rank, world, index)
-            verdict = torch.tensor([1 if group is not None else 0], dtype=torch.int64)
-            dist.all_reduce(verdict, op=dist.ReduceOp.MIN)  # over gloo: one failure anywhere moves everybody
-            if int(verdict.item()) == 1:
+            # [came up here, no start left behind here]: MIN over gloo -- one failure anywhere moves everybody, and everybody
+            # learns whether some rank still has a start (and maybe its probe all-reduce's kernel) hanging
+            verdict = torch.tensor([1 if group is not None else 0, 0 if _LEFT_BEHIND else 1], dtype=torch.int64)
+            dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+            _LEFT_BEHIND_ANYWHERE = int(verdict[1].item()) == 0
+            if int(verdict[0].item()) == 1:
                 _COUNTERS = group
             else:
                 _COUNTERS = None  # (a communicator that did come up on this rank is left alone: tearing it down may block)

@@ -153,15 +153,9 @@ class raw_env(ParallelEnv):
     ``auto_reset`` then defaults to False, so that ``while env.agents:`` loops end like they do around
     the reference); ``flight_tables`` (computer players only: ``True`` / ``"both"``: look both flight predictions up in
     per-device HBM tables -- 927 MB for the landing point + 82 MB for the six power-hit candidates, per process and device;
-    ``"power_hit"``: only the 82 MB table -- the candidates are what diverges, the landing point is one closed-form flight
-    and, with ``landing_reuse``, only predicted on the frames that interrupt a flight; ``False``: everything computed in
-    the kernel; results are identical in all three); ``landing_reuse`` (computer players only, default on: the kernels
-    note per game -- one byte -- that the stored ``expected_landing_point_x`` belongs to the stored ball and skip the
-    landing prediction along a free flight, where the reference recomputes the same value on every frame
-    (physics.py:314-315); the 44 state words stay the reference's bit for bit.  The notes are dropped whenever anything
-    but a step launch writes the state: :meth:`set_state`, ``reset``, and any torch operation on :attr:`state` or a view
-    of it -- the env watches the tensor's version counter before every launch; somebody who writes the state through its
-    raw pointer, or between replays of a captured hipGraph, calls :meth:`invalidate_landing`);
+    ``"power_hit"``: only the 82 MB table -- the candidates are what diverges most, the landing point is one closed-form
+    flight predicted in the kernel; ``False``: everything computed in the kernel; results are identical in all three,
+    config 3 runs at 8.7 / 13.2 / 14.5 us per 65 536-game step);
     ``state_format`` ("int32": the state lives in HBM as the ``int32[44, num_envs]`` tensor :attr:`state`,
     live and writable; "packed": as 36 bytes per game instead of 176 -- the bit-packed format of
     ``include/pikazoo_hip.h`` -- which makes large batches about a third faster; every result is identical,
@@ -196,7 +190,7 @@ class raw_env(ParallelEnv):
                  validate_actions: bool = True, scalar_api: bool = False, flight_tables=True,
                  sprite_dir=None, sprites=None, state_format: str = "int32", scenery: bool = False,
                  observation_dtype=torch.int32, output_ring: int = 1, place_trajectories: bool = True,
-                 validate_every: int = 64, landing_reuse: Optional[bool] = None):
+                 validate_every: int = 64):
         assert serve in ("winner", "alternate", "random")  # pikazoo_env.py:104
         if render_mode not in (None, "rgb_array"):
             raise NotImplementedError('render_mode must be None or "rgb_array" (no "human" window on a GPU batch)')
@@ -293,13 +287,7 @@ class raw_env(ParallelEnv):
         # columns are padded to a multiple of 64 games so that every workgroup's 256-byte segment of a column is
         # aligned whatever num_envs is (a ragged pitch costs ~10 % per launch); `state` is the [44, n] view
         self._stride = (n + 63) // 64 * 64
-        # landing_reuse: pz_config.landing_fresh, one byte per game the step kernels maintain (see the class docstring)
-        self.landing_reuse = computer and (True if landing_reuse is None else bool(landing_reuse))
-        self._fresh = None
-        self._state_version = 0  # torch's version counter of the state tensor when the notes were last known to hold
-        if self.landing_reuse:
-            self._fresh = torch.zeros(self._stride, dtype=torch.uint8, device=self.device)
-            cfg.landing_fresh = self._fresh.data_ptr()
+
         if cfg.packed_state:
             # group A [stride][4] dwords, group B [stride][4] dwords, tail [stride] dwords (include/pikazoo_hip.h)
             self._state_buf = torch.zeros(_native.PACKED_BYTES_PER_GAME * self._stride, dtype=torch.uint8, device=dev)
@@ -311,7 +299,6 @@ class raw_env(ParallelEnv):
             self._state_view = self._state_buf[:, :n]
             self._scores = self._state_view[_E_SCORE_P1:_E_SCORE_P1 + 2].t()  # live [n, 2] view of the state
         self._state_ptr = self._state_buf.data_ptr()
-        self._state_version = self._state_buf._version
         # the output buffers: `output_ring` sets, used in rotation (one set: every step overwrites the last results)
         self._ring = []
         for _ in range(int(output_ring)):
@@ -410,17 +397,6 @@ class raw_env(ParallelEnv):
             return self._state_view.clone()
         return self._unpacked()[0][:, :self.num_envs]
 
-    def invalidate_landing(self):
-        """Somebody other than the step kernels wrote the state: every game's stored landing point is taken as stale
-        (``pz_config.landing_fresh`` is cleared; the next frame predicts again -- see ``landing_reuse``).  The env calls
-        this itself for :meth:`set_state` and for torch operations on :attr:`state` (it watches the tensor's version
-        counter); a writer it cannot see -- a raw-pointer kernel, a write between replays of a captured graph -- calls
-        it.  A no-op without a computer player."""
-        if self._fresh is not None:
-            self._fresh.zero_()
-            self._state_version = self._state_buf._version
-
-
     def _unpacked(self):
         """(int32[44, stride] copy of the packed state, its stride)"""
         out = torch.empty((_native.STATE_WORDS, self._stride), dtype=torch.int32, device=self.device)
@@ -460,7 +436,6 @@ class raw_env(ParallelEnv):
             raise ValueError(f"state must be int32[{_native.STATE_WORDS}, {self.num_envs}]")
         if self._state_view is not None:
             self._state_view.copy_(state)
-            self.invalidate_landing()
             return
         src = state.contiguous()
         misfits = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -471,7 +446,6 @@ class raw_env(ParallelEnv):
         if int(misfits.item()):
             raise ValueError(f"{int(misfits.item())} games hold values outside the packed format's fields")
         self._state_buf.copy_(staged)
-        self.invalidate_landing()
 
     @property
     def packed_misfits(self) -> int:
@@ -768,8 +742,6 @@ class raw_env(ParallelEnv):
         if f1 != f2:  # one launch reads one element type: two dtypes meet in int64, which holds all four
             a1, a2 = self._action_tensor(a1).to(torch.int64), self._action_tensor(a2).to(torch.int64)
             p1, p2, f1 = a1.data_ptr(), a2.data_ptr(), 1
-        if self._fresh is not None and self._state_buf._version != self._state_version:
-            self.invalidate_landing()  # (a torch operation wrote the state tensor since the last launch: landing_reuse)
         if len(self._ring) > 1:
             self._next_outputs()
         self._last_traj = None  # (this launch overwrites the single-frame buffers)
@@ -836,8 +808,6 @@ class raw_env(ParallelEnv):
         ``action_seed``, step indices ``t0 .. t0+k-1``; ``t0`` defaults to ``steps_done``) in ONE
         launch.  Returns the last frame's step tuple."""
         self._no_unfused_wrappers("step_random")
-        if self._fresh is not None and self._state_buf._version != self._state_version:
-            self.invalidate_landing()
         if t0 is None:
             t0 = self.steps_done
         self._next_outputs()
@@ -863,8 +833,6 @@ class raw_env(ParallelEnv):
         ``bool[k, N]``.  Bit-identical to ``k`` calls of ``step(random_actions(...))``; the state
         tensor is read and written once.  Pass the previous result as ``out`` to reuse its buffers."""
         self._no_unfused_wrappers("rollout_random")
-        if self._fresh is not None and self._state_buf._version != self._state_version:
-            self.invalidate_landing()
         if t0 is None:
             t0 = self.steps_done
         k, n, dev = int(k), self.num_envs, self.device
@@ -897,8 +865,6 @@ class raw_env(ParallelEnv):
         call this is asks with :meth:`check_actions` before it trusts the trajectory; with ``validate_every=1`` (strict)
         this call synchronises and raises itself."""
         self._no_unfused_wrappers("step_many")
-        if self._fresh is not None and self._state_buf._version != self._state_version:
-            self.invalidate_landing()
         n, dev = self.num_envs, self.device
         if actions.dim() != 3 or actions.shape[1] != 2 or actions.shape[2] != n:
             raise ValueError(f"actions must have shape [k, 2, {n}]")

@@ -7,7 +7,6 @@
 Nothing here reads /root/reference: that path does not exist on the GPU box.
 """
 import json
-import os
 import sys
 from pathlib import Path
 
@@ -20,7 +19,6 @@ for p in (REPO, REPO / "pika-zoo_amd"):
         sys.path.insert(0, str(p))
 
 GOLDEN = REPO / "tests" / "golden"
-EVERY_FRAME = os.environ.get("PZ_TEST_LANDING_REUSE") == "0"
 
 
 def pytest_configure(config):
@@ -39,18 +37,6 @@ def pytest_sessionstart(session):
         pz_build.build()
     except Exception as exc:  # noqa: BLE001 - the tests that need the library will say so loudly
         print(f"[conftest] could not build libpikazoo_hip.so: {exc}")
-    if EVERY_FRAME:
-        # PZ_TEST_LANDING_REUSE=0: the whole suite once more with the reference's own rule -- the computer player's landing
-        # point predicted on EVERY frame (physics.py:314-315; pz_config.landing_fresh = NULL) -- instead of the product's
-        # default (only where a flight is interrupted).  A test-side default, the product is not touched.
-        from pikazoo_amd import env as E
-
-        product_init = E.raw_env.__init__
-
-        def init(self, *a, landing_reuse=None, **kw):
-            product_init(self, *a, landing_reuse=False if landing_reuse is None else landing_reuse, **kw)
-
-        E.raw_env.__init__ = init
 
 
 def load_golden(name):

@@ -22,6 +22,16 @@ def built_lib():
     return pz_build.build()
 
 
+def free_port() -> str:
+    """A TCP port nobody holds right now (the rendezvous tests would otherwise collide with a concurrent session, or with
+    their own previous run's socket in TIME_WAIT, and fail after their full timeout)."""
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return str(sock.getsockname()[1])
+
+
 def header_functions(header="pikazoo_hip.h"):
     text = (REPO / "include" / header).read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -78,7 +88,7 @@ def test_binding_matches_library_layout(built_lib):
 
     lib = _native.load()
     assert lib.pz_abi_version() == 10 and lib.pz_state_words() == 44 and lib.pz_obs_dim() == 35
-    assert lib.pz_config_bytes() == C.sizeof(_native.PzConfig) == 128
+    assert lib.pz_config_bytes() == C.sizeof(_native.PzConfig) == 120
     assert lib.pz_error_string(0) == b"ok" and b"NULL" in lib.pz_error_string(-1)
     assert C.sizeof(_native.PzFlightTables) == 16
 
@@ -107,6 +117,60 @@ def test_library_carries_the_digest_of_the_sources_it_was_built_from(built_lib, 
             _native.load()
     finally:
         _native._lib, _native.LIB_PATH = saved
+
+
+_PETTINGZOO_PROBE = r'''
+import sys, types
+# a stand-in PettingZoo: just the two classes the reference's env and wrappers subclass
+pz, utils = types.ModuleType("pettingzoo"), types.ModuleType("pettingzoo.utils")
+class ParallelEnv:  # pettingzoo.ParallelEnv (pikazoo/env/pikazoo_env.py:21,72)
+    def state(self):
+        raise NotImplementedError
+    @property
+    def num_agents(self):
+        return len(self.agents)
+class BaseParallelWrapper(ParallelEnv):  # pettingzoo.utils.BaseParallelWrapper (pikazoo/wrappers/simplify_action.py:3,7)
+    def __init__(self, env):
+        self.env = env
+pz.ParallelEnv, utils.BaseParallelWrapper, pz.utils = ParallelEnv, BaseParallelWrapper, utils
+if sys.argv[2] == "with":
+    sys.modules["pettingzoo"], sys.modules["pettingzoo.utils"] = pz, utils
+sys.path.insert(0, sys.argv[1])
+from pikazoo_amd import env, pikazoo_v0, wrappers
+from pikazoo_amd.wrappers import base
+real = sys.argv[2] == "with"
+assert issubclass(pikazoo_v0.raw_env, ParallelEnv) == real, pikazoo_v0.raw_env.__mro__
+assert (env.ParallelEnv is ParallelEnv) == real
+for name in wrappers.__all__:
+    cls = getattr(wrappers, name)
+    assert issubclass(cls, base.BaseParallelWrapper)
+    assert issubclass(cls, BaseParallelWrapper) == real and issubclass(cls, ParallelEnv) == real, (name, cls.__mro__)
+# the forwarding stays this package's own either way: attributes the PettingZoo base defines itself are read through
+class Inner:
+    possible_agents = agents = ["player_1", "player_2"]
+    metadata = {"name": "pikazoo_v0"}
+    state = "a tensor here, not PettingZoo's method"
+    num_agents = max_num_agents = 2
+    unwrapped = "inner"
+    extra = 7
+w = base.BaseParallelWrapper(Inner())
+assert w.state == Inner.state and w.num_agents == 2 and w.unwrapped == "inner" and w.extra == 7
+assert w.possible_agents is Inner.possible_agents and w.metadata is Inner.metadata and w.agents is Inner.agents
+print("ok", real)
+'''
+
+
+@pytest.mark.parametrize("pettingzoo", ["with", "without"])
+def test_env_and_wrappers_subclass_pettingzoos_classes_when_it_is_importable(tmp_path, pettingzoo):
+    """The reference is `class raw_env(ParallelEnv)` and its wrappers are `BaseParallelWrapper`s (pikazoo_env.py:72,
+    wrappers/simplify_action.py:7); downstream libraries test `isinstance`.  With PettingZoo importable this package's
+    classes take its classes as bases (the try-import of spaces.py), without it (this image) plain stand-ins.  Checked in a
+    child process with a stand-in `pettingzoo` in sys.modules: the MRO switches, the wrappers' forwarding does not."""
+    script = tmp_path / "probe.py"
+    script.write_text(_PETTINGZOO_PROBE)
+    r = subprocess.run([sys.executable, str(script), str(REPO / "pika-zoo_amd"), pettingzoo], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == f"ok {pettingzoo == 'with'}", r.stdout + r.stderr
 
 
 def test_header_layout_matches_oracle_layout(oracle):
@@ -226,9 +290,10 @@ def test_counters_fall_back_to_gloo_when_rccl_cannot_start(tmp_path):
         pytest.skip("needs a box without a GPU (RCCL starts fine with one)")
     script = tmp_path / "worker.py"
     script.write_text(_FALLBACK_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", OMP_NUM_THREADS="1")
+    port = free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29543", str(script), str(REPO),
+                           "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(REPO),
                            str(tmp_path)], env=env, timeout=600)
     backend, world, total, rccl, note = (tmp_path / "fallback.txt").read_text().split(" ", 4)
     assert (backend, world, total, rccl) == ("gloo", "2", "3", "0") and "unavailable" in note
@@ -248,7 +313,7 @@ t0 = time.time()
 rank, world, _ = dist.init_from_env("nccl")
 total, = dist.all_reduce_sum([rank + 1])             # the counters still travel: over gloo
 open(os.path.join(sys.argv[2], f"hang_{rank}.txt"), "w").write(
-    f"{dist.backend_name()} {world} {total} {dist.rccl_ranks()} {int(dist.left_behind())} {time.time() - t0:.1f} {dist.fallback_note()}")
+    f"{dist.backend_name()} {world} {total} {dist.rccl_ranks()} {int(dist.left_behind())}{int(dist.left_behind_anywhere())} {time.time() - t0:.1f} {dist.fallback_note()}")
 print(f"rank {rank} done", flush=True)
 dist.shutdown()                                      # must not block on the start that was left behind
 raise SystemExit("shutdown() returned although an RCCL start was left behind in the job")
@@ -263,15 +328,16 @@ def test_an_rccl_start_that_hangs_is_given_up_on_and_the_job_still_ends(tmp_path
     blocks for ever on rank 1 of 2."""
     script = tmp_path / "worker.py"
     script.write_text(_HANG_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29563", OMP_NUM_THREADS="1", PIKAZOO_RCCL_START_TIMEOUT_S="2")
+    port = free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1", PIKAZOO_RCCL_START_TIMEOUT_S="2")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29563", str(script), str(REPO), str(tmp_path)],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(REPO), str(tmp_path)],
                        env=env, timeout=300, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     for rank in (0, 1):
         backend, world, total, rccl, left, took, note = (tmp_path / f"hang_{rank}.txt").read_text().split(" ", 6)
         assert (backend, world, total, rccl) == ("gloo", "2", "3", "0") and float(took) < 60
-        assert left == str(rank)  # only rank 1 left a start behind ...
+        assert left == f"{rank}1"  # only rank 1 left a start behind, and EVERY rank knows that somebody did ...
         assert "unavailable" in note and ("did not come up within 2 s" in note) == (rank == 1)  # ... and says so
 
 
@@ -280,9 +346,10 @@ def test_two_rank_sharding_equals_single_process(tmp_path, oracle):
     trajectories and totals as the single-process batch (env ids are global)."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="1")
+    port = free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), str(REPO),
+                           "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(REPO),
                            str(tmp_path)], env=env, timeout=600)
     whole = oracle.OracleEnv(96, oracle.make_config(is_player2_computer=True, winning_score=2, seed=7))
     whole.reset()
@@ -324,9 +391,10 @@ def test_config_4_at_its_real_rank_count_eight_ranks_over_gloo(tmp_path, oracle)
     per-rank rows arrive in rank order, and every rank's games are the games a single process steps under those ids."""
     script = tmp_path / "worker8.py"
     script.write_text(_WORKER8)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29553", OMP_NUM_THREADS="1")
+    port = free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
-                           "--master-addr", "127.0.0.1", "--master-port", "29553", str(script), str(REPO),
+                           "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(REPO),
                            str(tmp_path)], env=env, timeout=900)
     n_total, episodes, rows, n_global, world, backend, rccl = eval((tmp_path / "agg8.txt").read_text())  # noqa: S307
     assert (n_total, n_global, world, backend, rccl) == (524288, 524288, 8, "gloo", 0)
@@ -546,10 +614,11 @@ def test_no_scratch_and_bounded_scalar_spills_in_the_step_kernels(built_lib, tmp
     """Code-object notes of the shipped library: no step / rollout kernel touches scratch memory or spills a VGPR, and
     the k-frame kernels of a plain configuration (no fused wrapper, no statistics: the PLAIN instantiations the host
     picks for them) stay within the scalar register file -- round 3's generic forms carried 61-81 SGPR spills around
-    their frame loop.  "Touches": the single-frame kernels and the PLAIN forms reserve no scratch at all; a generic
-    k-frame form may carry a dead spill slot in its descriptor (the scalar register allocator leaves one behind in some of
-    them -- 20 bytes that come and go with unrelated changes, `llc -print-after=prologepilog`: every other frame object
-    dead) as long as its code holds no scratch instruction."""
+    their frame loop.  "Touches": the single-frame kernels and the PLAIN forms reserve no scratch at all.  A GENERIC
+    k-frame form may carry a few dead spill slots in its descriptor: the scalar register allocator leaves them behind in
+    one or another of those kernels (`-mllvm -print-after=prologepilog`: a 16- and a 4-byte frame object, every SGPR slot
+    dead) -- which one changes with unrelated edits, round 6 saw it move three times while the spill counts fell -- so
+    the invariant held here is the one that matters at run time: its code holds no scratch instruction."""
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
         pytest.skip("llvm-readelf not available")
     sys.path.insert(0, str(REPO / "tools"))
@@ -559,6 +628,7 @@ def test_no_scratch_and_bounded_scalar_spills_in_the_step_kernels(built_lib, tmp
     kernels = {name.split("(")[0].replace("void pz::", ""): r for name, r in rows}
     step = {k: r for k, r in kernels.items() if k.startswith(("step_kernel<", "step_pair_kernel<", "rollout_pair_kernel<"))}
     assert len(step) > 100, "the scan did not see the step kernels"
+
     def generic_k_frame_form(name):  # <..., MODE 2 / 3, ..., PLAIN false>
         args = [x.strip() for x in name[name.index("<") + 1:name.rindex(">")].split(",")]
         return args[2] in ("2", "3") and args[-1] == "false"
@@ -567,7 +637,7 @@ def test_no_scratch_and_bounded_scalar_spills_in_the_step_kernels(built_lib, tmp
         assert r[".vgpr_spill_count"] == 0, f"{name} spills VGPRs"
         reserved = r[".private_segment_fixed_size"]
         if reserved:
-            assert generic_k_frame_form(name) and reserved <= 32, f"{name} reserves {reserved} B of scratch"
+            assert generic_k_frame_form(name) and reserved <= 64, f"{name} reserves {reserved} B of scratch"
             ins = _kernel_instructions(built_lib, tmp_path, name)
             assert not any(t.startswith("scratch_") or "s[0:3]" in t for t in ins), f"{name} uses scratch memory"
     # <AI1, AI2, MODE (2 rollout, 3 tape), SPARSE, SCOUT, PACKED, OBS16, PLAIN> / <AI1, AI2, MODE, PACKED, OBS16, PLAIN>

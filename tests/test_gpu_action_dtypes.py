@@ -1,12 +1,8 @@
-"""GPU tests (``-m gpu``) of the two things ABI 10 added to the step path:
-
-* the action vectors go into the launch in the caller's element type (``pz_config.action_format``: int32, int64 --
-  torch's default integer dtype --, uint8, int16), range-checked on the FULL value: the reference raises ``IndexError``
-  from its table lookup (pikazoo_env.py:182), a cast to int32 would wrap 2**32 + 3 to 3 before any check saw it;
-* the landing point of a computer player's ball is predicted only on the frames that interrupt a flight
-  (``pz_config.landing_fresh`` / ``landing_reuse=``), where the reference predicts on every frame (physics.py:314-315):
-  the 44 state words must stay the reference's bit for bit, in every flight-table mode (both / power_hit / none), in both
-  state formats, and whatever else writes the state in between.
+"""GPU tests (``-m gpu``) of what ABI 10 added to the step path: the action vectors go into the launch in the caller's
+element type (``pz_config.action_format``: int32, int64 -- torch's default integer dtype --, uint8, int16), range-checked
+on the FULL value: the reference raises ``IndexError`` from its table lookup (pikazoo_env.py:182), a cast to int32 would
+wrap 2**32 + 3 to 3 before any check saw it.  (The flight-table mode ``"power_hit"`` of the same ABI runs through the
+parity parametrisations of test_gpu_parity.py / test_gpu_packed.py.)
 """
 import ctypes as C
 
@@ -14,12 +10,9 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, golden_state
-
 pytestmark = pytest.mark.gpu
 
 DTYPES = [torch.int64, torch.int16, torch.uint8, torch.int32]
-TABLE_MODES = [True, "power_hit", False]
 
 
 def cpu(t):
@@ -199,181 +192,8 @@ def test_c_abi_counts_on_the_full_value_and_refuses_unknown_formats():
 
 
 # ------------------------------------------------------------------------------------------------
-# 2. the landing point along a free flight (pz_config.landing_fresh)
+# 2. the flight-table modes
 # ------------------------------------------------------------------------------------------------
-AI_FIXTURES = ["cfg3_p2_computer", "p1_computer", "both_computer", "full_wrapper_stack"]
-
-
-@pytest.mark.parametrize("reuse", [True, False])
-@pytest.mark.parametrize("fmt", ["int32", "packed"])
-@pytest.mark.parametrize("tables", TABLE_MODES)
-@pytest.mark.parametrize("name", AI_FIXTURES)
-def test_reference_trajectories_with_and_without_landing_reuse(name, tables, fmt, reuse):
-    """The reference's own trajectories (tests/golden) in every flight-table mode, with the landing point predicted on
-    every frame like the reference and only where a flight is interrupted.  The state is READ (a copy) on every frame and
-    never written: with `reuse` the notes stay up from frame to frame, which is the path under test."""
-    from conftest import apply_product_wrappers
-    from pikazoo_amd import pikazoo_v0
-
-    d = load_golden(name)
-    meta = d["meta"]
-    env = apply_product_wrappers(pikazoo_v0.env(**meta["env_kwargs"], num_envs=meta["lanes"], seed=meta["seed"],
-                                                env_id_base=meta["env_id_base"], device="cuda:0", flight_tables=tables,
-                                                state_format=fmt, landing_reuse=reuse), meta["wrappers"] or {})
-    raw = env.unwrapped
-    assert raw.landing_reuse is reuse and (raw._fresh is not None) == reuse
-    assert raw.flight_tables == {True: "both", "power_hit": "power_hit", False: "none"}[tables]
-    env.reset()
-    assert np.array_equal(cpu(raw.read_state()), d["state0"])
-    acts = torch.as_tensor(d["actions"].astype(np.int32), device=raw.device)
-    fresh_seen = 0
-    for t in range(meta["steps"]):
-        obs, rew, term, _, _ = env.step({"player_1": acts[t, 0], "player_2": acts[t, 1]})
-        st = cpu(raw.read_state())
-        want = golden_state(d, t)
-        if not np.array_equal(st, want):
-            f, l = np.argwhere(st != want)[0]
-            pytest.fail(f"{name} tables={tables} {fmt} reuse={reuse}: step {t} lane {l} word {f}: {st[f, l]} != {want[f, l]}")
-        if reuse:
-            fresh_seen += int(raw._fresh[:raw.num_envs].sum().item())
-    if raw.obs_dtype == torch.int32:
-        assert np.array_equal(cpu(obs["player_1"]), d["obs"][-1, 0].astype(np.int32))
-    if reuse:  # the notes were up on most frames: the path under test did run
-        assert fresh_seen > 0.8 * meta["steps"] * meta["lanes"], fresh_seen
-
-
-@pytest.mark.parametrize("tables", TABLE_MODES)
-@pytest.mark.parametrize("kw", [dict(is_player2_computer=True), dict(is_player1_computer=True, is_player2_computer=True),
-                                dict(is_player1_computer=True, winning_score=2, auto_reset=False)])
-def test_a_fresh_note_means_the_stored_point_is_the_stored_balls_prediction(kw, tables, oracle):
-    """The invariant itself, against the oracle's predictor: wherever a game's note is up, expected_landing_point_x of
-    the stored state equals calculate_expected_landing_point_x_for (physics.py:643-686) of the stored ball."""
-    n, seed = 2048, 8
-    env = make(n, seed=seed, flight_tables=tables, landing_reuse=True, **kw)
-    env.reset()
-    checked = 0
-    for t in range(400):
-        env.step(env.random_actions(31, t))
-        if t % 40 == 39:
-            st, fresh = cpu(env.read_state()), cpu(env._fresh[:n]).astype(bool)
-            for l in np.flatnonzero(fresh)[::7]:
-                assert st[36, l] == oracle.expected_landing_x(int(st[26, l]), int(st[27, l]), int(st[28, l]), int(st[29, l])), (t, l)
-                checked += 1
-    assert checked > 500
-
-
-@pytest.mark.parametrize("fmt", ["int32", "packed"])
-@pytest.mark.parametrize("tables", TABLE_MODES)
-def test_writes_to_the_state_between_steps_drop_the_notes(tables, fmt, oracle):
-    """Anything but a step launch that writes the state makes the stored landing points stale: set_state, a masked
-    reset, a torch operation on `env.state` or on a view kept from earlier (the env watches the tensor's version
-    counter).  Each time the next frames must equal the oracle's, which predicts on every frame."""
-    n, seed, aseed = 1024, 12, 99
-    env = make(n, seed=seed, is_player2_computer=True, flight_tables=tables, state_format=fmt, winning_score=3,
-               landing_reuse=True)
-    ref = oracle_env(oracle, n, seed, is_player2_computer=True, winning_score=3)
-    env.reset(), ref.reset()
-    kept_view = env.state if fmt == "int32" else None
-    t = 0
-
-    def run(frames):
-        nonlocal t
-        for _ in range(frames):
-            a1, a2 = oracle.random_actions(n, 0, aseed, t, 18)
-            env.step({"player_1": torch.as_tensor(a1, device=env.device), "player_2": torch.as_tensor(a2, device=env.device)})
-            ref.step(a1, a2)
-            t += 1
-        assert np.array_equal(cpu(env.read_state()), ref.state), t
-
-    run(60)
-    assert int(env._fresh.sum().item()) > n // 2
-    rng = np.random.default_rng(0)
-    # (1) the ball moved by hand, through set_state
-    st = ref.state.copy()
-    st[26] = rng.integers(20, 433, n)
-    st[27] = rng.integers(0, 200, n)
-    st[28] = rng.integers(-10, 11, n)
-    st[29] = rng.integers(-30, 31, n)
-    ref.state[:] = st
-    env.set_state(torch.as_tensor(st, device=env.device))
-    assert int(env._fresh.sum().item()) == 0
-    run(40)
-    # (2) a masked reset: only the reset games lose their note
-    mask = (np.arange(n) % 3 == 0).astype(np.uint8)
-    before = cpu(env._fresh[:n]).copy()
-    env.reset(mask=torch.as_tensor(mask, device=env.device)), ref.reset(mask)
-    after = cpu(env._fresh[:n])
-    assert not after[mask == 1].any() and np.array_equal(after[mask == 0], before[mask == 0])
-    run(40)
-    if fmt == "int32":
-        # (3) a torch write through the live tensor, and (4) through a view kept from before the steps
-        st = ref.state.copy()
-        st[26] = rng.integers(20, 433, n)
-        st[29] = rng.integers(-20, 21, n)
-        ref.state[:] = st
-        env.state[26] = torch.as_tensor(st[26], device=env.device)
-        env.state[29].copy_(torch.as_tensor(st[29], device=env.device))
-        run(40)
-        st = ref.state.copy()
-        st[27] = rng.integers(0, 150, n)
-        ref.state[:] = st
-        kept_view[27] = torch.as_tensor(st[27], device=env.device)
-        run(40)
-        # (5) only the stored landing point scribbled over: the reference never reads it (it predicts afresh)
-        kept_view[36] = 7
-        ref.state[36] = 7
-        run(40)
-    # (6) a writer the env cannot see says so itself
-    env.invalidate_landing()
-    assert int(env._fresh.sum().item()) == 0
-    run(20)
-
-
-@pytest.mark.parametrize("tables", [True, "power_hit"])
-def test_k_frame_launches_keep_and_use_the_notes(tables, oracle):
-    """pz_step_random / pz_rollout_random / pz_step_many read the notes for their first frame and leave them for the next
-    launch, on both sides of the kernel switch at 393 216 games and mixed with single frames."""
-    for n in (4096, 393216 + 128):
-        seed = 17
-        env = make(n, seed=seed, is_player2_computer=True, flight_tables=tables, landing_reuse=True)
-        lanes = min(n, 2048)
-        ref = oracle_env(oracle, lanes, seed, is_player2_computer=True)
-        env.reset(), ref.reset()
-        t = 0
-        for launch in range(6):
-            if launch % 3 == 0:
-                env.rollout_random(55, 16, t0=t)
-            elif launch % 3 == 1:
-                env.step_random(55, t0=t, k=16)
-            else:
-                tape = torch.stack([torch.stack([env.random_actions(55, t + j)[a] for a in env.possible_agents])
-                                    for j in range(16)])
-                env.step_many(tape)
-            ref.rollout_random(55, t, 16)
-            t += 16
-            assert int(env._fresh[:n].sum().item()) > n // 2
-            env.step(env.random_actions(55, t))
-            ref.rollout_random(55, t, 1)
-            t += 1
-            assert np.array_equal(cpu(env.read_state()[:, :lanes]), ref.state), (n, launch)
-
-
-def test_landing_reuse_is_off_without_a_computer_player_and_on_request():
-    from conftest import EVERY_FRAME
-
-    if EVERY_FRAME:
-        pytest.skip("PZ_TEST_LANDING_REUSE=0 changes the default this test is about")
-    hh = make(64, seed=1)
-    assert hh.landing_reuse is False and hh._fresh is None and hh._cfg.landing_fresh is None
-    hh.invalidate_landing()  # a no-op
-    off = make(64, seed=1, is_player2_computer=True, landing_reuse=False)
-    assert off.landing_reuse is False and off._cfg.landing_fresh is None
-    on = make(64, seed=1, is_player2_computer=True)
-    assert on.landing_reuse is True and on._cfg.landing_fresh == on._fresh.data_ptr()
-    with pytest.raises(ValueError):
-        make(64, flight_tables="landing")
-
-
 def test_flight_table_modes_cost_what_the_readme_says():
     from pikazoo_amd import env as E
 
@@ -381,4 +201,7 @@ def test_flight_table_modes_cost_what_the_readme_says():
     assert E.flight_table_bytes(True) == E.flight_table_bytes("both") == 927_653_344 + 82_467_840
     assert E.flight_table_bytes("power_hit") == 82_467_840 and E.flight_table_bytes(False) == E.flight_table_bytes("none") == 0
     e = make(64, seed=1, is_player2_computer=True, flight_tables="power_hit")
-    assert e._tables[0].landing is None and e._tables[0].power_hit is not None
+    assert e._tables[0].landing is None and e._tables[0].power_hit is not None and e.flight_tables == "power_hit"
+    assert make(64, seed=1, is_player2_computer=True).flight_tables == "both" and make(64, seed=1).flight_tables == "none"
+    with pytest.raises(ValueError):
+        make(64, flight_tables="landing")

@@ -916,3 +916,19 @@ def test_convert_single_agent_matches_the_reference_wrapper(name):
     st = d["states"][-1].astype(np.int32)
     st[43] = d["rng_counter"][-1]
     assert np.array_equal(env.state.cpu().numpy(), st)
+
+
+def test_pettingzoos_own_parallel_api_test_when_it_is_installed():
+    """The reference's one API test is `parallel_api_test(env, 1_000_000)` (tests/test_parallel_api.py:5-7).  With
+    PettingZoo installed `raw_env` IS a ParallelEnv (pikazoo_amd/env.py) and the harness itself runs against the scalar
+    API (num_envs = 1: the reference's exact return types); this image has no PettingZoo, where the test skips and
+    `test_parallel_api_conformance_scalar` above stays the restatement of what the harness checks."""
+    pz_test = pytest.importorskip("pettingzoo.test", reason="pettingzoo is not installed in this image (no network): the "
+                                  "harness is restated in test_parallel_api_conformance_scalar")
+    from pettingzoo import ParallelEnv
+
+    from pikazoo_amd import pikazoo_v0
+
+    env = pikazoo_v0.env(num_envs=1, scalar_api=True)
+    assert isinstance(env, ParallelEnv)
+    pz_test.parallel_api_test(env, num_cycles=10_000)

@@ -971,7 +971,6 @@ def test_human_vs_human_k_frame_launches_on_int16_rows_vs_oracle(fmt, oracle):
     ("cfg3_p2_computer_tables", dict(is_player2_computer=True), {}),
     ("cfg3_p2_computer_scout", dict(is_player2_computer=True, flight_tables=False), {}),
     ("cfg3_p2_computer_power_hit_table", dict(is_player2_computer=True, flight_tables="power_hit"), {}),
-    ("cfg3_p2_computer_every_frame", dict(is_player2_computer=True, landing_reuse=False), {}),
     ("cfg5_fused_wrappers", dict(), dict(simplify_action=True,
                                          additional_reward=(0.0, -0.01, 0.0, 0.01, 0.0, 0.01, 0.0, -0.01))),
 ])
@@ -981,7 +980,7 @@ def test_headline_size_every_lane_vs_oracle(name, kw, wr, oracle):
     from oracle.ref_capture import fused_options
 
     n, steps, seed, base, aseed = 65536, 320, 11, 1 << 33, 99
-    okw = {k: v for k, v in kw.items() if k not in ("flight_tables", "landing_reuse")}
+    okw = {k: v for k, v in kw.items() if k != "flight_tables"}
     env = make_env(num_envs=n, seed=seed, env_id_base=base, winning_score=2, wrappers=wr, **kw)
     raw = env.unwrapped
     ref = oracle.OracleEnv(n, oracle.make_config(winning_score=2, seed=seed, env_id_base=base, **okw,

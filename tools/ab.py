@@ -6,9 +6,8 @@ rounds in ONE process, median and min reported).
     python tools/ab.py [--ai] [--n 65536] [--rollout K] name1 name2 ...    # on the GPU box: time them
                                                                            # (--rollout: pz_rollout_random, K frames/launch)
     a name with the suffix "+t" runs that library WITH both flight look-up tables (pz_flight_tables), "+q" with the
-    power-hit table alone, "+f" with the landing-freshness bytes (pz_config.landing_fresh: the landing point predicted
-    only where a flight is interrupted), "+p" on the packed state format, "+h" with int16 observations, combined at will,
-    e.g. `python tools/ab.py --ai base+t base+tf base+qf base+f`: run-time variants of ONE library.
+    power-hit table alone, "+p" on the packed state format, "+h" with int16 observations, combined at will,
+    e.g. `python tools/ab.py --ai base base+t base+q base+tph`: run-time variants of ONE library.
 
 Compile-time variants are DIAGNOSTIC builds (pika-zoo_amd/csrc/pz_diagnostic.hpp: the one switch of the kernel
 sources): BITS are the low 16 bits of -DPZ_DIAGNOSTIC_BUILD (1 stamps, 2 no pair kernel, 4 no rollout pair kernel,
@@ -142,10 +141,7 @@ def main():
         assert base.pz_build_flight_tables(t_land.data_ptr(), t_hit.data_ptr(), stream) == 0
         tables = _native.PzFlightTables(t_land.data_ptr(), t_hit.data_ptr())
         tables_hit = _native.PzFlightTables(None, t_hit.data_ptr())  # "+q": the power-hit table alone
-    # "+f": the landing-freshness bytes of that variant's state (pz_config.landing_fresh)
-    fresh = {nm: torch.zeros(n, dtype=torch.uint8, device=dev) for nm in names if "f" in mods(nm)}
-    for nm, buf in fresh.items():
-        cfgs[nm].landing_fresh = buf.data_ptr()
+
     for nm in names:
         assert libs[nm].pz_init(states[nm].data_ptr(), n, n, C.byref(cfgs[nm]), stream) == 0
         obs = obs16 if "h" in mods(nm) else obs32
@@ -193,18 +189,14 @@ def main():
             assert rc == 0, (nm, rc)  # (-3: a PZ_DEV_SUBSET build without this launch's kernel family)
         return steps
 
-    snapshots, fresh_snap = {}, {}
+    snapshots = {}
     for nm in names:
         run(nm, 700)
         snapshots[nm] = states[nm].clone()
-        if nm in fresh:
-            fresh_snap[nm] = fresh[nm].clone()
     torch.cuda.synchronize()
 
     def restore(nm):
         states[nm].copy_(snapshots[nm])
-        if nm in fresh:
-            fresh[nm].copy_(fresh_snap[nm])
 
     # every variant must produce the same trajectory as base (compared on the outputs; the state only between
     # variants of the same layout)

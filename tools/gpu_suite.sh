@@ -4,11 +4,8 @@
 # that fails ends the script: no GPU step is started behind a failed one.
 #
 #   check   GPU test suite, __graft_entry__.smoke(), the default bench line (+ its --configs-out file)
-#   check_every_frame  the GPU test suite once more with the reference's own rule as the default of every env it builds:
-#           the computer player's landing point predicted on EVERY frame (PZ_TEST_LANDING_REUSE=0, tests/conftest.py)
-#   reuse   round 6's A/B: config 3 with and without the landing-freshness bytes (pz_config.landing_fresh), in the three
-#           flight-table modes, interleaved in one process on one library (cold and hot action tape), then the early stores
-#           of DESIGN 4.2 re-measured on top of it (kill criterion of the hand-shake: < 1 %)
+#   tables  config 3 in the three flight-table modes (both / power-hit table only / none), interleaved in one process on one
+#           library, cold and hot action tape; then DESIGN 4.2's early stores re-measured on the round's kernels
 #   bench   the default bench line and the --extra line only
 #   driver  the bench line exactly as the driver runs it (--steps 20 --warmup 5)
 #   variants  the bench line's other workloads and launch modes, headline only (--no-configs): config 3, config 5, packed,
@@ -88,21 +85,15 @@ for path in sys.argv[1:]:
 sys.exit(1 if bad else 0)
 PY
     ;;
-check_every_frame)
-    export PZ_TEST_LANDING_REUSE=0
-    step 1100 gputest_every_frame.log python3 -m pytest tests -m gpu -x -q
-    tail -n 4 "$O/gputest_every_frame.log"
-    ;;
-reuse)
+tables)
     # (pz_diagnostic.hpp bits: 32 = no early stores, 16 = early stores without the hand-shake; subset 2753 = the single-frame
     # kernels -- pair and single-wave / scout --, human vs human and player 2 = computer)
     step 600 build_variants.log python3 tools/ab.py --build --subset 2753 early0=32 unordered=16
-    step 400 ab_landing_reuse_cold_tape.log python3 tools/ab.py --ai --slices 2048 --samples base+t base+tf base+q base+qf base base+f
-    step 400 ab_landing_reuse_hot_tape.log python3 tools/ab.py --ai --samples base+t base+tf base+q base+qf base base+f
-    step 400 ab_landing_reuse_packed_cold_tape.log python3 tools/ab.py --ai --slices 2048 base+tp base+tpf base+qp base+qpf
-    step 400 ab_early_stores_on_top_of_reuse_cold_tape.log python3 tools/ab.py --ai --slices 2048 --samples base+tf early0+tf unordered+tf base+qf early0+qf
-    step 400 ab_early_stores_on_top_of_reuse_hot_tape.log python3 tools/ab.py --ai --samples base+tf early0+tf unordered+tf
-    tail -n 9 "$O"/ab_*.log
+    step 400 ab_flight_table_modes_cold_tape.log python3 tools/ab.py --ai --slices 2048 --samples base+t base+q base
+    step 400 ab_flight_table_modes_hot_tape.log python3 tools/ab.py --ai --samples base+t base+q base
+    step 400 ab_early_stores_cold_tape.log python3 tools/ab.py --ai --slices 2048 --samples base+t early0+t unordered+t
+    step 400 ab_early_stores_hot_tape.log python3 tools/ab.py --ai --samples base+t early0+t unordered+t
+    tail -n 6 "$O"/ab_*.log
     ;;
 edge)
     step 600 build_variants.log python3 tools/ab.py --build --subset 705 unordered=16 early0=32 delayedge=0x200 delayunordered=0x210

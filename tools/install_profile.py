@@ -23,6 +23,7 @@ TRAFFIC = {
     "random_random_4096": ("cfg2", "pz::step_pair_kernel<false, false, false, false>", 4096),
     "cfg3": ("cfg3", "pz::step_pair_kernel<false, true, false, false>", 65536),
     "cfg3_compute": ("cfg3c", "pz::step_kernel<false, true, 0, true, 1, false, false, false>", 65536),
+    "cfg3_power_hit": ("cfg3q", "pz::step_pair_kernel<false, true, false, false>", 65536),
     "cfg5": ("cfg5", "pz::step_pair_kernel<false, false, false, false>", 65536),
     "random_random_524288": ("big", "pz::step_kernel<false, false, 0, true, 0, false, false, false>", 524288),
     "random_random_int16obs": ("i16", "pz::step_pair_kernel<false, false, false, false>", 65536),
@@ -74,7 +75,7 @@ def main():
         print(f"  traffic {key}: {e['hbm_bytes_per_launch'] / 1e6:.2f} MB = 2 x {e['fetch_size_kb_raw']:.0f} KB read + "
               f"{e['write_size_kb']:.0f} KB written")
     tpath.write_text(json.dumps(traffic, indent=1))
-    for prefix in ("hh", "pk", "cfg3", "cfg3c"):
+    for prefix in ("hh", "pk", "cfg3", "cfg3q", "cfg3c"):
         for kernel, e in derived.get(prefix, {}).items():
             if "valu_insts_per_wave" in e and ("pair" in kernel or ", 0, true, 1" in kernel):
                 print(f"  {prefix} {kernel}: VALU/wave {e['valu_insts_per_wave']:.0f}, active lanes "

@@ -2,6 +2,9 @@
 """Condense the raw rocprofv3 output of tools/profile.sh into the files committed under profiles/.
 
     python tools/pmc_summary.py TAG        # reads gpurun_out/prof_TAG/<run>/, writes gpurun_out/prof_TAG/out/TAG_*
+    python tools/pmc_summary.py --record-build FILE   # what tools/profile.sh runs FIRST: the build id and the step
+                                                      # kernels' instruction-stream digests of the library the counters
+                                                      # are about to be collected on
 
 (tools/profile.sh runs it on the GPU box and then deletes the raw traces: gpurun brings back at most 64 MiB;
 copy gpurun_out/prof_TAG/out/* into profiles/ to commit them.)
@@ -22,6 +25,17 @@ from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
 STEP_KERNELS = ("pz::step_pair_kernel", "pz::step_kernel", "pz::rollout_pair_kernel")
+
+
+def build_record():
+    """{build_id, kernel_digests} of the library on disk (tools/kernel_digest.py)."""
+    sys.path.insert(0, str(REPO / "pika-zoo_amd"))
+    sys.path.insert(0, str(REPO / "tools"))
+    import kernel_digest
+    from pikazoo_amd import _native
+
+    return {"build_id": _native.build_id(),
+            "kernel_digests": {k: d for k, (d, _) in kernel_digest.kernels(_native.LIB_PATH).items() if k.startswith(STEP_KERNELS)}}
 
 
 def short(name):
@@ -205,15 +219,23 @@ def main():
         derived[prefix] = d
     out = {"tag": tag, "derived": derived, "raw_means": summary}
     # which build the counters were taken on, and the instruction-stream digest of every step kernel of that build:
-    # bench.py accepts these figures on another build only for a kernel whose digest is unchanged (tools/kernel_digest.py)
+    # bench.py accepts these figures on another build only for a kernel whose digest is unchanged (tools/kernel_digest.py).
+    # The record was written by profile.sh BEFORE its first rocprofv3 run (build_at_collection.json); a library rebuilt
+    # between collection and this summary would otherwise stamp the counters with the wrong build.
+    recorded = src / "build_at_collection.json"
     try:
-        sys.path.insert(0, str(REPO / "pika-zoo_amd"))
-        sys.path.insert(0, str(REPO / "tools"))
-        import kernel_digest
-        from pikazoo_amd import _native
-
-        out["build_id"] = _native.build_id()
-        out["kernel_digests"] = {k: d for k, (d, _) in kernel_digest.kernels(_native.LIB_PATH).items() if k.startswith(STEP_KERNELS)}
+        now = build_record()
+        if recorded.exists():
+            then = json.loads(recorded.read_text())
+            if then["build_id"] != now["build_id"]:
+                raise SystemExit(f"the library was rebuilt since the counters were collected ({then['build_id']} -> "
+                                 f"{now['build_id']}): refusing to stamp them with another build")
+            out.update(then)
+        else:
+            print("(no build_at_collection.json beside the traces: stamping the library on disk)")
+            out.update(now)
+    except SystemExit:
+        raise
     except Exception as exc:  # noqa: BLE001
         print(f"(no build id / kernel digests: {type(exc).__name__}: {exc})")
     if summary:  # (a run of kernel-trace sections only has no counters: it must not replace a full run's summary, which
@@ -223,4 +245,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 3 and sys.argv[1] == "--record-build":
+        Path(sys.argv[2]).write_text(json.dumps(build_record(), indent=1))
+    else:
+        main()

@@ -4,6 +4,7 @@
 #   kt        --kernel-trace --stats of the default bench line (all single-GPU BASELINE configs in one run)
 #   pmc_hh    FETCH_SIZE / WRITE_SIZE / SQ passes on the headline (random/random, 65 536 games)
 #   pmc_cfg3  the same passes on config 3 (player 2 = computer, flight look-up tables)
+#   pmc_cfg3q the same passes on config 3 with the power-hit table alone (the landing point predicted in the kernel)
 #   pmc_cfg3c the same passes on config 3 with the flight predictors computed in the kernel (scout-wave launch)
 #   pmc_big   FETCH_SIZE / WRITE_SIZE at 524 288 games (config 4's total size: past the Infinity Cache)
 #   kt_roll   --kernel-trace --stats of pz_rollout_random / pz_step_many (k = 32)
@@ -22,11 +23,13 @@
 set -u
 TAG=${1:?tag}
 shift
-SECTIONS=${*:-kt kt_hh pmc_hh pmc_cfg3 pmc_cfg3c pmc_big pmc_more kt_roll pmc_roll pmc_pk pmc_pkbig pmc_ph calib}
+SECTIONS=${*:-kt kt_hh pmc_hh pmc_cfg3 pmc_cfg3q pmc_cfg3c pmc_big pmc_more kt_roll pmc_roll pmc_pk pmc_pkbig pmc_ph calib}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 PY=python3
+# the build the counters are collected on, recorded BEFORE the first run (pmc_summary.py refuses another one afterwards)
+$PY tools/pmc_summary.py --record-build "$OUT/build_at_collection.json" || { echo "could not record the build"; exit 1; }
 SQ_A="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 SQ_B="SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS"
 
@@ -58,6 +61,7 @@ for s in $SECTIONS; do
     kt) run kt --kernel-trace --stats -- $PY bench.py --no-cpu || exit 1 ;;
     pmc_hh) pmc_set hh --no-cpu --no-configs --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1 ;;
     pmc_cfg3) pmc_set cfg3 --no-cpu --no-configs --p2-computer --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1 ;;
+    pmc_cfg3q) pmc_set cfg3q --no-cpu --no-configs --p2-computer --flight-tables power_hit --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1 ;;
     pmc_cfg3c) pmc_set cfg3c --no-cpu --no-configs --p2-computer --no-flight-tables --steps 40 --warmup 10 --burn-in 512 --launch cabi || exit 1 ;;
     pmc_big)
         run big_fetch --kernel-trace --pmc FETCH_SIZE -- $PY bench.py --no-cpu --no-configs --num-envs 524288 --steps 30 --warmup 10 --burn-in 256 --launch cabi || exit 1
