@@ -745,11 +745,17 @@ def test_randomized_config_sweep_vs_oracle(oracle):
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     tables_ref = C.byref(flight_tables(dev)[0])
+    hit_only = flight_tables(dev, landing=False)[0]  # (ABI 10: the 82 MB power-hit table alone)
+    hit_only_ref = C.byref(hit_only)
     trials = int(os.environ.get("PZ_SWEEP_TRIALS", "60"))  # a one-off long run is kept under profiles/
     for trial in range(trials):
         if trial and trial % 5000 == 0:  # (a long run says that it is alive: the GPU box kills a silent command as hung)
             print(f"[sweep] {trial} of {trials} configurations bit-exact so far", flush=True)
-        tb = tables_ref if rnd.random() < 0.5 else None  # flight look-up tables or computed predictors
+        # both flight look-up tables, the power-hit table alone, or computed predictors
+        tb = rnd.choice([tables_ref, tables_ref, hit_only_ref, None, None])
+        # (ABI 10) the element type of pz_step's action vectors: int32, int64, uint8, int16
+        act_name = rnd.choice(["int32", "int32", "int64", "int64", "uint8", "int16"])
+        act_dtype = getattr(torch, act_name)
         n = rnd.choice([1, 2, 3, 31, 63, 64, 65, 100, 127, 128, 129, 255, 300, 511, 640, 700])
         stride = n + rnd.choice([0, 0, 1, 7, 64, 130])
         k = dict(winning_score=rnd.choice([1, 1, 2, 3]), serve=rnd.choice(["winner", "alternate", "random"]),
@@ -832,14 +838,16 @@ def test_randomized_config_sweep_vs_oracle(oracle):
                     dst.copy_(src[-1])  # the single-frame buffers of this test follow the last frame
                 t += kk
             elif mode == "step":
+                cfg.action_format = _native.ACTION_FORMATS[act_name]
                 for _ in range(15):
                     a1, a2 = oracle.random_actions(n, k["env_id_base"], aseed, t, n_act)
-                    d1, d2 = torch.as_tensor(a1, device=dev), torch.as_tensor(a2, device=dev)
+                    d1, d2 = torch.as_tensor(a1, device=dev).to(act_dtype), torch.as_tensor(a2, device=dev).to(act_dtype)
                     assert lib.pz_step(state.data_ptr(), n, stride, C.byref(cfg), d1.data_ptr(), d2.data_ptr(),
                                        obs[0].data_ptr(), obs[1].data_ptr(), rew[0].data_ptr(), rew[1].data_ptr(),
                                        term.data_ptr(), sp, tb, stream) == 0
                     ref.step(a1, a2)
                     t += 1
+                cfg.action_format = 0  # (pz_step_many parks int32 rows)
             else:
                 kk = 1 if mode == "random" else rnd.choice([2, 5, 17])
                 reps = 12 if mode == "random" else 2
@@ -850,7 +858,8 @@ def test_randomized_config_sweep_vs_oracle(oracle):
                     ref.rollout_random(aseed, t, kk)
                     t += kk
             torch.cuda.synchronize()
-            ctx = (trial, phase, mode, n, stride, tb is not None, packed, k)
+            ctx = (trial, phase, mode, n, stride, "none" if tb is None else ("both" if tb is tables_ref else "power_hit"),
+                   act_name, packed, k)
             got, untouched = columns()
             assert np.array_equal(got, ref.state), ctx
             assert untouched, ctx

@@ -10,6 +10,7 @@
 #   kt_roll   --kernel-trace --stats of pz_rollout_random / pz_step_many (k = 32)
 #   pmc_roll  the four passes on the k-frame kernels (pz_rollout_random human and player 2 = computer, pz_step_many; k = 32)
 #   kt_hh     --kernel-trace --stats of the headline workload ALONE (no other config shares its kernel row)
+#   kt_cfg3   --kernel-trace --stats of config 3 on both tables ALONE (in `kt` its kernel row also holds the power-hit-table runs)
 #   calib     FETCH_SIZE / WRITE_SIZE on known-byte kernels of the step kernels' access widths (tools/calib_traffic.hip)
 #   pmc_more  FETCH_SIZE / WRITE_SIZE of the remaining bench entries: config 2 (4 096 games), config 5 (fused wrappers),
 #             config 3 on the packed format, int32 state + int16 observations
@@ -23,7 +24,7 @@
 set -u
 TAG=${1:?tag}
 shift
-SECTIONS=${*:-kt kt_hh pmc_hh pmc_cfg3 pmc_cfg3q pmc_cfg3c pmc_big pmc_more kt_roll pmc_roll pmc_pk pmc_pkbig pmc_ph calib}
+SECTIONS=${*:-kt kt_hh kt_cfg3 pmc_hh pmc_cfg3 pmc_cfg3q pmc_cfg3c pmc_big pmc_more kt_roll pmc_roll pmc_pk pmc_pkbig pmc_ph calib}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -90,6 +91,7 @@ for s in $SECTIONS; do
     kt_roll) run roll --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --rollouts || exit 1 ;;
     pmc_roll) pmc_set roll --no-cpu --no-configs --rollouts || exit 1 ;;
     kt_hh) run hh_kt --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs || exit 1 ;;
+    kt_cfg3) run cfg3_kt --kernel-trace --stats -- $PY bench.py --no-cpu --no-configs --p2-computer || exit 1 ;;
     calib)
         [ -x tools/bin/calib_traffic ] || { mkdir -p tools/bin && hipcc -O3 --offload-arch=gfx950 tools/calib_traffic.hip -o tools/bin/calib_traffic; } || exit 1
         run calib_fetch --kernel-trace --pmc FETCH_SIZE -- tools/bin/calib_traffic || exit 1
