@@ -213,6 +213,22 @@ def _why_not_walk(device, budget: int):
 
 
 def alloc_pair(shape, dtype, device, *, max_spacer_bytes: int = None):
+    """`_alloc_pair_probed` behind a safety net.  Placement moves time, never results, and it leans on things that differ
+    between torch versions and allocators (private memory pools, the caching allocator's block reuse, pool snapshots): if
+    anything in it raises, the caller gets two plainly allocated tensors and ``last_info["error"]`` says why -- the k-frame
+    launches then run at the one-rank rate (a quarter slower), they do not fail."""
+    global last_info
+    try:
+        return _alloc_pair_probed(shape, dtype, device, max_spacer_bytes=max_spacer_bytes)
+    except torch.cuda.OutOfMemoryError:
+        raise  # (the tensors themselves do not fit: not placement's to hide)
+    except Exception as exc:  # noqa: BLE001
+        last_info = {"probed": False, "error": f"{type(exc).__name__}: {exc}"[:200]}
+        device = torch.device(device)
+        return torch.empty(shape, dtype=dtype, device=device), torch.empty(shape, dtype=dtype, device=device)
+
+
+def _alloc_pair_probed(shape, dtype, device, *, max_spacer_bytes: int = None):
     """Two uninitialised tensors of `shape` that do not share a rank of the device memory, when that can be arranged.
 
     Returns (a, b).  `last_info` says what happened: ``probed`` (False for small tensors, while a hipGraph is being

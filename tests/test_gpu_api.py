@@ -654,6 +654,20 @@ def test_placement_gives_up_promptly_and_leaves_the_process_memory_alone(monkeyp
     info, took = run()
     assert info == {"probed": False, "bytes": 32 * 65536 * 35 * 4}
     monkeypatch.delenv("PIKAZOO_PLACE_TRAJECTORIES")
+    # an allocator / torch that does not behave the way the probing assumes (here: the probe itself raises): two plainly
+    # allocated tensors and the reason, never an exception -- placement moves time, not results
+    def broken(*a, **kw):
+        raise RuntimeError("this allocator has no private pools")
+    monkeypatch.setattr(placement, "pair_ratio", broken)
+    info, took = run()
+    assert info["probed"] is False and "no private pools" in info["error"]
+    from pikazoo_amd import pikazoo_v0
+
+    env = pikazoo_v0.env(num_envs=65536, seed=2)
+    env.reset()
+    traj = env.rollout_random(5, 32)
+    assert "error" in env.trajectory_placement and traj["obs"]["player_1"].shape == (32, 65536, 35)
+    monkeypatch.undo()
     # a real walk: whatever it held is back with the driver afterwards, torch's own cache was never emptied
     torch.cuda.synchronize()
     before = torch.cuda.memory_reserved(dev)
