@@ -32,7 +32,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        # any policy producing int32 tensors [n] works; here: the env's own seeded device policy stream for player_1
+        # any policy producing integer tensors [n] works -- int32, or what torch gives by default: int64 (argmax,
+        # multinomial, Categorical.sample), uint8, int16: the launch reads them as they are --; here: the env's own seeded
+        # device policy stream for player_1
         # (player_2 is the rule-based AI; its action entry is read but does not steer it)
         actions = env.unwrapped.random_actions(action_seed=7)
         obs, rewards, terminations, truncations, infos = env.step(actions)
