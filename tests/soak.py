@@ -59,6 +59,11 @@ def main():
         ("p1 computer, flight tables", dict(is_player1_computer=True), dict(is_player1_computer=True), None),
         ("config 3: p2 computer, computed predictors", dict(is_player2_computer=True, flight_tables=False),
          dict(is_player2_computer=True), None),
+        ("config 3: p2 computer, power-hit table only", dict(is_player2_computer=True, flight_tables="power_hit"),
+         dict(is_player2_computer=True), None),
+        ("both computer, power-hit table only", dict(is_player1_computer=True, is_player2_computer=True,
+                                                     flight_tables="power_hit"),
+         dict(is_player1_computer=True, is_player2_computer=True), None),
         ("both computer, random serve, tables", dict(is_player1_computer=True, is_player2_computer=True, serve="random"),
          dict(is_player1_computer=True, is_player2_computer=True, serve="random"), None),
         ("config 5 + RewardInNormalState + RecordEpisodeStatistics", dict(), dict(), "wrappers"),
