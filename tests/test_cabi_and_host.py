@@ -173,6 +173,35 @@ def test_env_and_wrappers_subclass_pettingzoos_classes_when_it_is_importable(tmp
     assert r.returncode == 0 and r.stdout.strip() == f"ok {pettingzoo == 'with'}", r.stdout + r.stderr
 
 
+def test_a_diagnostic_build_is_never_taken_for_the_product(built_lib, tmp_path):
+    """csrc/pz_diagnostic.hpp is the one compile-time switch of the kernel sources.  A library built with it (tools/ab.py,
+    tools/stamps.py: into tools/bin/) says so itself -- pz_build_id() == "diagnostic" --, carries no product id in its
+    file, and is refused by the binding when somebody puts it on the product's path; build.py refuses the flag (checked
+    in test_library_carries_the_digest_of_the_sources_it_was_built_from).  Built here as a subset variant: seconds."""
+    import build as pz_build
+    from pikazoo_amd import _native
+
+    sys.path.insert(0, str(REPO / "tools"))
+    import ab
+
+    variant = tmp_path / "libpikazoo_hip.so"
+    bits = ab.diag_bits(bits=32, subset=705)  # no early stores; single-frame pair kernels, human and player 2 = computer
+    subprocess.check_call([pz_build.hipcc_path(), *pz_build.FLAGS, "-shared", "-fPIC", f"-DPZ_DIAGNOSTIC_BUILD={bits}u",
+                           f"-I{REPO / 'include'}", f"-I{REPO / 'pika-zoo_amd' / 'csrc'}", "-o", str(variant),
+                           str(REPO / "pika-zoo_amd" / "csrc" / "pz_kernels.hip")])
+    lib = C.CDLL(str(variant))
+    lib.pz_build_id.restype = C.c_char_p
+    assert lib.pz_build_id() == b"diagnostic" and lib.pz_abi_version() == _native.ABI_VERSION
+    assert pz_build.library_id(variant) != pz_build.source_id()
+    assert {"pz_debug_read_stamps", "pz_debug_read_frame_stamps"} <= set(dynamic_pz_symbols(variant))  # (the product: not)
+    saved, _native._lib, _native.LIB_PATH = (_native._lib, _native.LIB_PATH), None, variant
+    try:
+        with pytest.raises(_native.PikazooNativeError, match="stale"):
+            _native.load()
+    finally:
+        _native._lib, _native.LIB_PATH = saved
+
+
 def test_header_layout_matches_oracle_layout(oracle):
     """The product header and the oracle declare the state layout independently; keep them equal."""
     from pikazoo_amd import _native
