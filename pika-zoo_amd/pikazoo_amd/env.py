@@ -870,11 +870,12 @@ class raw_env(ParallelEnv):
             raise ValueError(f"actions must have shape [k, 2, {n}]")
         if actions.dtype.is_floating_point or actions.dtype == torch.bool or actions.dtype.is_complex:
             raise TypeError(f"actions must be an integer tensor, got {actions.dtype}")
-        if actions.dtype == torch.int64:
-            # the launch parks the tape from int32 rows; a plain cast would WRAP (2**32 + 3 -> 3) in front of its range
-            # check, so the narrowing saturates first: every out-of-range value stays out of range (-1 or 127), and the
-            # launch counts it like any other (two small torch launches per k frames, no synchronisation)
-            actions = actions.to(dev).clamp(-1, 127).to(torch.int32)
+        if actions.dtype != torch.int32 and actions.dtype.itemsize >= 4:
+            # (int64, and the unsigned 32- / 64-bit types.)  The launch parks the tape from int32 rows; a plain cast would
+            # WRAP (2**32 + 3 -> 3) in front of its range check, so the narrowing saturates first: every out-of-range value
+            # stays out of range (-1 or 127), and the launch counts it like any other (two small torch launches per k
+            # frames, no synchronisation)
+            actions = actions.to(device=dev, dtype=torch.int64).clamp(-1, 127).to(torch.int32)
         if actions.dtype != torch.int32 or actions.device != dev or not actions.is_contiguous():
             actions = actions.to(device=dev, dtype=torch.int32).contiguous()  # (the smaller integer types: widened, exact)
         k = int(actions.shape[0])
