@@ -92,7 +92,7 @@ def _start_rccl(rank: int, world: int, index: int):
     either variable overridden, that is how long a job that left a start behind may still run (`left_behind_anywhere()`
     tells it so; bench.py prints it and ends through `shutdown()`)."""
     try:
-        for var in ("TORCH_NCCL_ASYNC_ERROR_HANDLING", "NCCL_ASYNC_ERROR_HANDLING", "TORCH_NCCL_ENABLE_MONITORING"):
+        for var in ("TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCH_NCCL_ENABLE_MONITORING"):
             os.environ.setdefault(var, "0")
         dev = torch.device("cuda", index)
         torch.cuda.set_device(dev)  # (the current device is per thread)
