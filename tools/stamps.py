@@ -24,6 +24,7 @@ LIB = REPO / "tools" / "bin" / "stamps.so"
 def main():
     args = sys.argv[1:]
     if "--build" in args:
+        LIB.parent.mkdir(parents=True, exist_ok=True)  # (tools/bin/ does not travel to the GPU box: build there)
         subprocess.check_call(["hipcc", *PRODUCT_FLAGS, "-shared", "-fPIC", "-DPZ_DIAGNOSTIC_BUILD=1u",
                                f"-I{REPO / 'include'}", f"-I{REPO / 'pika-zoo_amd' / 'csrc'}", "-o", str(LIB),
                                str(REPO / "pika-zoo_amd" / "csrc" / "pz_kernels.hip")])
